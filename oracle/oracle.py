@@ -1,0 +1,178 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/raster_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by the product package.  Parity status:
+"parity unpinned" against the reference CUDA kernels (see raster_oracle.c header).
+
+The two entry points mirror the reference's torch-C++ operators
+(DGR/rasterize_points.cu:136-222 RasterizeGaussiansCUDA, :224-305
+RasterizeGaussiansBackwardCUDA, :43-134 the ragged-SH inference variant) on numpy
+arrays, so parity tests read like calls into the reference `_C` module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libraster_oracle.so")
+    src = os.path.join(_HERE, "raster_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libraster_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_bin.restype = C.c_int64
+        _LIB.orc_higher_msb.restype = C.c_uint32
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if a.size else None
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+TILE = 16
+
+
+def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+            viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degrees, campos,
+            ragged=None, counter_mode=False, want_ambig=False, ambig_rel=1e-4):
+    """Oracle of `_C.rasterize_gaussians` (and `_variableSH_bands` when `ragged`
+    = (coeffs_num, per_band_count, cumsum_count) and `sh` is the flat ragged buffer).
+    Absent optional inputs: None or empty arrays.  Returns a dict with the public
+    outputs (num_rendered, color[3,H,W], radii[P]) and the internal state needed by
+    `backward` / bit-exact binning checks (keys, point_list, ranges, n_contrib, final_T...)."""
+    L = lib()
+    means3D = _f32(means3D)
+    P = 0 if means3D is None else means3D.shape[0]
+    bg = _f32(bg)
+    colors_precomp, scales, rotations, cov3D_precomp = map(_f32, (colors_precomp, scales, rotations, cov3D_precomp))
+    sh = _f32(sh)
+    opacity = _f32(opacity)
+    vm, pm, campos = _f32(viewmatrix), _f32(projmatrix), _f32(campos)
+    degrees = _i32(degrees) if degrees is not None else np.zeros(P, np.int32)
+    M = 0
+    coeffs = perband = cumsum = None
+    if ragged is not None:
+        coeffs, perband, cumsum = map(_i32, ragged)
+    elif sh is not None:
+        M = sh.shape[1]
+    N = W * H
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    st = dict(P=P, M=M, W=W, H=H, tan_fovx=float(tan_fovx), tan_fovy=float(tan_fovy), mod=float(scale_modifier),
+              bg=bg, means3D=means3D, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+              cov3D_precomp=cov3D_precomp, vm=vm, pm=pm, campos=campos, sh=sh, degrees=degrees)
+    radii = np.zeros(P, np.int32)
+    xy = np.zeros((P, 2), np.float32)
+    depths = np.zeros(P, np.float32)
+    cov3D = np.zeros((P, 6), np.float32)
+    conic_op = np.zeros((P, 4), np.float32)
+    rgb = np.zeros((P, 3), np.float32)
+    clamped = np.zeros((P, 3), np.uint8)
+    tiles = np.zeros(P, np.uint32)
+    color = np.zeros((3, H, W), np.float32)
+    final_T = np.zeros(N, np.float32)
+    n_contrib = np.zeros(N, np.uint32)
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    R = 0
+    keys = np.zeros(0, np.uint64)
+    plist = np.zeros(0, np.uint32)
+    touched = transm = ambig = None
+    if P:
+        L.orc_preprocess(C.c_int(P), C.c_int(M), _p(degrees), _p(means3D), _p(scales), C.c_float(scale_modifier),
+                         _p(rotations), _p(opacity), _p(sh), _p(cov3D_precomp), _p(colors_precomp), _p(vm), _p(pm),
+                         _p(campos), C.c_int(W), C.c_int(H), C.c_float(tan_fovx), C.c_float(tan_fovy),
+                         _p(coeffs), _p(perband), _p(cumsum), _p(radii), _p(xy), _p(depths), _p(cov3D),
+                         _p(conic_op), _p(rgb), _p(clamped), _p(tiles))
+        R = int(L.orc_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
+                          None, None, None))
+        keys = np.zeros(max(R, 1), np.uint64)
+        plist = np.zeros(max(R, 1), np.uint32)
+        L.orc_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
+                  _p(keys), _p(plist), _p(ranges))
+        keys, plist = keys[:R], plist[:R]
+        feat = colors_precomp if colors_precomp is not None else rgb
+        if counter_mode:
+            touched = np.zeros(P, np.int32)
+            transm = np.zeros(P, np.float32)
+        if want_ambig:
+            ambig = np.zeros(N, np.uint8)
+        L.orc_blend_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(plist), _p(xy), _p(feat), _p(conic_op), _p(bg),
+                        _p(color), _p(final_T), _p(n_contrib), _p(touched), _p(transm), _p(ambig),
+                        C.c_float(ambig_rel))
+    else:
+        color[:] = 0  # reference returns the zero-initialised image when P == 0 (rasterize_points.cu:170,185)
+    st.update(radii=radii, xy=xy, depths=depths, cov3D=cov3D, conic_op=conic_op, rgb=rgb, clamped=clamped,
+              tiles_touched=tiles, keys=keys, point_list=plist, ranges=ranges, final_T=final_T,
+              n_contrib=n_contrib, num_rendered=R)
+    out = dict(num_rendered=R, color=color, radii=radii, state=st)
+    if counter_mode:
+        out.update(touched_pixels=touched, transmittance=transm)
+    if want_ambig:
+        out["ambig"] = ambig.reshape(H, W)
+    return out
+
+
+def backward(st, dL_dout_color, lambda_sh_sparsity=0.0):
+    """Oracle of `_C.rasterize_gaussians_backward`: returns the 8 gradient arrays in the
+    reference order (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+    dL_dscales, dL_drotations) as a dict."""
+    L = lib()
+    P, M, W, H = st["P"], st["M"], st["W"], st["H"]
+    g = _f32(dL_dout_color)
+    dmean2D = np.zeros((P, 3), np.float32)
+    dconic = np.zeros((P, 4), np.float32)
+    dopac = np.zeros((P, 1), np.float32)
+    dcolor = np.zeros((P, 3), np.float32)
+    dmean3D = np.zeros((P, 3), np.float32)
+    dcov3D = np.zeros((P, 6), np.float32)
+    dsh = np.zeros((P, M, 3), np.float32)
+    dscale = np.zeros((P, 3), np.float32)
+    drot = np.zeros((P, 4), np.float32)
+    if P:
+        feat = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+        L.orc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]), _p(st["bg"]),
+                        _p(st["xy"]), _p(st["conic_op"]), _p(feat), _p(st["final_T"]), _p(st["n_contrib"]),
+                        _p(g), _p(dmean2D), _p(dconic), _p(dopac), _p(dcolor))
+        cov = st["cov3D_precomp"] if st["cov3D_precomp"] is not None else st["cov3D"]
+        L.orc_preprocess_bwd(C.c_int(P), C.c_int(M), _p(st["degrees"]), _p(st["means3D"]), _p(st["radii"]),
+                             _p(st["sh"]), _p(st["clamped"]), _p(st["scales"]), _p(st["rotations"]),
+                             C.c_float(st["mod"]), _p(cov), _p(st["vm"]), _p(st["pm"]), _p(st["campos"]),
+                             C.c_int(W), C.c_int(H), C.c_float(st["tan_fovx"]), C.c_float(st["tan_fovy"]),
+                             _p(dmean2D), _p(st["conic_op"]), _p(dconic), _p(dmean3D), _p(dcolor), _p(dcov3D),
+                             _p(dsh), _p(dscale), _p(drot), _p(dopac), C.c_float(lambda_sh_sparsity))
+    return dict(dL_dmeans2D=dmean2D, dL_dcolors=dcolor, dL_dopacity=dopac, dL_dmeans3D=dmean3D,
+                dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale, dL_drotations=drot, dL_dconic=dconic)
+
+
+def mark_visible(means3D, viewmatrix):
+    L = lib()
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    out = np.zeros(P, np.uint8)
+    L.orc_mark_visible(C.c_int(P), _p(means3D), _p(_f32(viewmatrix)), _p(out))
+    return out.astype(bool)
+
+
+def higher_msb(n):
+    return int(lib().orc_higher_msb(C.c_uint32(n)))
