@@ -1,0 +1,223 @@
+"""bench.py -- throughput of the rasterizer hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one training iteration of the path BASELINE.json names: forward + backward of the tile rasterizer
+for ONE view per rank (through the autograd boundary `_RasterizeGaussians`, exactly as
+gaussian_renderer.render() + loss.backward() drive it), on the synthetic 500k-Gaussian / 1600x1062 scene of
+SURVEY.md 8d, inputs resident in HBM.  With N > 1 ranks every rank renders a different camera of the same
+replicated scene and the step ends with the RCCL exchange of parameter gradients + densification statistics
+(reduced-3dgs_amd/multiview.py), i.e. weak scaling in views.
+
+Rank 0 prints ONE JSON line: metric/value = whole-job training iterations (views) per second; plus
+`roofline` for the dominant kernel (algorithmic bytes of SURVEY.md 8d / its HIP-event duration measured
+inside the timed region by the library's stage timers) and `cpu_baseline` (the C oracle timed on the host
+cores for one iteration of the same workload; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "reduced-3dgs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import synth_scene as ss  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def stage_bytes(P, R, N, Tn, Kbar):
+    """Algorithmic bytes per launch of each stage, SURVEY.md 8d (terms of B_fwd / B_bwd regrouped by the
+    library's stages; the sort term is the reference-algorithm figure R*24*ceil(bits/8) as 8d prescribes)."""
+    sort_passes = 6 if Tn > 4096 else 5  # ceil((32 + msb(Tn)) / 8) for the tile counts used here
+    return {
+        "preprocess_fwd": P * (48 + 12 * Kbar) + P * 75,
+        "depth_sort_scan": P * 8,
+        "tile_binning": P * 20 + R * 12 + R * 24 * sort_passes + R * 8 + Tn * 8,
+        "blend_fwd": R * 40 + N * 20,
+        "blend_bwd": R * 40 + N * 20 + R * 36,
+        "preprocess_bwd": P * 300 + P * 92 + P * (175 + 24 * Kbar),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="metric_500k_1600x1062", choices=list(ss.WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cameras", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    from multiview import ViewParallelExchange
+
+    w = ss.WORKLOADS[args.workload]
+    W, H, P = w["W"], w["H"], w["P"]
+    N, Tn = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    cam0 = ss.make_camera(W, H, w["f"], None)
+    g = ss.make_gaussians(P, cam0, seed=0, degree_mode=w["degree_mode"])
+    Kbar = float(((g["degrees"].reshape(-1) + 1) ** 2).mean())
+
+    def dv(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+    leaves = {k: dv(g[k]).requires_grad_() for k in ("means3D", "opacity", "scales", "rotations", "sh")}
+    degrees = dv(g["degrees"])
+    bg = dv(np.zeros(3, np.float32))
+    dl = dv(ss.upstream_grad(W, H, seed=1))
+    empty = torch.Tensor([])
+    cams = [cam0] + [ss.make_camera(W, H, w["f"], s) for s in range(1, args.cameras)]
+    settings = [dgr.GaussianRasterizationSettings(H, W, c.tanfovx, c.tanfovy, bg, 1.0, dv(c.world_view_transform),
+                                                  dv(c.full_proj_transform), 3, dv(c.camera_center), False, False)
+                for c in cams]
+    exch = ViewParallelExchange({"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)},
+                                P, device) if world > 1 else None
+
+    def cam_index(step):
+        return (step * world + rank) % len(cams)
+
+    def train_step(step):
+        for t in leaves.values():
+            t.grad = None
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0  # gaussian_renderer/__init__.py:27
+        means2D.retain_grad()
+        color, radii = dgr.rasterize_gaussians(leaves["means3D"], means2D, leaves["sh"], degrees, empty,
+                                               leaves["opacity"], leaves["scales"], leaves["rotations"], empty,
+                                               settings[cam_index(step)], 0.0)
+        color.backward(dl)
+        if exch is not None:
+            exch.pack({k: v.grad for k, v in leaves.items()}, means2D.grad, radii)
+            exch.exchange()
+        return radii
+
+    # num_rendered per camera (property of the input; every per-pair byte term scales with it)
+    Rs, Vs = [], []
+    with torch.no_grad():
+        for s_ in settings:
+            out = _C.rasterize_gaussians(s_.bg, leaves["means3D"], empty, leaves["opacity"], leaves["scales"],
+                                         leaves["rotations"], 1.0, empty, s_.viewmatrix, s_.projmatrix, s_.tanfovx,
+                                         s_.tanfovy, H, W, leaves["sh"], degrees, s_.campos, False, False)
+            Rs.append(out[0])
+            Vs.append(int((out[2] > 0).sum()))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        train_step(i)
+    torch.cuda.synchronize()
+    _C.profile_enable(True)
+    _C.profile_read()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        train_step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _C.profile_read()
+    _C.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # render-only throughput (render.py's FPS path: forward under no_grad), after the timed region
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        for i in range(args.steps):
+            s_ = settings[cam_index(i)]
+            _C.rasterize_gaussians(s_.bg, leaves["means3D"], empty, leaves["opacity"], leaves["scales"],
+                                   leaves["rotations"], 1.0, empty, s_.viewmatrix, s_.projmatrix, s_.tanfovx,
+                                   s_.tanfovy, H, W, leaves["sh"], degrees, s_.campos, False, False)
+        torch.cuda.synchronize()
+        render_s = time.perf_counter() - tr0
+
+    used = [cam_index(args.warmup + i) for i in range(args.steps)]
+    R_mean = float(np.mean([Rs[k] for k in used]))
+    V_mean = float(np.mean([Vs[k] for k in used]))
+    sb = stage_bytes(P, R_mean, N, Tn, Kbar)
+    stages = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt:
+            avg_ms = ms / cnt
+            stages[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "alg_bytes": int(sb[name]),
+                            "GBps": round(sb[name] / (avg_ms * 1e-3) / 1e9, 1)}
+    dom = max(stages, key=lambda k: stages[k]["avg_ms"]) if stages else None
+    roofline = None
+    if dom:
+        A = stages[dom]["GBps"]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(A / HBM_PEAK_GBS, 4), "traffic": None}
+    iters_per_s = args.steps * world / elapsed
+    B_iter = P * (718 + 36 * Kbar) + R_mean * 280 + N * 40
+    result = {
+        "metric": "train iters/s (fwd+bwd) + Mpix/s render, 500k Gaussians @1600x1062",
+        "value": round(iters_per_s, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "gaussians": P, "width": W, "height": H, "sh_degree": 3,
+                   "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
+                   "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                   "exchange": "RCCL reduce-scatter+all-gather of 59 fp32 grads + 2 stats / Gaussian, MAX radii"
+                   if world > 1 else None},
+        "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
+        "render_fps": round(args.steps / render_s, 1),
+        "roofline": roofline,
+        "iter_roofline": {"B_iter_bytes": int(B_iter), "achieved_GBps": round(B_iter * iters_per_s / world / 1e9, 1),
+                          "frac_of_8TBps": round(B_iter * iters_per_s / world / 8e12, 4)},
+        "stages": stages,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        c = cams[0]
+        dl_np = ss.upstream_grad(W, H, seed=1)
+        tc0 = time.perf_counter()
+        ref = orc.forward(np.zeros(3, np.float32), g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0,
+                          None, c.world_view_transform, c.full_proj_transform, c.tanfovx, c.tanfovy, H, W, g["sh"],
+                          g["degrees"], c.camera_center)
+        tc1 = time.perf_counter()
+        orc.backward(ref["state"], dl_np, 0.0)
+        tc2 = time.perf_counter()
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        result["cpu_baseline"] = {
+            "value": round(1.0 / (tc2 - tc0), 4), "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"1 full fwd+bwd iteration of the same workload (camera 0) by the C oracle "
+                      f"(OpenMP over pixels/tiles in the blend stages, per-Gaussian stages scalar): "
+                      f"fwd {tc1 - tc0:.2f} s, bwd {tc2 - tc1:.2f} s"}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

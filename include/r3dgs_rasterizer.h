@@ -1,0 +1,121 @@
+/*
+ * r3dgs_rasterizer.h -- C ABI of the MI355X-native differentiable Gaussian-splatting rasterizer
+ * (shared library libr3dgs_hip.so, built from reduced-3dgs_amd/csrc/ for gfx950).
+ *
+ * This is the drop-in boundary for the hot path of graphdeco-inria/reduced-3dgs: each entry point
+ * replaces one static method of `CudaRasterizer::Rasterizer`
+ * (submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:20-117), with the same argument
+ * order and meaning, expressed in plain C:
+ *   - `std::function<char*(size_t)>` allocator callbacks  ->  r3dgs_alloc_fn + user pointer
+ *   - `bool`                                               ->  int (0 / 1)
+ *   - an explicit HIP stream (`void*` = hipStream_t; the reference uses the legacy default stream)
+ *   - errors: the reference throws std::runtime_error; here functions return a negative status and
+ *     r3dgs_last_error() returns the message (thread-local).  A host shim turns that into the
+ *     exception its language expects.
+ * All pointers are DEVICE pointers (fp32 / int32, contiguous) unless stated otherwise; optional inputs
+ * are NULL when absent (the reference tests `ptr != nullptr`, forward.cu:403,441).
+ * No torch / HIP types appear in any signature.
+ */
+#ifndef R3DGS_RASTERIZER_H
+#define R3DGS_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Resizable-buffer callback: must return a device pointer to at least `bytes` bytes that stays valid
+ * until the matching r3dgs_backward call.  Replaces resizeFunctional() of rasterize_points.cu:33-41. */
+typedef char* (*r3dgs_alloc_fn)(size_t bytes, void* user);
+
+/* Library identification string, e.g. "r3dgs-hip gfx950 0.1". Host memory, never freed. */
+const char* r3dgs_version(void);
+
+/* Message of the last failed call on this thread ("" if none). Host memory owned by the library. */
+const char* r3dgs_last_error(void);
+
+/* Sizes of the three opaque state blobs (the reference's required<GeometryState>(P) etc.,
+ * rasterizer_impl.h:66-72).  Layouts are private to the library. */
+size_t r3dgs_geometry_bytes(int P);
+size_t r3dgs_binning_bytes(int num_rendered);
+size_t r3dgs_image_bytes(int width, int height);
+
+/* Rasterizer::markVisible (rasterizer.h:25-30, rasterizer_impl.cu:149-161): present[i] = view-space z > 0.2.
+ * `present` is a device array of P bytes (0/1).  Returns 0 or a negative status. */
+int r3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                       unsigned char* present, void* stream);
+
+/* Rasterizer::forward (rasterizer.h:31-56, rasterizer_impl.cu:359-504).
+ * Returns num_rendered (>= 0) or a negative status.  Performs ONE host synchronisation on `stream`
+ * (num_rendered sizes the binning blob, like the reference's cudaMemcpy at rasterizer_impl.cu:446).
+ *   D        : per-Gaussian SH degree [P] (int32)
+ *   M        : SH coefficients per Gaussian in the dense `shs` tensor [P, M, 3] (<= 16)
+ *   opacities: RAW (pre-sigmoid); scales: ACTIVATED; rotations: UNIT quaternions (r,x,y,z)
+ *   viewmatrix / projmatrix: 4x4 in the reference's transposed layout (scene/cameras.py:54-56)
+ *   out_color: [3, H, W], fully written;  radii: [P] int32 or NULL
+ *   out_touched_pixels [P] int32 / out_transmittance [P] fp32: accumulated into (caller zeroes) when
+ *     calculate_mean_transmittance != 0 (forward.cu:560-564), else ignored
+ *   prefiltered: accepted for signature parity and ignored (the reference only uses it to trap) */
+int r3dgs_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer,
+                  void* binning_user, r3dgs_alloc_fn imageBuffer, void* image_user, int P, const int* D, int M,
+                  const float* background, int width, int height, const float* means3D, const float* shs,
+                  const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                  const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                  float* out_color, int* out_touched_pixels, float* out_transmittance, int* radii,
+                  int calculate_mean_transmittance, int debug, void* stream);
+
+/* Rasterizer::inferenceForward (rasterizer.h:89-116, rasterizer_impl.cu:206-355): forward with the ragged,
+ * degree-sorted SH buffer of the variable-SH-band inference path (forward.cu:19-36).
+ * coeffsNum / perBandPrimitiveCount / cumSumPrimitiveCount: device int32[bandsNum], bandsNum == 4. */
+int r3dgs_inference_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer,
+                            void* binning_user, r3dgs_alloc_fn imageBuffer, void* image_user, int P, const int* D,
+                            int bandsNum, const int* coeffsNum, const int* perBandPrimitiveCount,
+                            const int* cumSumPrimitiveCount, const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                            int prefiltered, float* out_color, int* out_touched_pixels, float* out_transmittance,
+                            int* radii, int calculate_mean_transmittance, int debug, void* stream);
+
+/* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
+ * No host synchronisation.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
+ * rasterize_points.cu:245; the multiplier lambda / (visible * 45) is formed on the device).
+ * Every element of every output is written (zeros where the reference relies on zero-initialised
+ * tensors), so outputs may be uninitialised.  dL_dconic ([P,2,2]) may be NULL.
+ * Shapes: dL_dpix [3,H,W]; dL_dmean2D [P,3]; dL_dopacity [P]; dL_dcolor [P,3]; dL_dmean3D [P,3];
+ * dL_dcov3D [P,6]; dL_dsh [P,M,3]; dL_dscale [P,3]; dL_drot [P,4]. */
+int r3dgs_backward(int P, const int* D, int M, int R, const float* background, int width, int height,
+                   const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                   const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                   float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                   float lambda_sh_sparsity, int debug, void* stream);
+
+/* Debug accessor for bit-exact checks of the integer stages (SURVEY.md 8b "provide a debug accessor"):
+ * copies, out of the opaque blobs of a finished forward, the sorted list in the REFERENCE's format --
+ * keys[i] = (tile << 32) | depth_bits (rasterizer_impl.cu:110-113), point_list, per-tile ranges,
+ * n_contrib and final T.  Any output pointer may be NULL.  Device pointers. */
+int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+                         char* image_buffer, uint64_t* keys, uint32_t* point_list, uint32_t* ranges /*[Tn][2]*/,
+                         uint32_t* n_contrib, float* final_T, uint32_t* tiles_touched, void* stream);
+
+/* Optional per-stage timing (not in the reference; it times with torch.cuda.Event pairs from Python,
+ * train.py:52-53, gaussian_renderer/__init__.py:95-98).  When enabled, every forward/backward records a
+ * HIP event pair around each stage ON THE CALLER'S STREAM.  r3dgs_profile_read() waits for the recorded
+ * events, writes per-stage total milliseconds and launch counts (arrays of r3dgs_profile_stage_count()
+ * entries, host memory) and resets the counters. */
+int r3dgs_profile_enable(int on);
+int r3dgs_profile_stage_count(void);
+const char* r3dgs_profile_stage_name(int stage);
+int r3dgs_profile_read(double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3DGS_RASTERIZER_H */

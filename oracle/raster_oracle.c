@@ -461,58 +461,76 @@ void orc_blend_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* 
                    const uint32_t* n_contrib, const float* dL_dpix, float* dL_dmean2D /*P*3*/,
                    float* dL_dconic /*P*4*/, float* dL_dopacity /*P*/, float* dL_dcolor /*P*3*/)
 {
-    const int gx = (W + TILE - 1) / TILE;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     double* acc = (double*)calloc((size_t)P * 9, sizeof(double));
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-    for (int py = 0; py < H; py++)
-        for (int px = 0; px < W; px++) {
-            const int tile = (py / TILE) * gx + (px / TILE);
+    /* one tile per task; per-tile partial sums (double) are flushed once per list entry, so the
+     * threads only meet in a few atomic adds and the result does not depend on the thread count
+     * beyond double rounding */
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
             const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
-            const size_t pix = (size_t)W * py + px;
-            const float pxf = (float)px, pyf = (float)py;
-            const float T_final = final_T[pix];
-            float T = T_final;
-            const uint32_t last_contributor = n_contrib[pix];
-            float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0, dpx[3];
-            for (int ch = 0; ch < 3; ch++) dpx[ch] = dL_dpix[(size_t)ch * H * W + pix];
-            /* walk positions last_contributor-1 .. 0 of the tile list (backward.cu:524-526) */
-            for (int64_t pos = (int64_t)last_contributor - 1; pos >= 0; pos--) {
-                const uint32_t id = point_list[r0 + pos];
-                (void)r1;
-                const float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
-                const float* co = conic_op + 4 * id;
-                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                if (power > 0.0f) continue;
-                const float G = expf(power);
-                const float alpha = fminf_(0.99f, co[3] * G);
-                if (alpha < 1.0f / 255.0f) continue;
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                double* a = acc + 9 * (size_t)id;
-                for (int ch = 0; ch < 3; ch++) {
-                    const float c = colors[3 * id + ch];
-                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                    last_color[ch] = c;
-                    dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
-                    a[6 + ch] += (double)(dchannel_dcolor * dpx[ch]);
+            if (r1 <= r0) continue;
+            double* loc = (double*)calloc((size_t)(r1 - r0) * 9, sizeof(double));
+            for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+                for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+                    const size_t pix = (size_t)W * py + px;
+                    const float pxf = (float)px, pyf = (float)py;
+                    const float T_final = final_T[pix];
+                    float T = T_final;
+                    const uint32_t last_contributor = n_contrib[pix];
+                    float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0, dpx[3];
+                    for (int ch = 0; ch < 3; ch++) dpx[ch] = dL_dpix[(size_t)ch * H * W + pix];
+                    /* walk positions last_contributor-1 .. 0 of the tile list (backward.cu:524-526) */
+                    for (int64_t pos = (int64_t)last_contributor - 1; pos >= 0; pos--) {
+                        const uint32_t id = point_list[r0 + pos];
+                        const float dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
+                        const float* co = conic_op + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float G = expf(power);
+                        const float alpha = fminf_(0.99f, co[3] * G);
+                        if (alpha < 1.0f / 255.0f) continue;
+                        T = T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * T;
+                        float dL_dalpha = 0.0f;
+                        double* a = loc + 9 * (size_t)pos;
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float c = colors[3 * id + ch];
+                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            last_color[ch] = c;
+                            dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
+                            a[6 + ch] += (double)(dchannel_dcolor * dpx[ch]);
+                        }
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        float bg_dot = 0;
+                        for (int ch = 0; ch < 3; ch++) bg_dot += bg[ch] * dpx[ch];
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = co[3] * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                        a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                        a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                        a[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                        a[3] += (double)(-0.5f * gdx * dy * dL_dG);
+                        a[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                        a[5] += (double)(G * dL_dalpha);
+                    }
                 }
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                float bg_dot = 0;
-                for (int ch = 0; ch < 3; ch++) bg_dot += bg[ch] * dpx[ch];
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = co[3] * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-                a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
-                a[2] += (double)(-0.5f * gdx * dx * dL_dG);
-                a[3] += (double)(-0.5f * gdx * dy * dL_dG);
-                a[4] += (double)(-0.5f * gdy * dy * dL_dG);
-                a[5] += (double)(G * dL_dalpha);
+            for (uint32_t k = 0; k < r1 - r0; k++) {
+                const double* l = loc + 9 * (size_t)k;
+                double* a = acc + 9 * (size_t)point_list[r0 + k];
+                for (int c = 0; c < 9; c++)
+                    if (l[c] != 0.0) {
+#pragma omp atomic
+                        a[c] += l[c];
+                    }
             }
+            free(loc);
         }
     for (int i = 0; i < P; i++) {
         const double* a = acc + 9 * (size_t)i;

@@ -1,0 +1,67 @@
+"""Builds libr3dgs_hip.so (the C-ABI rasterizer library) for gfx950 with hipcc, in-tree.
+
+    python reduced-3dgs_amd/build.py [--force]
+
+Per-translation-unit flags matter for parity:
+  * preprocess*.hip : -ffp-contract=off + correctly rounded fp32 divide/sqrt, so the integer outputs
+                      (radii, tile rects, tiles_touched, sort order) are reproducible bit-for-bit;
+  * blend.hip       : contraction allowed (FMA) + hardware exp: compared to 1e-5 / 1e-4, not bitwise;
+  * -munsafe-fp-atomics: float atomicAdd lowers to global_atomic_add_f32 instead of a CAS loop.
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libr3dgs_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+          "-Wno-unused-function", "-I", CSRC]
+EXACT = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+UNITS = {
+    "preprocess.hip": EXACT,
+    "preprocess_bwd.hip": EXACT,
+    "binning.hip": [],
+    "blend.hip": ["-ffp-contract=fast"],
+    "capi.hip": [],
+}
+HEADERS = ["common.h", "gauss_math.h", "blend_math.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h")]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=True):
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)])
+    jobs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append(([HIPCC] + COMMON + extra + ["-c", s, "-o", o], src))
+    def run(job):
+        cmd, name = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r.returncode, r.stdout + r.stderr
+    failed = False
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for name, rc, log in ex.map(run, jobs):
+            if verbose and (rc != 0 or log.strip()):
+                print(f"--- {name} (rc={rc})\n{log}")
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in UNITS]
+    if jobs or force or not os.path.exists(OUT):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

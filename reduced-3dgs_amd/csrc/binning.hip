@@ -1,0 +1,174 @@
+// binning.hip -- tile binning: which Gaussians touch which 16x16 tile, in front-to-back order.
+//
+// Replaces rasterizer_impl.cu:441 (InclusiveSum), :78-119 duplicateWithKeys, :465-473 the 64-bit
+// (tile|depth) radix sort and :124-146 identifyTileRanges of
+// /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer, with the SAME resulting order
+// (tile-major; inside a tile ascending depth bits, ties by ascending Gaussian index) but far less sort
+// traffic, which is what bounds this stage on MI355X:
+//
+//   reference: sort R (u64 key, u32 value) pairs on 32+log2(tiles) bits  -> ~6 passes x 24 B x R
+//   here:      1. stable sort the P Gaussians once by their 32 depth bits (4 passes x 16 B x P, P << R)
+//              2. inclusive scan of tiles_touched in that depth order
+//              3. emit the R (tile, id) pairs in depth order, load-balanced per wave
+//              4. stable sort the pairs on the log2(tiles) tile bits only (2 passes x 16 B x R)
+//   Stability of both sorts + ascending-id input order reproduces the reference's tie-break exactly.
+//
+// The sorts / scan use rocPRIM device primitives (onesweep radix sort, decoupled-lookback scan).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace r3 {
+
+struct GatherTiles {
+    const uint32_t* tiles;
+    __host__ __device__ uint32_t operator()(uint32_t id) const { return tiles[id]; }
+};
+
+size_t depth_sort_temp_bytes(size_t P)
+{
+    size_t a = 0, b = 0;
+    uint32_t* n = nullptr;
+    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, rocprim::counting_iterator<uint32_t>(0), n, P, 0, 32));
+    auto it = rocprim::make_transform_iterator(n, GatherTiles{n});
+    R3_HIP(rocprim::inclusive_scan(nullptr, b, it, n, P, rocprim::plus<uint32_t>()));
+    return (a > b ? a : b) + 256;
+}
+
+size_t tile_sort_temp_bytes(size_t R)
+{
+    size_t a = 0;
+    uint32_t* n = nullptr;
+    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
+    return a + 256;
+}
+
+void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
+{
+    size_t bytes = g.temp_bytes;
+    R3_HIP(rocprim::radix_sort_pairs(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
+                                     g.order, (size_t)P, 0, 32, s));
+    bytes = g.temp_bytes;
+    auto it = rocprim::make_transform_iterator(g.order, GatherTiles{g.tiles});
+    R3_HIP(rocprim::inclusive_scan(g.temp, bytes, it, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
+}
+
+// rasterizer_impl.cu:43-58 getHigherMsb
+static uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb)
+            msb += step;
+        else
+            msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// Pair emission, one wave per 64 depth-consecutive Gaussians.  Instead of one thread looping over all
+// tiles of its Gaussian (hundreds for a large splat while its neighbours idle), the wave flattens the
+// 64 tile counts into one range and every lane writes every 64th output: coalesced stores, no imbalance.
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, const uint32_t* __restrict__ order,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ tiles,
+                                                         const ushort4* __restrict__ rect, int gx,
+                                                         uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out)
+{
+    __shared__ uint32_t s_end[4][64];
+    __shared__ uint32_t s_id[4][64];
+    __shared__ ushort4 s_rect[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    uint32_t end, cnt = 0, id = 0;
+    ushort4 rc = make_ushort4(0, 0, 0, 0);
+    if (j < P) {
+        id = order[j];
+        end = offsets[j];
+        cnt = tiles[id];
+        rc = rect[id];
+    } else {
+        end = offsets[P - 1];
+    }
+    s_end[wave][lane] = end;
+    s_id[wave][lane] = id;
+    s_rect[wave][lane] = rc;
+    const uint32_t wave_begin = __shfl(end - cnt, 0);
+    const uint32_t wave_end = __shfl(end, 63);
+    __syncthreads();
+    const uint32_t total = wave_end - wave_begin;
+    for (uint32_t t = lane; t < total; t += 64) {
+        const uint32_t pos = wave_begin + t;
+        int lo = 0, hi = 63;  // smallest s with s_end[s] > pos
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_end[wave][mid] > pos)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const uint32_t start = lo == 0 ? wave_begin : s_end[wave][lo - 1];
+        const uint32_t local = pos - start;
+        const ushort4 r = s_rect[wave][lo];
+        const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
+        const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x) order, rasterizer_impl.cu:106-117
+        tile_out[pos] = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
+        id_out[pos] = s_id[wave][lo];
+    }
+}
+
+// rasterizer_impl.cu:124-146 identifyTileRanges on 32-bit tile keys
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_sorted, uint2* ranges)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = tile_sorted[i];
+    if (i == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = tile_sorted[i - 1];
+        if (cur != prev) {
+            ranges[prev].y = i;
+            ranges[cur].x = i;
+        }
+    }
+    if (i == R - 1) ranges[cur].y = R;
+}
+
+void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s)
+{
+    const size_t Tn = (size_t)gx * gy;
+    R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
+    if (R <= 0) return;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.order, g.offsets, g.tiles,
+                       g.rect, gx, b.tile_in, b.gauss_in);
+    const int bits = (int)higher_msb((uint32_t)Tn);
+    size_t bytes = b.temp_bytes;
+    R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
+                                     bits, s));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, img.ranges);
+}
+
+// debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list
+__global__ __launch_bounds__(256) void export_keys_kernel(int R, const uint32_t* __restrict__ tile_sorted,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const GRec* __restrict__ rec, uint64_t* keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(rec[point_list[i]].depth);
+}
+
+void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s)
+{
+    if (R <= 0) return;
+    hipLaunchKernelGGL(export_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, b.point_list,
+                       g.rec, keys_out);
+}
+
+}  // namespace r3

@@ -1,0 +1,346 @@
+// blend.hip -- per-tile front-to-back alpha blending (forward) and its per-pixel backward, gfx950.
+//
+// Replaces cuda_rasterizer/forward.cu:461-582 renderCUDA and backward.cu:437-595 renderCUDA of
+// /root/reference/submodules/diff-gaussian-rasterization.
+//
+// MI355X-first structure (not the reference's 256-thread block with two barriers per chunk):
+//   * ONE 64-lane wave owns a whole pixel region of a tile and streams the tile's list on its own:
+//     no cross-wave barriers, single-wave workgroups, so the CU's 8-deep wave slots hide the gather
+//     latency.  Each lane carries PPL pixels (PPL 8x8 quadrants of the 16x16 tile), so every LDS
+//     broadcast read of a Gaussian record is amortised over PPL pixels per lane (the LDS pipe, shared
+//     by the CU's 4 SIMDs, would otherwise co-limit with the VALU).
+//   * the list is fetched 64 entries at a time: lane j gathers the 48-byte GRec of entry j (one
+//     cache-line-local load instead of the reference's five scattered arrays) into LDS.
+//   * backward: the 9 partial sums of a Gaussian are first added over the lane's PPL pixels, reduced
+//     across the wave with DPP row operations (no LDS, no atomics), parked in LDS per list entry, and
+//     flushed once per 64-entry chunk with all 64 lanes issuing the global float atomics -- one atomic
+//     per (tile region, Gaussian, component) instead of one per (pixel, Gaussian, component), and none at
+//     all for entries that touched no pixel of the region.
+//   * workgroup ids are remapped so that consecutive tiles run on the same XCD (shared L2 for the
+//     records of Gaussians straddling neighbouring tiles).
+#include "blend_math.h"
+#include "common.h"
+
+namespace r3 {
+
+constexpr int kChunk = 64;
+
+struct LdsRec {  // 48 B, same field order as GRec's first 9 floats
+    float4 a;    // x, y, cA, cB
+    float4 b;    // cC, op, r, g
+    float4 c;    // b, -, -, -
+};
+
+__device__ __forceinline__ Splat load_splat(const LdsRec& r)
+{
+    Splat s;
+    s.x = r.a.x;
+    s.y = r.a.y;
+    s.cA = r.a.z;
+    s.cB = r.a.w;
+    s.cC = r.b.x;
+    s.op = r.b.y;
+    s.r = r.b.z;
+    s.g = r.b.w;
+    s.b = r.c.x;
+    return s;
+}
+
+// consecutive logical ids on one XCD: hardware places workgroup b on XCD b % 8 (speed only, never correctness)
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
+{
+    const uint32_t per = nblocks >> 3;
+    if (b >= per * 8) return b;  // tail
+    return (b & 7u) * per + (b >> 3);
+}
+
+// full-wave sum via DPP; result valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+#define R3_DPP_ADD(ctrl, rmask)                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
+    R3_DPP_ADD(0xb1, 0xf);   // quad_perm [1,0,3,2]
+    R3_DPP_ADD(0x4e, 0xf);   // quad_perm [2,3,0,1]
+    R3_DPP_ADD(0x124, 0xf);  // row_ror:4
+    R3_DPP_ADD(0x128, 0xf);  // row_ror:8   -> every lane of a 16-lane row holds the row sum
+    R3_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    R3_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef R3_DPP_ADD
+    return v;
+}
+
+template <int PPL>
+__device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q, int lane, int* px, int* py)
+{
+    const int b4 = part * PPL + q;  // 8x8 quadrant inside the 16x16 tile
+    *px = tile_x * kTile + (b4 & 1) * 8 + (lane & 7);
+    *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
+}
+
+struct BlendFwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const GRec* rec;
+    int W, H, gx;
+    uint32_t nblocks;
+    const float* bg;
+    float* out_color;
+    float* final_T;
+    uint32_t* n_contrib;
+    int* touched;
+    float* transmittance;
+};
+
+template <int PPL, bool COUNTERS>
+__global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
+{
+    __shared__ LdsRec s_rec[kChunk];
+    __shared__ uint32_t s_id[kChunk];
+    constexpr int PARTS = 4 / PPL;
+    const int lane = threadIdx.x;
+    const uint32_t wg = xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tile = wg / PARTS;
+    const int part = (int)(wg % PARTS);
+    const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
+    const uint2 range = a.ranges[tile];
+
+    float pxf[PPL], pyf[PPL];
+    FwdPix pix[PPL];
+    bool inside[PPL];
+    uint32_t live = 0;  // bit q set while pixel q still blends
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        int px, py;
+        pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
+        pxf[q] = (float)px;
+        pyf[q] = (float)py;
+        inside[q] = px < a.W && py < a.H;
+        pix[q].T = 1.0f;
+        pix[q].C0 = pix[q].C1 = pix[q].C2 = 0.f;
+        pix[q].last = 0;
+        if (inside[q]) live |= 1u << q;
+    }
+
+    for (uint32_t base = range.x; base < range.y; base += kChunk) {
+        if (__ballot(live != 0) == 0ull) break;  // every pixel of the region saturated
+        __syncthreads();
+        const uint32_t idx = base + lane;
+        if (idx < range.y) {
+            const uint32_t id = a.point_list[idx];
+            const float4* g = reinterpret_cast<const float4*>(a.rec + id);
+            s_rec[lane].a = g[0];
+            s_rec[lane].b = g[1];
+            s_rec[lane].c = g[2];
+            s_id[lane] = id;
+        }
+        __syncthreads();
+        const int n = (int)min((uint32_t)kChunk, range.y - base);
+        for (int j = 0; j < n; j++) {
+            const Splat s = load_splat(s_rec[j]);
+            const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
+            int cnt = 0;
+            float tsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                if (live & (1u << q)) {
+                    float Tb;
+                    const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
+                    if (r == 2) live &= ~(1u << q);
+                    if (COUNTERS && r == 1) {
+                        cnt++;
+                        tsum += Tb;
+                    }
+                }
+            }
+            if (COUNTERS) {  // forward.cu:560-564, one atomic pair per (region, Gaussian) instead of per pixel
+                if (__ballot(cnt != 0) != 0ull) {
+                    const float c = wave_sum_to_lane63((float)cnt);
+                    const float t = wave_sum_to_lane63(tsum);
+                    if (lane == 63) {
+                        atomicAdd(a.touched + s_id[j], (int)c);
+                        atomicAdd(a.transmittance + s_id[j], t);
+                    }
+                }
+            }
+        }
+    }
+    const size_t plane = (size_t)a.W * a.H;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        if (inside[q]) {
+            const size_t p = (size_t)a.W * (size_t)pyf[q] + (size_t)pxf[q];
+            a.final_T[p] = pix[q].T;
+            a.n_contrib[p] = pix[q].last;
+            a.out_color[p] = pix[q].C0 + pix[q].T * bg0;
+            a.out_color[plane + p] = pix[q].C1 + pix[q].T * bg1;
+            a.out_color[2 * plane + p] = pix[q].C2 + pix[q].T * bg2;
+        }
+    }
+}
+
+void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
+                          ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s)
+{
+    constexpr int PPL = 4;
+    BlendFwdArgs a;
+    a.ranges = img.ranges;
+    a.point_list = b.point_list;
+    a.rec = g.rec;
+    a.W = view.W;
+    a.H = view.H;
+    a.gx = (view.W + kTile - 1) / kTile;
+    a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
+    a.bg = view.bg;
+    a.out_color = out_color;
+    a.final_T = img.final_T;
+    a.n_contrib = img.n_contrib;
+    a.touched = touched;
+    a.transmittance = transmittance;
+    if (touched)
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct BlendBwdArgs {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const GRec* rec;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    int W, H, gx;
+    uint32_t nblocks;
+    const float* bg;
+    float* acc;  // [P][kAccStride]: mx, my, cA, cB, cC, op, r, g, b
+};
+
+constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
+
+template <int PPL>
+__global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
+{
+    __shared__ LdsRec s_rec[kChunk];
+    __shared__ uint32_t s_id[kChunk];
+    __shared__ float s_grad[kChunk * kGradStride];
+    constexpr int PARTS = 4 / PPL;
+    const int lane = threadIdx.x;
+    const uint32_t wg = xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tile = wg / PARTS;
+    const int part = (int)(wg % PARTS);
+    const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
+    const uint2 range = a.ranges[tile];
+    const size_t plane = (size_t)a.W * a.H;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+
+    float pxf[PPL], pyf[PPL];
+    BwdPix pix[PPL];
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        int px, py;
+        pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
+        pxf[q] = (float)px;
+        pyf[q] = (float)py;
+        const bool inside = px < a.W && py < a.H;
+        BwdPix& p = pix[q];
+        p.acc0 = p.acc1 = p.acc2 = 0.f;
+        p.lc0 = p.lc1 = p.lc2 = p.la = 0.f;
+        p.T = p.T_final = p.bg_dot = 0.f;
+        p.g0 = p.g1 = p.g2 = 0.f;
+        p.last = 0;
+        if (inside) {
+            const size_t id = (size_t)a.W * py + px;
+            p.T_final = a.final_T[id];
+            p.T = p.T_final;
+            p.last = a.n_contrib[id];
+            p.g0 = a.dL_dpix[id];
+            p.g1 = a.dL_dpix[plane + id];
+            p.g2 = a.dL_dpix[2 * plane + id];
+            p.bg_dot = bg0 * p.g0 + bg1 * p.g1 + bg2 * p.g2;
+        }
+        lmax = max(lmax, p.last);
+    }
+    // deepest contributor of the whole region: nothing behind it matters to any pixel here
+    for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off));
+    if (lmax == 0) return;
+
+    const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
+    for (int cbase = (int)((lmax - 1) / kChunk) * kChunk; cbase >= 0; cbase -= kChunk) {
+        __syncthreads();
+        const uint32_t pos_l = (uint32_t)cbase + (uint32_t)lane;
+        if (pos_l < lmax) {
+            const uint32_t id = a.point_list[range.x + pos_l];
+            const float4* g = reinterpret_cast<const float4*>(a.rec + id);
+            s_rec[lane].a = g[0];
+            s_rec[lane].b = g[1];
+            s_rec[lane].c = g[2];
+            s_id[lane] = id;
+        }
+        s_grad[lane * kGradStride + 9] = 0.f;
+        __syncthreads();
+        const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
+        for (int j = n - 1; j >= 0; j--) {
+            const Splat s = load_splat(s_rec[j]);
+            const uint32_t pos = (uint32_t)(cbase + j);
+            SplatGrad sg;
+            sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
+            if (__ballot(any) != 0ull) {
+                const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
+                const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);
+                const float v4 = wave_sum_to_lane63(sg.cC), v5 = wave_sum_to_lane63(sg.op);
+                const float v6 = wave_sum_to_lane63(sg.r), v7 = wave_sum_to_lane63(sg.g);
+                const float v8 = wave_sum_to_lane63(sg.b);
+                if (lane == 63) {
+                    float* d = s_grad + j * kGradStride;
+                    d[0] = v0 * half_w;
+                    d[1] = v1 * half_h;
+                    d[2] = v2;
+                    d[3] = v3;
+                    d[4] = v4;
+                    d[5] = v5;
+                    d[6] = v6;
+                    d[7] = v7;
+                    d[8] = v8;
+                    d[9] = 1.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < n && s_grad[lane * kGradStride + 9] != 0.f) {
+            float* dst = a.acc + (size_t)s_id[lane] * kAccStride;
+            const float* src = s_grad + lane * kGradStride;
+#pragma unroll
+            for (int k = 0; k < 9; k++) atomicAdd(dst + k, src[k]);
+        }
+    }
+}
+
+void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b,
+                           const ImageState& img, const float* dL_dpix, hipStream_t s)
+{
+    constexpr int PPL = 4;
+    BlendBwdArgs a;
+    a.ranges = img.ranges;
+    a.point_list = b.point_list;
+    a.rec = g.rec;
+    a.final_T = img.final_T;
+    a.n_contrib = img.n_contrib;
+    a.dL_dpix = dL_dpix;
+    a.W = view.W;
+    a.H = view.H;
+    a.gx = (view.W + kTile - 1) / kTile;
+    a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
+    a.bg = view.bg;
+    a.acc = g.acc;
+    hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
+}
+
+}  // namespace r3

@@ -1,0 +1,115 @@
+// blend_math.h -- per-(pixel, Gaussian) arithmetic of the alpha-blend forward and backward.
+//
+// __host__ __device__ so that tests/hostcheck/hostcheck.hip can run the very same step functions
+// on the CPU.  The blend translation units are compiled with FMA contraction allowed and the
+// hardware exp (v_exp_f32): results are compared with the oracle to 1e-5 (colour) / 1e-4 (grads),
+// not bit-for-bit.
+//
+// Follows (relative to /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer):
+//   forward.cu:528-570  inner loop of renderCUDA (fwd)   -> fwd_step()
+//   backward.cu:520-593 inner loop of renderCUDA (bwd)   -> bwd_step()
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace r3 {
+
+#ifndef R3_HD
+#define R3_HD __host__ __device__ __forceinline__
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R3_EXP(x) __expf(x)
+#define R3_RCP(x) __builtin_amdgcn_rcpf(x)  // v_rcp_f32, 1 ulp
+#else
+#define R3_EXP(x) expf(x)
+#define R3_RCP(x) (1.0f / (x))
+#endif
+
+// the 9 floats a pixel needs from a Gaussian
+struct Splat {
+    float x, y, cA, cB, cC, op, r, g, b;
+};
+
+struct FwdPix {
+    float T, C0, C1, C2;
+    uint32_t last;  // 1-based list position of the last blended entry (n_contrib)
+};
+
+// One list entry against one pixel.  Returns 0: skipped, 1: blended, 2: pixel saturated (done).
+// `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance the entry saw.
+R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
+{
+    const float dx = s.x - pxf, dy = s.y - pyf;
+    const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
+    if (power > 0.0f) return 0;
+    const float alpha = fminf(0.99f, s.op * R3_EXP(power));
+    if (alpha < 1.0f / 255.0f) return 0;
+    const float test_T = p.T * (1.0f - alpha);
+    if (test_T < 0.0001f) return 2;
+    const float w = alpha * p.T;
+    p.C0 += s.r * w;
+    p.C1 += s.g * w;
+    p.C2 += s.b * w;
+    *T_before = p.T;
+    p.T = test_T;
+    p.last = pos1;
+    return 1;
+}
+
+// per-pixel state of the back-to-front walk
+struct BwdPix {
+    float T, T_final, bg_dot;
+    float acc0, acc1, acc2;      // accum_rec
+    float lc0, lc1, lc2, la;     // last_color, last_alpha
+    float g0, g1, g2;            // dL_dpixel
+    uint32_t last;               // n_contrib
+};
+
+// per-Gaussian partial gradient of one lane (summed over its pixels, then over the wave)
+struct SplatGrad {
+    float mx, my, cA, cB, cC, op, r, g, b;
+};
+
+// One list entry (0-based position `pos`) against one pixel; accumulates into `a`.
+// Returns true when the entry contributed.  dmean2D is accumulated WITHOUT the 0.5*W / 0.5*H
+// viewport factors (backward.cu:498-499); the caller applies them once after the reduction.
+R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
+{
+    if (pos >= p.last) return false;  // behind this pixel's last contributor (backward.cu:524-526)
+    const float dx = s.x - pxf, dy = s.y - pyf;
+    const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
+    if (power > 0.0f) return false;
+    const float G = R3_EXP(power);
+    const float alpha = fminf(0.99f, s.op * G);
+    if (alpha < 1.0f / 255.0f) return false;
+    const float ra = R3_RCP(1.0f - alpha);
+    p.T = p.T * ra;  // T recovered by division (backward.cu:541)
+    const float dch = alpha * p.T;
+    p.acc0 = p.la * p.lc0 + (1.f - p.la) * p.acc0;
+    p.acc1 = p.la * p.lc1 + (1.f - p.la) * p.acc1;
+    p.acc2 = p.la * p.lc2 + (1.f - p.la) * p.acc2;
+    p.lc0 = s.r;
+    p.lc1 = s.g;
+    p.lc2 = s.b;
+    float dL_dalpha = (s.r - p.acc0) * p.g0 + (s.g - p.acc1) * p.g1 + (s.b - p.acc2) * p.g2;
+    a.r += dch * p.g0;
+    a.g += dch * p.g1;
+    a.b += dch * p.g2;
+    dL_dalpha *= p.T;
+    p.la = alpha;
+    dL_dalpha += (-p.T_final * ra) * p.bg_dot;
+    const float dL_dG = s.op * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    const float dG_ddelx = -gdx * s.cA - gdy * s.cB;
+    const float dG_ddely = -gdy * s.cC - gdx * s.cB;
+    a.mx += dL_dG * dG_ddelx;
+    a.my += dL_dG * dG_ddely;
+    a.cA += -0.5f * gdx * dx * dL_dG;
+    a.cB += -0.5f * gdx * dy * dL_dG;
+    a.cC += -0.5f * gdy * dy * dL_dG;
+    a.op += G * dL_dalpha;
+    return true;
+}
+
+}  // namespace r3

@@ -1,0 +1,239 @@
+// common.h -- buffer layouts, launch helpers and error plumbing shared by the HIP translation units.
+//
+// The three caller-owned byte buffers play the role of the reference's GeometryState / BinningState /
+// ImageState blobs (cuda_rasterizer/rasterizer_impl.h:21-73, rasterizer_impl.cu:163-202): produced by
+// forward through allocator callbacks, kept alive by the caller, handed back verbatim to backward.
+// Their internal layout is private to this library and is MI355X-first, not the reference's:
+//   * one 48-byte gather record per Gaussian (GRec) instead of five separate arrays,
+//   * depth-sorted Gaussian order + 32-bit tile keys instead of 64-bit (tile|depth) keys,
+//   * a per-Gaussian gradient accumulator row for the backward.
+// The parts the backward needs sit at the FRONT of each blob so that their offsets do not depend on
+// library temp-storage sizes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "gauss_math.h"
+
+namespace r3 {
+
+constexpr size_t kAlign = 256;
+constexpr int kAccStride = 12;  // floats per Gaussian in the backward accumulator (9 used)
+
+struct GeomHeader {
+    uint32_t visible_count;  // #Gaussians with radii > 0 in this view (rasterizer_impl.cu:549-566)
+    uint32_t num_rendered;   // R
+    uint32_t magic;
+    uint32_t pad[61];
+};
+static_assert(sizeof(GeomHeader) == 256, "header is one 256-B line");
+
+struct Carver {
+    char* p;
+    explicit Carver(char* base)
+        : p(reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + kAlign - 1) & ~(uintptr_t)(kAlign - 1)))
+    {
+    }
+    template <class T>
+    T* take(size_t count)
+    {
+        T* r = reinterpret_cast<T*>(p);
+        size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
+        p += bytes;
+        return r;
+    }
+};
+
+struct GeomState {
+    GeomHeader* header;
+    GRec* rec;            // [P]
+    float* acc;           // [P * kAccStride]   backward accumulators
+    ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
+    uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
+    uint32_t* tiles;      // [P]  tiles_touched
+    uint32_t* key_sorted; // [P]
+    uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
+    uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
+    int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
+    char* temp;           // sort / scan temp storage
+    size_t temp_bytes;
+    static GeomState carve(char* base, size_t P, size_t temp_bytes)
+    {
+        Carver c(base);
+        GeomState g;
+        g.header = c.take<GeomHeader>(1);
+        g.rec = c.take<GRec>(P);
+        g.acc = c.take<float>(P * kAccStride);
+        g.rect = c.take<ushort4>(P);
+        g.depth_key = c.take<uint32_t>(P);
+        g.tiles = c.take<uint32_t>(P);
+        g.key_sorted = c.take<uint32_t>(P);
+        g.order = c.take<uint32_t>(P);
+        g.offsets = c.take<uint32_t>(P);
+        g.radii_internal = c.take<int>(P);
+        g.temp = c.take<char>(temp_bytes);
+        g.temp_bytes = temp_bytes;
+        g.end = c.p;
+        return g;
+    }
+    char* end;
+};
+
+struct BinState {
+    uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
+    uint32_t* tile_sorted; // [R] tile id of each entry
+    uint32_t* tile_in;     // [R]
+    uint32_t* gauss_in;    // [R]
+    char* temp;
+    size_t temp_bytes;
+    char* end;
+    static BinState carve(char* base, size_t R, size_t temp_bytes)
+    {
+        Carver c(base);
+        BinState b;
+        b.point_list = c.take<uint32_t>(R);
+        b.tile_sorted = c.take<uint32_t>(R);
+        b.tile_in = c.take<uint32_t>(R);
+        b.gauss_in = c.take<uint32_t>(R);
+        b.temp = c.take<char>(temp_bytes);
+        b.temp_bytes = temp_bytes;
+        b.end = c.p;
+        return b;
+    }
+};
+
+struct ImageState {
+    float* final_T;       // [N]
+    uint32_t* n_contrib;  // [N]
+    uint2* ranges;        // [Tn]
+    char* end;
+    static ImageState carve(char* base, size_t N, size_t Tn)
+    {
+        Carver c(base);
+        ImageState s;
+        s.final_T = c.take<float>(N);
+        s.n_contrib = c.take<uint32_t>(N);
+        s.ranges = c.take<uint2>(Tn);
+        s.end = c.p;
+        return s;
+    }
+};
+
+template <class S, class... A>
+size_t required_bytes(A... a)
+{
+    S s = S::carve(nullptr, a...);
+    return (size_t)reinterpret_cast<uintptr_t>(s.end) + kAlign;
+}
+
+// temp-storage queries (binning.hip)
+size_t depth_sort_temp_bytes(size_t P);
+size_t tile_sort_temp_bytes(size_t R);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define R3_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            throw r3::Error(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                            ":" + std::to_string(__LINE__) + ")");                                     \
+    } while (0)
+
+inline void check_launch(const char* what, hipStream_t s, bool debug)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(std::string(what) + ": launch failed: " + hipGetErrorString(e));
+    if (debug) {  // mirrors the reference's CHECK_CUDA(debug) (auxiliary.h:161-168): sync + surface the error here
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+
+// Per-view parameters as they arrive at the boundary: the matrices, camera position and background
+// are DEVICE tensors (gaussian_renderer/__init__.py:37-50 passes CUDA tensors), so kernels read them
+// through wave-uniform (scalar) loads; only the plain scalars travel in the kernel argument.
+struct ViewParams {
+    const float* view;    // [16] world->view, transposed/row-vector layout (scene/cameras.py:54)
+    const float* proj;    // [16] full projection, same layout
+    const float* campos;  // [3]
+    const float* bg;      // [3]
+    float tan_fovx, tan_fovy;
+    int W, H;
+    float scale_modifier;
+};
+
+__device__ __forceinline__ Camera load_camera(const ViewParams& v)
+{
+    Camera c;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        c.view[k] = v.view[k];
+        c.proj[k] = v.proj[k];
+    }
+    c.campos[0] = v.campos[0];
+    c.campos[1] = v.campos[1];
+    c.campos[2] = v.campos[2];
+    c.tan_fovx = v.tan_fovx;
+    c.tan_fovy = v.tan_fovy;
+    c.focal_y = v.H / (2.0f * v.tan_fovy);  // rasterizer_impl.cu:386-387
+    c.focal_x = v.W / (2.0f * v.tan_fovx);
+    c.W = v.W;
+    c.H = v.H;
+    c.gx = (v.W + kTile - 1) / kTile;
+    c.gy = (v.H + kTile - 1) / kTile;
+    c.scale_modifier = v.scale_modifier;
+    return c;
+}
+
+// ---- per-stage host launchers (one per translation unit) ------------------------------------
+struct FwdInputs {
+    int P, M;
+    const int* degrees;
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    // ragged SH (inference variant, forward.cu:19-36); null for the dense path
+    const int* coeffs_num;
+    const int* per_band_count;
+    const int* cumsum_count;
+};
+
+void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
+
+// depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])
+void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);
+void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s);
+void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s);
+
+void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
+                          ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s);
+void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b,
+                           const ImageState& img, const float* dL_dpix, hipStream_t s);
+
+struct BwdOutputs {
+    float* dL_dmean2D;   // [P,3]
+    float* dL_dopacity;  // [P,1]
+    float* dL_dcolor;    // [P,3]
+    float* dL_dmean3D;   // [P,3]
+    float* dL_dcov3D;    // [P,6]
+    float* dL_dsh;       // [P,M,3]
+    float* dL_dscale;    // [P,3]
+    float* dL_drot;      // [P,4]
+    float* dL_dconic;    // [P,4] optional (nullptr: not exported)
+};
+void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
+                                const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
+
+}  // namespace r3

@@ -1,0 +1,196 @@
+// preprocess.hip -- per-view, per-Gaussian forward stage on gfx950 (wave64).
+//
+// Replaces cuda_rasterizer/forward.cu:353-456 preprocessCUDA (dense SH [P,M,3] + per-Gaussian degrees),
+// forward.cu:245-350 variableSHPreprocessCUDA (ragged degree-sorted SH buffer) and
+// rasterizer_impl.cu:62-74 checkFrustum of /root/reference/submodules/diff-gaussian-rasterization.
+//
+// One lane per Gaussian, 256-thread workgroups.  HBM-bound: each wave first copies the SH rows of its
+// 64 Gaussians -- one contiguous span of the [P,M,3] tensor (or of the ragged buffer) -- into LDS with
+// fully coalesced loads, then every lane evaluates its own row out of LDS (bank-skewed index), instead
+// of 64 lanes striding 192 B apart through global memory.  Output is one 48-byte record per visible
+// Gaussian (GRec), the tile rect, the depth sort key and tiles_touched.
+// Built with -ffp-contract=off: radii / rects / tiles_touched are bit-exact against the oracle.
+#include "common.h"
+
+namespace r3 {
+
+constexpr int kPreBlock = 256;
+constexpr int kMaxCoeff = 16;
+constexpr int kRowFloats = 3 * kMaxCoeff;                        // 48
+constexpr int kWaveShFloats = 64 * kRowFloats + (64 * kRowFloats) / 32;  // + bank skew
+
+__device__ __forceinline__ int skew(int e) { return e + (e >> 5); }
+
+struct ShRowLds {
+    const float* base;
+    int roff;
+    __device__ __forceinline__ float at(int e) const { return base[skew(roff + e)]; }
+};
+
+struct PreArgs {
+    FwdInputs in;
+    ViewParams view;
+    GRec* rec;
+    ushort4* rect;
+    uint32_t* depth_key;
+    uint32_t* tiles;
+    uint32_t* visible_count;
+    int* radii;
+};
+
+// forward.cu:19-36 getSHOffset (float3 units)
+__device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const int* perband, const int* cumsum, int* deg)
+{
+    int off = 0;
+    *deg = 0;
+    if (idx < cumsum[0]) return idx * coeffs[0];
+    *deg = 1;
+    off += perband[0] * coeffs[0];
+    if (idx < cumsum[1]) return off + (idx - cumsum[0]) * coeffs[1];
+    *deg = 2;
+    off += perband[1] * coeffs[1];
+    if (idx < cumsum[2]) return off + (idx - cumsum[1]) * coeffs[2];
+    *deg = 3;
+    off += perband[2] * coeffs[2];
+    return off + (idx - cumsum[2]) * coeffs[3];
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
+{
+    __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.in.P, M = a.in.M;
+    const int i = blockIdx.x * kPreBlock + tid;
+    const bool valid = i < P;
+    const int wave_first = blockIdx.x * kPreBlock + wave * 64;
+    const Camera cam = load_camera(a.view);
+
+    float mx = 0.f, my = 0.f, mz = 1.f;
+    PreOut o;
+    o.radius = 0;
+    o.tiles = 0;
+    if (valid) {
+        mx = a.in.means3D[3 * i];
+        my = a.in.means3D[3 * i + 1];
+        mz = a.in.means3D[3 * i + 2];
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6];
+        const float* c6p = nullptr;
+        if (a.in.cov3D_precomp) {
+            for (int k = 0; k < 6; k++) c6[k] = a.in.cov3D_precomp[6 * i + k];
+            c6p = c6;
+        } else {
+            for (int k = 0; k < 3; k++) sc[k] = a.in.scales[3 * i + k];
+            for (int k = 0; k < 4; k++) q[k] = a.in.rotations[4 * i + k];
+        }
+        preprocess_one(cam, mx, my, mz, sc, q, c6p, a.in.opacities[i], &o);
+    }
+    const bool vis = o.radius > 0;
+    const bool need_sh = vis && (a.in.colors_precomp == nullptr);
+
+    // ---- per-lane SH row placement inside the wave's contiguous span --------------------------
+    int deg = 0, roff = 0;  // roff in floats relative to the span start
+    long span_first = 0;    // first float of the wave's span in the SH buffer
+    int span_len = 0;       // floats
+    if (a.in.colors_precomp == nullptr) {
+        if (RAGGED) {
+            const int last_i = min(wave_first + 63, P - 1);
+            int d0, dl;
+            const int off_first = wave_first < P ? ragged_offset(wave_first, a.in.coeffs_num, a.in.per_band_count, a.in.cumsum_count, &d0) : 0;
+            const int off_last = wave_first < P ? ragged_offset(last_i, a.in.coeffs_num, a.in.per_band_count, a.in.cumsum_count, &dl) : 0;
+            span_first = 3L * off_first;
+            span_len = wave_first < P ? 3 * (off_last + (dl + 1) * (dl + 1) - off_first) : 0;
+            if (valid) {
+                const int off = ragged_offset(i, a.in.coeffs_num, a.in.per_band_count, a.in.cumsum_count, &deg);
+                roff = 3 * (off - off_first);
+            }
+        } else {
+            const int nrows = max(0, min(64, P - wave_first));
+            span_first = 3L * M * wave_first;
+            span_len = nrows * 3 * M;
+            roff = lane * 3 * M;
+            if (valid) deg = a.in.degrees[i];
+        }
+    }
+    // wave-uniform: does any lane of this wave need its SH row?
+    const bool wave_needs = __ballot(need_sh) != 0ull;
+    if (wave_needs) {
+        const float* src = a.in.shs + span_first;
+        float* dst = s_sh[wave];
+        for (int e = lane; e < span_len; e += 64) dst[skew(e)] = src[e];
+    }
+    __syncthreads();
+
+    if (valid) {
+        uint32_t dkey = 0xFFFFFFFFu;
+        if (vis) {
+            float rgb[3];
+            uint32_t cbits = 0;
+            if (need_sh) {
+                ShRowLds row{s_sh[wave], roff};
+                sh_to_rgb(deg, row, mx, my, mz, cam.campos, rgb, &cbits);
+            } else {
+                rgb[0] = a.in.colors_precomp[3 * i];
+                rgb[1] = a.in.colors_precomp[3 * i + 1];
+                rgb[2] = a.in.colors_precomp[3 * i + 2];
+            }
+            GRec r;
+            r.x = o.px;
+            r.y = o.py;
+            r.cA = o.conic[0];
+            r.cB = o.conic[1];
+            r.cC = o.conic[2];
+            r.op = o.opacity;
+            r.r = rgb[0];
+            r.g = rgb[1];
+            r.b = rgb[2];
+            r.depth = o.depth;
+            r.clamp_bits = cbits;
+            r.rect = 0;
+            a.rec[i] = r;
+            a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
+                                     (unsigned short)o.rmax[1]);
+            dkey = __float_as_uint(o.depth);
+        }
+        a.radii[i] = o.radius;
+        a.tiles[i] = o.tiles;
+        a.depth_key[i] = dkey;
+    }
+    const unsigned long long vmask = __ballot(vis);
+    if (lane == 0 && vmask) atomicAdd(a.visible_count, (uint32_t)__popcll(vmask));
+}
+
+void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s)
+{
+    PreArgs a;
+    a.in = in;
+    a.view = view;
+    a.rec = g.rec;
+    a.rect = g.rect;
+    a.depth_key = g.depth_key;
+    a.tiles = g.tiles;
+    a.visible_count = &g.header->visible_count;
+    a.radii = radii;
+    const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
+    if (in.coeffs_num)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+}
+
+// rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* means, const float* view, bool* present)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float pv[3];
+    xform4x3(view, means[3 * i], means[3 * i + 1], means[3 * i + 2], pv);
+    present[i] = pv[2] > 0.2f;
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+}  // namespace r3

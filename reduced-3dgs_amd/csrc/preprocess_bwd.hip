@@ -1,0 +1,169 @@
+// preprocess_bwd.hip -- per-Gaussian backward stage on gfx950, ONE fused kernel.
+//
+// Replaces the two reference kernels cuda_rasterizer/backward.cu:177-307 computeCov2DCUDA and
+// backward.cu:379-434 preprocessCUDA (+ :20-172 SH, :311-374 cov3D), and the count(radii>0) reduction of
+// rasterizer_impl.cu:549-571 (the visible count was already produced by the forward; no host sync, no
+// malloc/free in the backward) of /root/reference/submodules/diff-gaussian-rasterization.
+//
+// HBM-bound streaming kernel: one lane per Gaussian.  The wave's 64 SH rows are staged through LDS with
+// coalesced loads, the dL/dsh rows are built IN PLACE in the same LDS span and written back with
+// coalesced stores -- including the zeros the API contract demands for bands above a Gaussian's degree
+// and for culled Gaussians -- so the caller does not have to memset the 12*M*P-byte tensor first.
+// Every output element of every Gaussian is written (zeros where the reference leaves its
+// zero-initialised tensors untouched), so outputs may be uninitialised memory.
+#include "common.h"
+
+namespace r3 {
+
+constexpr int kBwdBlock = 256;
+constexpr int kBwdWaveShFloats = 64 * 48 + (64 * 48) / 32;
+
+__device__ __forceinline__ int bskew(int e) { return e + (e >> 5); }
+
+struct ShRowLdsRW {
+    float* base;
+    int roff;
+    __device__ __forceinline__ float at(int e) const { return base[bskew(roff + e)]; }
+    __device__ __forceinline__ void put(int e, float v) const { base[bskew(roff + e)] = v; }
+};
+
+struct PreBwdArgs {
+    FwdInputs in;
+    ViewParams view;
+    const int* radii;
+    const GRec* rec;
+    const float* acc;
+    const uint32_t* visible_count;
+    float lambda_sh;
+    BwdOutputs out;
+};
+
+__global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
+{
+    __shared__ float s_sh[kBwdBlock / 64][kBwdWaveShFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.in.P, M = a.in.M;
+    const int i = blockIdx.x * kBwdBlock + tid;
+    const bool valid = i < P;
+    const int wave_first = blockIdx.x * kBwdBlock + wave * 64;
+    const Camera cam = load_camera(a.view);
+    const bool has_sh = a.in.shs != nullptr;
+
+    const bool vis = valid && a.radii[i] > 0;
+    const int nrows = max(0, min(64, P - wave_first));
+    const int span_len = has_sh ? nrows * 3 * M : 0;
+    const long span_first = 3L * M * wave_first;
+    float* lds = s_sh[wave];
+    const bool wave_vis = __ballot(vis) != 0ull;
+    if (has_sh && wave_vis) {
+        const float* src = a.in.shs + span_first;
+        for (int e = lane; e < span_len; e += 64) lds[bskew(e)] = src[e];
+    }
+    __syncthreads();
+
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float g2x = 0.f, g2y = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f};
+    int K = 0;
+    ShRowLdsRW row{lds, lane * 3 * M};
+    if (vis) {
+        const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
+        const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
+        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+        g2x = a0.x;
+        g2y = a0.y;
+        gcon[0] = a0.z;
+        gcon[1] = a0.w;
+        gcon[2] = a1.x;
+        dop = a1.y;
+        dcol[0] = a1.z;
+        dcol[1] = a1.w;
+        dcol[2] = a2.x;
+        const GRec r = a.rec[i];
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6];
+        if (a.in.cov3D_precomp) {
+            for (int k = 0; k < 6; k++) c6[k] = a.in.cov3D_precomp[6 * i + k];
+        } else {
+            for (int k = 0; k < 3; k++) sc[k] = a.in.scales[3 * i + k];
+            for (int k = 0; k < 4; k++) q[k] = a.in.rotations[4 * i + k];
+            cov3d_from_scale_rot(sc, cam.scale_modifier, q, c6);  // recomputed, not stored by the forward
+        }
+        cov2d_backward(cam, mx, my, mz, c6, gcon[0], gcon[1], gcon[2], dcov6, dmean);
+        project_backward(cam, mx, my, mz, g2x, g2y, dmean);
+        if (has_sh) {
+            float mult = 0.f;
+            if (a.lambda_sh != 0.f) mult = a.lambda_sh / (float)((int)(*a.visible_count) * 15 * 3);
+            const int deg = a.in.degrees[i];
+            K = (deg + 1) * (deg + 1);
+            sh_backward(deg, row, row, mx, my, mz, cam.campos, r.clamp_bits, dcol, mult, dmean);
+        }
+        if (a.in.scales) cov3d_backward(sc, cam.scale_modifier, q, dcov6, dscale, dq);
+        dop = opacity_backward(dop, r.op);
+    }
+    if (has_sh && valid) {
+        if (wave_vis) {
+            for (int e = 3 * K; e < 3 * M; e++) row.put(e, 0.f);  // bands above this Gaussian's degree / culled rows
+        }
+    }
+    __syncthreads();
+    if (has_sh) {
+        float* dst = a.out.dL_dsh + span_first;
+        if (wave_vis) {
+            for (int e = lane; e < span_len; e += 64) dst[e] = lds[bskew(e)];
+        } else {
+            for (int e = lane; e < span_len; e += 64) dst[e] = 0.f;
+        }
+    }
+    if (valid) {
+        float* o;
+        o = a.out.dL_dmean2D + 3 * (size_t)i;
+        o[0] = g2x;
+        o[1] = g2y;
+        o[2] = 0.f;
+        a.out.dL_dopacity[i] = dop;
+        o = a.out.dL_dcolor + 3 * (size_t)i;
+        o[0] = dcol[0];
+        o[1] = dcol[1];
+        o[2] = dcol[2];
+        o = a.out.dL_dmean3D + 3 * (size_t)i;
+        o[0] = dmean[0];
+        o[1] = dmean[1];
+        o[2] = dmean[2];
+        o = a.out.dL_dcov3D + 6 * (size_t)i;
+        for (int k = 0; k < 6; k++) o[k] = dcov6[k];
+        o = a.out.dL_dscale + 3 * (size_t)i;
+        o[0] = dscale[0];
+        o[1] = dscale[1];
+        o[2] = dscale[2];
+        o = a.out.dL_drot + 4 * (size_t)i;
+        o[0] = dq[0];
+        o[1] = dq[1];
+        o[2] = dq[2];
+        o[3] = dq[3];
+        if (a.out.dL_dconic) {
+            o = a.out.dL_dconic + 4 * (size_t)i;
+            o[0] = gcon[0];
+            o[1] = gcon[1];
+            o[2] = 0.f;
+            o[3] = gcon[2];
+        }
+    }
+}
+
+void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
+                                const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s)
+{
+    PreBwdArgs a;
+    a.in = in;
+    a.view = view;
+    a.radii = radii;
+    a.rec = g.rec;
+    a.acc = g.acc;
+    a.visible_count = &g.header->visible_count;
+    a.lambda_sh = lambda_sh_sparsity;
+    a.out = out;
+    const int blocks = (in.P + kBwdBlock - 1) / kBwdBlock;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kBwdBlock), 0, s, a);
+}
+
+}  // namespace r3

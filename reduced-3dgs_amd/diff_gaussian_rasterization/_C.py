@@ -1,0 +1,276 @@
+"""`diff_gaussian_rasterization._C` -- operator set of the MI355X-native rasterizer.
+
+Same symbols, positional signatures, return tuples and error behaviour as the reference's pybind
+module (submodules/diff-gaussian-rasterization/ext.cpp:16-25, rasterize_points.h:18-92), implemented as
+thin marshalling over the C ABI of libr3dgs_hip.so (include/r3dgs_rasterizer.h).  PyTorch is plumbing
+only here: device memory (outputs + the three opaque state blobs), the current HIP stream, contiguity.
+
+There is NO fallback: if the HIP library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libr3dgs_hip.so")
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(f"{_LIB_PATH} not found: build it with `python reduced-3dgs_amd/build.py` "
+                      "(the rasterizer has no CPU or PyTorch fallback)")
+_lib = C.CDLL(_LIB_PATH)
+
+_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+_lib.r3dgs_version.restype = C.c_char_p
+_lib.r3dgs_last_error.restype = C.c_char_p
+for _n in ("r3dgs_geometry_bytes", "r3dgs_binning_bytes"):
+    getattr(_lib, _n).restype = C.c_size_t
+    getattr(_lib, _n).argtypes = [_i]
+_lib.r3dgs_image_bytes.restype = C.c_size_t
+_lib.r3dgs_image_bytes.argtypes = [_i, _i]
+_lib.r3dgs_mark_visible.restype = _i
+_lib.r3dgs_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
+_FWD_TAIL = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i,
+             _i, _vp]
+_lib.r3dgs_forward.restype = _i
+_lib.r3dgs_forward.argtypes = [_ALLOC, _vp, _ALLOC, _vp, _ALLOC, _vp, _i, _vp, _i] + _FWD_TAIL
+_lib.r3dgs_inference_forward.restype = _i
+_lib.r3dgs_inference_forward.argtypes = [_ALLOC, _vp, _ALLOC, _vp, _ALLOC, _vp, _i, _vp, _i, _vp, _vp, _vp] + _FWD_TAIL
+_lib.r3dgs_backward.restype = _i
+_lib.r3dgs_backward.argtypes = ([_i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                                 _vp, _vp, _vp, _vp] + [_vp] * 10 + [_f, _i, _vp])
+_lib.r3dgs_export_binning.restype = _i
+_lib.r3dgs_export_binning.argtypes = [_i, _i, _i, _i] + [_vp] * 10
+
+_lib.r3dgs_profile_enable.argtypes = [_i]
+_lib.r3dgs_profile_stage_name.restype = C.c_char_p
+_lib.r3dgs_profile_stage_name.argtypes = [_i]
+_lib.r3dgs_profile_read.argtypes = [_vp, _vp]
+
+LIBRARY_PATH = _LIB_PATH
+
+
+def profile_enable(on):
+    """Per-stage HIP-event timing inside the library (include/r3dgs_rasterizer.h r3dgs_profile_*)."""
+    _lib.r3dgs_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """-> {stage_name: (total_ms, launches)} since the last read; waits for the recorded events."""
+    n = _lib.r3dgs_profile_stage_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int * n)()
+    _check(_lib.r3dgs_profile_read(ms, cnt), "profile_read")
+    return {_lib.r3dgs_profile_stage_name(k).decode(): (ms[k], cnt[k]) for k in range(n)}
+
+
+def version():
+    return _lib.r3dgs_version().decode()
+
+
+def _check(status, what):
+    if status < 0:
+        raise RuntimeError(f"{what}: {_lib.r3dgs_last_error().decode()}")
+    return status
+
+
+def _ptr(t):
+    """Device pointer of a tensor, or NULL for an absent optional input (empty tensor, as the reference's
+    wrapper passes `torch.Tensor([])` for missing arguments, diff_gaussian_rasterization/__init__.py:209-218)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _dev_f32(t, dev):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != dev:
+        raise RuntimeError(f"expected a tensor on {dev}, got {t.device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _dev_i32(t, dev):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != dev:
+        raise RuntimeError(f"expected a tensor on {dev}, got {t.device}")
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"expected int32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _Blob:
+    """One caller-owned, resizable byte buffer (resizeFunctional of rasterize_points.cu:33-41)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=dev)
+
+        def alloc(nbytes, _user):
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+            return self.tensor.data_ptr()
+
+        self.cb = _ALLOC(alloc)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _forward_common(ragged, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                    viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
+                    prefiltered, debug, counters=None):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:158-161
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("the MI355X rasterizer needs device tensors (no CPU path)")
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    geom, binning, img = _Blob(dev), _Blob(dev), _Blob(dev)
+    if P == 0:
+        out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((0,), dtype=torch.int32, device=dev)
+        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    bg = _dev_f32(background, dev)
+    m3, col, op = _dev_f32(means3D, dev), _dev_f32(colors, dev), _dev_f32(opacity, dev)
+    sc, rot, cov = _dev_f32(scales, dev), _dev_f32(rotations, dev), _dev_f32(cov3D_precomp, dev)
+    vm, pm, cp = _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev), _dev_f32(campos, dev)
+    shc, deg = _dev_f32(sh, dev), _dev_i32(degrees, dev)
+    touched = transm = None
+    if counters is not None:
+        touched, transm = counters
+    with torch.cuda.device(dev):
+        tail = (_ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot),
+                _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                _ptr(out_color), _ptr(touched), _ptr(transm), _ptr(radii), int(counters is not None),
+                int(bool(debug)), _stream())
+        if ragged is None:
+            M = int(shc.size(1)) if shc is not None else 0
+            rendered = _lib.r3dgs_forward(geom.cb, None, binning.cb, None, img.cb, None, P, _ptr(deg), M, *tail)
+        else:
+            coeffs, perband, cumsum = (_dev_i32(t, dev) for t in ragged)
+            bands = int(perband.numel()) if perband is not None else 0
+            rendered = _lib.r3dgs_inference_forward(geom.cb, None, binning.cb, None, img.cb, None, P, _ptr(deg), bands,
+                                                    _ptr(coeffs), _ptr(perband), _ptr(cumsum), *tail)
+    _check(rendered, "rasterize_gaussians")
+    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:136-222) ->
+    (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    return _forward_common(None, background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                           cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                           degrees, campos, prefiltered, debug)
+
+
+def rasterize_gaussians_variableSH_bands(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                                         image_width, sh, perBandPrimitiveCount, cumSumPrimitiveCount, coeffsNum,
+                                         degrees, campos, prefiltered, debug):
+    """RasterizeGaussiansVariableSHBandsCUDA (rasterize_points.cu:43-134): inference-only forward over the
+    ragged, degree-sorted SH buffer."""
+    return _forward_common((coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount), background, means3D, colors,
+                           opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                           tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos, prefiltered, debug)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                 degrees, campos, geomBuffer, R, binningBuffer, imageBuffer, lambda_sh_sparsity,
+                                 debug, _want_conic=False):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:224-305) -> (dL_dmeans2D[P,3], dL_dcolors[P,3],
+    dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])."""
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    opts = dict(dtype=torch.float32, device=dev)
+    if P == 0:
+        z = lambda *s: torch.zeros(s, **opts)
+        return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+    e = lambda *s: torch.empty(s, **opts)  # every element is written by the library
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity = e(P, 3), e(P, 3), e(P, 3), e(P, 1)
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
+    dL_dconic = e(P, 2, 2) if _want_conic else None
+    bg, m3 = _dev_f32(background, dev), _dev_f32(means3D, dev)
+    col, sc, rot, cov = (_dev_f32(t, dev) for t in (colors, scales, rotations, cov3D_precomp))
+    vm, pm, cp = _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev), _dev_f32(campos, dev)
+    g, shc, deg, rad = _dev_f32(dL_dout_color, dev), _dev_f32(sh, dev), _dev_i32(degrees, dev), _dev_i32(radii, dev)
+    with torch.cuda.device(dev):
+        st = _lib.r3dgs_backward(P, _ptr(deg), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
+                                 float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp),
+                                 float(tan_fovx), float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer),
+                                 _ptr(imageBuffer), _ptr(g), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+                                 _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+                                 _ptr(dL_drotations), float(lambda_sh_sparsity), int(bool(debug)), _stream())
+    _check(st, "rasterize_gaussians_backward")
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dconic,) if _want_conic else out
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:307-326): bool[P], view-space z > 0.2."""
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P:
+        m3, vm, pm = _dev_f32(means3D, dev), _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev)
+        with torch.cuda.device(dev):
+            _check(_lib.r3dgs_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), _ptr(present), _stream()), "mark_visible")
+    return present
+
+
+def export_binning(P, R, H, W, geomBuffer, binningBuffer, imageBuffer):
+    """Debug accessor (not in the reference): sorted 64-bit keys in the reference's format, point list, tile
+    ranges, n_contrib, final T and tiles_touched of a finished forward -- for bit-exact integer parity tests."""
+    dev = geomBuffer.device
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    keys = torch.empty((R,), dtype=torch.int64, device=dev)
+    plist = torch.empty((R,), dtype=torch.int32, device=dev)
+    ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
+    n_contrib = torch.empty((H * W,), dtype=torch.int32, device=dev)
+    final_T = torch.empty((H * W,), dtype=torch.float32, device=dev)
+    tiles = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.r3dgs_export_binning(P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                                         _ptr(keys), _ptr(plist), _ptr(ranges), _ptr(n_contrib), _ptr(final_T),
+                                         _ptr(tiles), _stream()), "export_binning")
+    return dict(keys=keys, point_list=plist, ranges=ranges, n_contrib=n_contrib, final_T=final_T, tiles_touched=tiles)
+
+
+def rasterize_gaussians_counters(*args):
+    """Forward in counter mode (calculate_mean_transmittance, forward.cu:560-564): same arguments as
+    rasterize_gaussians; additionally returns (touched_pixels int32[P], transmittance fp32[P]).
+    This is the building block of calculate_colours_variance (reduced_3dgs.cu:89-140)."""
+    means3D = args[1]
+    P = int(means3D.size(0))
+    touched = torch.zeros((P,), dtype=torch.int32, device=means3D.device)
+    transm = torch.zeros((P,), dtype=torch.float32, device=means3D.device)
+    out = _forward_common(None, *args, counters=(touched, transm))
+    return out + (touched, transm)
+
+
+def _next_tier(name, where):
+    def fn(*_a, **_k):
+        raise NotImplementedError(f"_C.{name} ({where}) is outside the rasterizer hot path and not built yet "
+                                  "(SURVEY.md 8f 'next' rows)")
+    fn.__name__ = name
+    return fn
+
+
+# exported so that `from diff_gaussian_rasterization._C import ...` in scene/__init__.py:20,
+# scene/gaussian_model.py:23 and generate_results.py:10 resolves; they raise when called.
+calculate_colours_variance = _next_tier("calculate_colours_variance", "reduced_3dgs.cu:41-203")
+sphere_ellipsoid_intersection = _next_tier("sphere_ellipsoid_intersection", "reduced_3dgs.cu:205-237")
+allocate_minimum_redundancy_value = _next_tier("allocate_minimum_redundancy_value", "reduced_3dgs.cu:267-285")
+find_minimum_projected_pixel_size = _next_tier("find_minimum_projected_pixel_size", "reduced_3dgs.cu:239-263")
+kmeans_cuda = _next_tier("kmeans_cuda", "reduced_3dgs.cu:288-339")

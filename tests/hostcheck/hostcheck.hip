@@ -1,0 +1,196 @@
+// hostcheck.hip -- TEST SHIM: runs the product's __host__ __device__ per-Gaussian / per-pixel math
+// (reduced-3dgs_amd/csrc/gauss_math.h, blend_math.h) on the CPU, so tests/test_hostcheck.py can compare
+// the exact source the HIP kernels execute per lane against the oracle WITHOUT a GPU.
+// It is not part of the product and nothing in reduced-3dgs_amd/ links it; the cooperative kernel
+// skeletons (LDS staging, DPP reductions, atomics, sorts) are only exercised by the -m gpu tests.
+#include <cstring>
+#include <vector>
+
+#include "../../reduced-3dgs_amd/csrc/blend_math.h"
+#include "../../reduced-3dgs_amd/csrc/gauss_math.h"
+
+using namespace r3;
+
+static Camera make_cam(const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany,
+                       float mod)
+{
+    Camera c;
+    for (int k = 0; k < 16; k++) {
+        c.view[k] = view[k];
+        c.proj[k] = proj[k];
+    }
+    for (int k = 0; k < 3; k++) c.campos[k] = campos[k];
+    c.tan_fovx = tanx;
+    c.tan_fovy = tany;
+    c.focal_y = H / (2.0f * tany);
+    c.focal_x = W / (2.0f * tanx);
+    c.W = W;
+    c.H = H;
+    c.gx = (W + kTile - 1) / kTile;
+    c.gy = (H + kTile - 1) / kTile;
+    c.scale_modifier = mod;
+    return c;
+}
+
+extern "C" {
+
+void hc_preprocess(int P, int M, const int* degs, const float* means, const float* scales, float mod, const float* rots,
+                   const float* opac, const float* shs, const float* cov_pre, const float* col_pre, const float* view,
+                   const float* proj, const float* campos, int W, int H, float tanx, float tany, int* radii, float* xy,
+                   float* depths, float* conic_op, float* rgb, unsigned* clamp_bits, unsigned* tiles, int* rect)
+{
+    const Camera cam = make_cam(view, proj, campos, W, H, tanx, tany, mod);
+    for (int i = 0; i < P; i++) {
+        PreOut o;
+        float sc[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0};
+        if (!cov_pre) {
+            memcpy(sc, scales + 3 * i, 12);
+            memcpy(q, rots + 4 * i, 16);
+        }
+        preprocess_one(cam, means[3 * i], means[3 * i + 1], means[3 * i + 2], sc, q, cov_pre ? cov_pre + 6 * i : nullptr,
+                       opac[i], &o);
+        radii[i] = o.radius;
+        tiles[i] = o.tiles;
+        if (o.radius <= 0) continue;
+        xy[2 * i] = o.px;
+        xy[2 * i + 1] = o.py;
+        depths[i] = o.depth;
+        conic_op[4 * i] = o.conic[0];
+        conic_op[4 * i + 1] = o.conic[1];
+        conic_op[4 * i + 2] = o.conic[2];
+        conic_op[4 * i + 3] = o.opacity;
+        rect[4 * i] = o.rmin[0];
+        rect[4 * i + 1] = o.rmin[1];
+        rect[4 * i + 2] = o.rmax[0];
+        rect[4 * i + 3] = o.rmax[1];
+        if (col_pre) {
+            memcpy(rgb + 3 * i, col_pre + 3 * i, 12);
+            clamp_bits[i] = 0;
+        } else {
+            ShRowPlain row{shs + 3 * (size_t)M * i};
+            sh_to_rgb(degs[i], row, means[3 * i], means[3 * i + 1], means[3 * i + 2], cam.campos, rgb + 3 * i,
+                      clamp_bits + i);
+        }
+    }
+}
+
+static Splat splat_of(const float* xy, const float* conic_op, const float* rgb, unsigned id)
+{
+    Splat s;
+    s.x = xy[2 * id];
+    s.y = xy[2 * id + 1];
+    s.cA = conic_op[4 * id];
+    s.cB = conic_op[4 * id + 1];
+    s.cC = conic_op[4 * id + 2];
+    s.op = conic_op[4 * id + 3];
+    s.r = rgb[3 * id];
+    s.g = rgb[3 * id + 1];
+    s.b = rgb[3 * id + 2];
+    return s;
+}
+
+void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
+                  const float* conic_op, const float* bg, float* out_color, float* final_T, unsigned* n_contrib)
+{
+    const int gx = (W + kTile - 1) / kTile;
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / kTile) * gx + px / kTile;
+            FwdPix p;
+            p.T = 1.f;
+            p.C0 = p.C1 = p.C2 = 0.f;
+            p.last = 0;
+            for (unsigned k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
+                float Tb;
+                const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
+                if (fwd_step(s, (float)px, (float)py, k - ranges[2 * tile] + 1, p, &Tb) == 2) break;
+            }
+            const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
+            final_T[pix] = p.T;
+            n_contrib[pix] = p.last;
+            out_color[pix] = p.C0 + p.T * bg[0];
+            out_color[plane + pix] = p.C1 + p.T * bg[1];
+            out_color[2 * plane + pix] = p.C2 + p.T * bg[2];
+        }
+}
+
+// acc: double[P][9] = mx, my, cA, cB, cC, op, r, g, b  (mx,my already scaled by 0.5W / 0.5H)
+void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
+                  const float* xy, const float* conic_op, const float* rgb, const float* final_T,
+                  const unsigned* n_contrib, const float* dL_dpix, double* acc)
+{
+    (void)P;
+    const int gx = (W + kTile - 1) / kTile;
+    const size_t plane = (size_t)W * H;
+    const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const int tile = (py / kTile) * gx + px / kTile;
+            const size_t pix = (size_t)W * py + px;
+            BwdPix p;
+            p.acc0 = p.acc1 = p.acc2 = p.lc0 = p.lc1 = p.lc2 = p.la = 0.f;
+            p.T_final = p.T = final_T[pix];
+            p.last = n_contrib[pix];
+            p.g0 = dL_dpix[pix];
+            p.g1 = dL_dpix[plane + pix];
+            p.g2 = dL_dpix[2 * plane + pix];
+            p.bg_dot = bg[0] * p.g0 + bg[1] * p.g1 + bg[2] * p.g2;
+            for (long pos = (long)p.last - 1; pos >= 0; pos--) {
+                const unsigned id = point_list[ranges[2 * tile] + pos];
+                const Splat s = splat_of(xy, conic_op, rgb, id);
+                SplatGrad g;
+                g.mx = g.my = g.cA = g.cB = g.cC = g.op = g.r = g.g = g.b = 0.f;
+                if (bwd_step(s, (float)px, (float)py, (unsigned)pos, p, g)) {
+                    double* a = acc + 9 * (size_t)id;
+                    a[0] += (double)(g.mx * half_w);
+                    a[1] += (double)(g.my * half_h);
+                    a[2] += g.cA;
+                    a[3] += g.cB;
+                    a[4] += g.cC;
+                    a[5] += g.op;
+                    a[6] += g.r;
+                    a[7] += g.g;
+                    a[8] += g.b;
+                }
+            }
+        }
+}
+
+void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const int* radii, const float* shs,
+                       const unsigned* clamp_bits, const float* scales, const float* rots, float mod,
+                       const float* cov_pre, const float* view, const float* proj, const float* campos, int W, int H,
+                       float tanx, float tany, const float* dL_dmean2D, const float* conic_op, const float* dL_dconic,
+                       const float* dL_dcolor, float lambda_sh, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, float* dL_dopacity)
+{
+    const Camera cam = make_cam(view, proj, campos, W, H, tanx, tany, mod);
+    int V = 0;
+    for (int i = 0; i < P; i++) V += radii[i] > 0;
+    const float mult = lambda_sh != 0.f ? lambda_sh / (float)(V * 15 * 3) : 0.f;
+    for (int i = 0; i < P; i++) {
+        if (!(radii[i] > 0)) continue;
+        const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+        float sc[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, c6[6];
+        if (cov_pre)
+            memcpy(c6, cov_pre + 6 * i, 24);
+        else {
+            memcpy(sc, scales + 3 * i, 12);
+            memcpy(q, rots + 4 * i, 16);
+            cov3d_from_scale_rot(sc, mod, q, c6);
+        }
+        float dmean[3];
+        cov2d_backward(cam, mx, my, mz, c6, dL_dconic[4 * i], dL_dconic[4 * i + 1], dL_dconic[4 * i + 3],
+                       dL_dcov3D + 6 * i, dmean);
+        project_backward(cam, mx, my, mz, dL_dmean2D[3 * i], dL_dmean2D[3 * i + 1], dmean);
+        if (shs) {
+            ShRowPlain row{shs + 3 * (size_t)M * i};
+            ShGradPlain sink{dL_dsh + 3 * (size_t)M * i};
+            sh_backward(degs[i], row, sink, mx, my, mz, cam.campos, clamp_bits[i], dL_dcolor + 3 * i, mult, dmean);
+        }
+        memcpy(dL_dmean3D + 3 * i, dmean, 12);
+        if (!cov_pre) cov3d_backward(sc, mod, q, dL_dcov3D + 6 * i, dL_dscale + 3 * i, dL_drot + 4 * i);
+        dL_dopacity[i] = opacity_backward(dL_dopacity[i], conic_op[4 * i + 3]);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (`diff_gaussian_rasterization._C` is a
+ctypes binding of libr3dgs_hip.so), against the CPU oracle on the same seeded inputs and against the
+committed golden fixtures.
+
+Bars (BASELINE.json north_star):
+  * bit-exact: radii, num_rendered, tiles_touched, the sorted (tile<<32|depth) keys, point list, tile ranges,
+    n_contrib (on pixels whose blend decisions are not within 1e-5 of a threshold -- see `ambig`);
+  * rendered RGB: <= 1e-5 abs (same pixel set);
+  * gradients: <= 1e-4 relative (to the largest |component| of the tensor; the reference's own atomics make
+    single elements order-dependent in the last bits).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth_scene as ss
+from oracle import oracle as orc
+from tests.golden_cases import CASES, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+COLOR_ATOL = 1e-5
+GRAD_REL = 1e-4
+AMBIG_REL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def C_():
+    from diff_gaussian_rasterization import _C
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _C
+
+
+def dev(a, dtype=None):
+    if a is None:
+        return torch.empty(0)
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def hip_forward(C_, bg, g, cam, H, W, colors=None, cov=None, use_sh=True, use_sr=True, mod=1.0, debug=False):
+    args = (dev(bg), dev(g["means3D"]), dev(colors), dev(g["opacity"]), dev(g["scales"] if use_sr else None),
+            dev(g["rotations"] if use_sr else None), mod, dev(cov), dev(cam.world_view_transform),
+            dev(cam.full_proj_transform), cam.tanfovx, cam.tanfovy, H, W, dev(g["sh"] if use_sh else None),
+            dev(g["degrees"]), dev(cam.camera_center), False, debug)
+    return args, C_.rasterize_gaussians(*args)
+
+
+def hip_backward(C_, fargs, fout, dl, lam, debug=False):
+    R, color, radii, geom, binning, img = fout
+    (bg, m3, colors, op, sc, rot, mod, cov, vm, pm, tx, ty, H, W, sh, deg, campos, _, _) = fargs
+    return C_.rasterize_gaussians_backward(bg, m3, radii, colors, sc, rot, mod, cov, vm, pm, tx, ty, dev(dl), sh, deg,
+                                           campos, geom, R, binning, img, lam, debug, _want_conic=True)
+
+
+def oracle_forward(bg, g, cam, H, W, colors=None, cov=None, use_sh=True, use_sr=True, mod=1.0):
+    return orc.forward(bg, g["means3D"], colors, g["opacity"], g["scales"] if use_sr else None,
+                       g["rotations"] if use_sr else None, mod, cov, cam.world_view_transform,
+                       cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"] if use_sh else None,
+                       g["degrees"], cam.camera_center, want_ambig=True, ambig_rel=AMBIG_REL)
+
+
+def check_forward(C_, fout, ref, H, W, P):
+    R, color, radii, geom, binning, img = fout
+    st = ref["state"]
+    assert R == ref["num_rendered"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
+    ex = C_.export_binning(P, R, H, W, geom, binning, img)
+    np.testing.assert_array_equal(ex["tiles_touched"].cpu().numpy().astype(np.uint32), st["tiles_touched"])
+    np.testing.assert_array_equal(ex["keys"].cpu().numpy().view(np.uint64), st["keys"])
+    np.testing.assert_array_equal(ex["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
+    np.testing.assert_array_equal(ex["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
+    ok = ref["ambig"].reshape(-1) == 0
+    assert ok.mean() > 0.995, f"too many threshold-ambiguous pixels: {1 - ok.mean():.4f}"
+    np.testing.assert_array_equal(ex["n_contrib"].cpu().numpy().view(np.uint32)[ok], st["n_contrib"][ok])
+    c = color.cpu().numpy().reshape(3, -1)
+    err = np.abs(c - ref["color"].reshape(3, -1))
+    assert err[:, ok].max() <= COLOR_ATOL, f"colour error {err[:, ok].max():.3e}"
+    assert err.max() < 2e-2  # a flipped 1/255 decision moves a pixel by at most ~alpha*T*c
+    np.testing.assert_allclose(ex["final_T"].cpu().numpy()[ok], st["final_T"][ok], atol=COLOR_ATOL)
+    return ok
+
+
+def grads_close(name, ref, got, rel=GRAD_REL):
+    got = got.cpu().numpy().reshape(ref.shape)
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(ref - got).max()
+    assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} ({err / scale:.2e} rel)"
+
+
+def check_backward(bout, gr, st, M):
+    (dm2, dcol, dop, dm3, dcov, dsh, dsc, drot, dconic) = bout
+    grads_close("dL_dmeans2D", gr["dL_dmeans2D"], dm2)
+    grads_close("dL_dconic", gr["dL_dconic"][:, [0, 1, 3]], dconic.reshape(-1, 4)[:, [0, 1, 3]])
+    grads_close("dL_dcolors", gr["dL_dcolors"], dcol)
+    grads_close("dL_dopacity", gr["dL_dopacity"], dop)
+    grads_close("dL_dmeans3D", gr["dL_dmeans3D"], dm3)
+    grads_close("dL_dcov3D", gr["dL_dcov3D"], dcov)
+    if M:
+        grads_close("dL_dsh", gr["dL_dsh"], dsh)
+    grads_close("dL_dscales", gr["dL_dscales"], dsc)
+    grads_close("dL_drotations", gr["dL_drotations"], drot)
+    # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
+    inv = torch.from_numpy(st["radii"] == 0).cuda()
+    for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):
+        assert (t[inv] == 0).all()
+    assert (dm2[:, 2] == 0).all()
+    if M:
+        assert (dsh[inv] == 0).all()
+        K = (st["degrees"].reshape(-1).astype(np.int64) + 1) ** 2
+        mask = torch.from_numpy(np.arange(M)[None, :] >= K[:, None]).cuda()
+        assert (dsh[mask] == 0).all()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_cases_forward_backward(C_, golden_dir, name):
+    """Same seeded inputs as tests/golden/oracle_case_*.npz: HIP vs live oracle AND vs the committed fixture."""
+    kw = CASES[name]
+    cam, g, bg, dl = case_inputs(kw)
+    H, W, P = kw["H"], kw["W"], kw["P"]
+    ref = oracle_forward(bg, g, cam, H, W)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, debug=True)
+    check_forward(C_, fout, ref, H, W, P)
+    gr = orc.backward(ref["state"], dl, kw["lam"])
+    bout = hip_backward(C_, fargs, fout, dl, kw["lam"], debug=True)
+    check_backward(bout, gr, ref["state"], 16)
+    z = np.load(os.path.join(golden_dir, f"oracle_case_{name}.npz"))
+    assert fout[0] == int(z["num_rendered"])
+    np.testing.assert_array_equal(fout[2].cpu().numpy(), z["radii"])
+    ok = z["ambig"].reshape(-1) == 0
+    assert np.abs(fout[1].cpu().numpy().reshape(3, -1) - z["color"].reshape(3, -1))[:, ok].max() <= COLOR_ATOL
+    for k, t in (("dL_dmeans3D", bout[3]), ("dL_dsh", bout[5]), ("dL_dscales", bout[6]), ("dL_drotations", bout[7]),
+                 ("dL_dopacity", bout[2]), ("dL_dmeans2D", bout[0])):
+        grads_close("golden " + k, z[k], t)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=10_000, W=400, H=400, f=300.0, cam_seed=None, gseed=0, degree_mode="all0", scale_mu=0.012, lam=0.0),
+    dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02, lam=0.1),
+    dict(P=3_000, W=203, H=117, f=150.0, cam_seed=5, gseed=6, degree_mode="all3", scale_mu=0.05, lam=0.0, spread=1.4),
+], ids=["cfg0_10k_400x400_deg0", "20k_640x360_mixed_sparsity", "ragged_edges_ewa_clamp"])
+def test_oracle_parity_larger(C_, kw):
+    """BASELINE.json configs[0] (10k Gaussians, 400x400, degree 0) and two wider cases."""
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw["scale_mu"])
+    g["means3D"][:, :2] *= kw.get("spread", 1.0)
+    bg = np.array([0.1, 0.4, 0.9], np.float32)
+    dl = ss.upstream_grad(W, H, seed=2) * (W * H)
+    ref = oracle_forward(bg, g, cam, H, W)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    check_forward(C_, fout, ref, H, W, P)
+    gr = orc.backward(ref["state"], dl, kw["lam"])
+    bout = hip_backward(C_, fargs, fout, dl, kw["lam"])
+    check_backward(bout, gr, ref["state"], 16)
+
+
+def test_precomputed_colour_and_covariance(C_):
+    W, H, P = 160, 120, 4000
+    cam = ss.make_camera(W, H, 120.0, 7)
+    g = ss.make_gaussians(P, cam, seed=8, degree_mode="all3", scale_mu=0.05)
+    bg = np.array([1, 1, 1], np.float32)
+    rng = np.random.default_rng(3)
+    colors = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    cov = oracle_forward(bg, g, cam, H, W)["state"]["cov3D"].copy()
+    cov[(cov == 0).all(1)] = np.array([1e-3, 0, 0, 1e-3, 0, 1e-3], np.float32)
+    ref = oracle_forward(bg, g, cam, H, W, colors=colors, cov=cov, use_sh=False, use_sr=False)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, colors=colors, cov=cov, use_sh=False, use_sr=False)
+    check_forward(C_, fout, ref, H, W, P)
+    dl = ss.upstream_grad(W, H, seed=4) * (W * H)
+    gr = orc.backward(ref["state"], dl, 0.0)
+    bout = hip_backward(C_, fargs, fout, dl, 0.0)
+    check_backward(bout, gr, ref["state"], 0)
+    assert (bout[6] == 0).all() and (bout[7] == 0).all() and bout[5].shape == (P, 0, 3)
+
+
+def test_autograd_wrapper_like_render(C_):
+    """Drive the path exactly as gaussian_renderer.render() does (gaussian_renderer/__init__.py:27-135):
+    GaussianRasterizer module, means2D dummy with retain_grad, loss.backward()."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H, P = 200, 150, 5000
+    cam = ss.make_camera(W, H, 150.0, 2)
+    g = ss.make_gaussians(P, cam, seed=3, degree_mode="mixed", scale_mu=0.04)
+    bg = np.array([0, 0, 0], np.float32)
+    dl = ss.upstream_grad(W, H, seed=5) * (W * H)
+    leaves = {k: dev(g[k]).requires_grad_() for k in ("means3D", "opacity", "scales", "rotations", "sh")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0
+    means2D.retain_grad()
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                       bg=dev(bg), scale_modifier=1.0, viewmatrix=dev(cam.world_view_transform),
+                                       projmatrix=dev(cam.full_proj_transform), sh_degree=3,
+                                       campos=dev(cam.camera_center), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    color, radii = rast(means3D=leaves["means3D"], means2D=means2D, shs=leaves["sh"], degrees=dev(g["degrees"]),
+                        colors_precomp=None, opacities=leaves["opacity"], scales=leaves["scales"],
+                        rotations=leaves["rotations"], cov3D_precomp=None, lambda_sh_sparsity=0.05)
+    (color * dev(dl)).sum().backward()
+    ref = oracle_forward(bg, g, cam, H, W)
+    gr = orc.backward(ref["state"], dl, 0.05)
+    np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
+    grads_close("means3D", gr["dL_dmeans3D"], leaves["means3D"].grad)
+    grads_close("means2D", gr["dL_dmeans2D"], means2D.grad)
+    grads_close("opacity", gr["dL_dopacity"], leaves["opacity"].grad)
+    grads_close("scales", gr["dL_dscales"], leaves["scales"].grad)
+    grads_close("rotations", gr["dL_drotations"], leaves["rotations"].grad)
+    grads_close("sh", gr["dL_dsh"], leaves["sh"].grad)
+    vis = rast.markVisible(leaves["means3D"].detach())
+    np.testing.assert_array_equal(vis.cpu().numpy(), orc.mark_visible(g["means3D"], cam.world_view_transform))
+    with pytest.raises(Exception):
+        rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacity"], scales=leaves["scales"],
+             rotations=leaves["rotations"])  # neither SHs nor colours
+
+
+def test_ragged_sh_inference_and_counters(C_):
+    W, H, P = 240, 160, 6000
+    cam = ss.make_camera(W, H, 180.0, 1)
+    g = ss.make_gaussians(P, cam, seed=6, degree_mode="mixed", scale_mu=0.04)
+    order = np.argsort(g["degrees"].reshape(-1), kind="stable")
+    g = {k: np.ascontiguousarray(v[order]) for k, v in g.items()}
+    deg = g["degrees"].reshape(-1)
+    per_band = np.array([(deg == d).sum() for d in range(4)], np.int32)
+    cumsum = np.cumsum(per_band).astype(np.int32)
+    coeffs = np.array([1, 4, 9, 16], np.int32)
+    flat = np.concatenate([g["sh"][deg == d][:, :(d + 1) ** 2].reshape(-1) for d in range(4)]).astype(np.float32)
+    bg = np.array([0.2, 0.3, 0.4], np.float32)
+    ref = oracle_forward(bg, g, cam, H, W)
+    out = C_.rasterize_gaussians_variableSH_bands(
+        dev(bg), dev(g["means3D"]), torch.Tensor([]), dev(g["opacity"]), dev(g["scales"]), dev(g["rotations"]), 1.0,
+        torch.Tensor([]), dev(cam.world_view_transform), dev(cam.full_proj_transform), cam.tanfovx, cam.tanfovy, H, W,
+        dev(flat), dev(per_band), dev(cumsum), dev(coeffs), dev(g["degrees"]), dev(cam.camera_center), False, False)
+    check_forward(C_, out, ref, H, W, P)
+    # counter mode (forward.cu:560-564)
+    refc = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
+                       cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"],
+                       g["degrees"], cam.camera_center, counter_mode=True, want_ambig=True, ambig_rel=AMBIG_REL)
+    fargs, _ = hip_forward(C_, bg, g, cam, H, W)
+    outc = C_.rasterize_gaussians_counters(*fargs)
+    touched, transm = outc[-2].cpu().numpy(), outc[-1].cpu().numpy()
+    namb = int(refc["ambig"].sum())
+    assert np.abs(touched - refc["touched_pixels"]).sum() <= 2 * namb
+    np.testing.assert_allclose(transm, refc["transmittance"], rtol=1e-4, atol=1e-3 + namb)
+
+
+def test_empty_and_all_culled(C_):
+    cam = ss.make_camera(64, 48, 50.0, None)
+    bg = np.array([0.25, 0.5, 0.75], np.float32)
+    e3 = torch.zeros((0, 3), device="cuda")
+    out = C_.rasterize_gaussians(dev(bg), e3, torch.Tensor([]), torch.zeros((0, 1), device="cuda"), e3,
+                                 torch.zeros((0, 4), device="cuda"), 1.0, torch.Tensor([]),
+                                 dev(cam.world_view_transform), dev(cam.full_proj_transform), cam.tanfovx, cam.tanfovy,
+                                 48, 64, torch.zeros((0, 16, 3), device="cuda"),
+                                 torch.zeros((0, 1), dtype=torch.int32, device="cuda"), dev(cam.camera_center), False,
+                                 False)
+    assert out[0] == 0 and (out[1] == 0).all() and out[2].numel() == 0
+    g = ss.make_gaussians(300, cam, seed=0, degree_mode="all0")
+    g["means3D"][:, 2] = -1.0
+    fargs, fout = hip_forward(C_, bg, g, cam, 48, 64)
+    assert fout[0] == 0 and (fout[2] == 0).all()
+    np.testing.assert_array_equal(fout[1].cpu().numpy(), np.broadcast_to(bg[:, None, None], (3, 48, 64)))
+    bout = hip_backward(C_, fargs, fout, np.ones((3, 48, 64), np.float32), 0.0)
+    for t in bout[:8]:
+        assert (t == 0).all()
+    with pytest.raises(RuntimeError):
+        C_.rasterize_gaussians(dev(bg), torch.zeros((5, 4), device="cuda"), *fargs[2:])
+
+
+# -------------------------------------------------------------------------------------------------
+# BASELINE.json metric shape: size-independent properties (the oracle needs minutes here)
+# -------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def metric_scene():
+    w = ss.WORKLOADS["metric_500k_1600x1062"]
+    cam = ss.make_camera(w["W"], w["H"], w["f"], None)
+    g = ss.make_gaussians(w["P"], cam, seed=0, degree_mode=w["degree_mode"])
+    return w, cam, g
+
+
+def test_full_size_properties(C_, metric_scene):
+    w, cam, g = metric_scene
+    W, H, P = w["W"], w["H"], w["P"]
+    black, white = np.zeros(3, np.float32), np.ones(3, np.float32)
+    fargs, fout = hip_forward(C_, black, g, cam, H, W)
+    R, color, radii, geom, binning, img = fout
+    ex = C_.export_binning(P, R, H, W, geom, binning, img)
+    keys = ex["keys"]
+    assert R == int(ex["tiles_touched"].to(torch.int64).sum())                      # checksum of checksums
+    assert bool((keys[1:] >= keys[:-1]).all())                                      # sortedness (tile, depth)
+    rng_ = ex["ranges"].to(torch.int64)
+    assert int((rng_[:, 1] - rng_[:, 0]).sum()) == R                                # ranges partition the list
+    tile_of = keys >> 32
+    starts = rng_[:, 0][rng_[:, 1] > rng_[:, 0]]
+    assert bool((tile_of[starts] == torch.nonzero(rng_[:, 1] > rng_[:, 0]).squeeze(1)).all())
+    # equal-depth ties resolved by ascending Gaussian index (stable sort + ascending emission)
+    same = keys[1:] == keys[:-1]
+    pl = ex["point_list"].to(torch.int64)
+    assert bool((pl[1:][same] > pl[:-1][same]).all())
+    assert bool(((radii > 0) == (ex["tiles_touched"] > 0)).all())
+    # idempotence / determinism of the forward
+    _, fout2 = hip_forward(C_, black, g, cam, H, W)
+    assert fout2[0] == R and torch.equal(fout2[1], color) and torch.equal(fout2[2], radii)
+    # background linearity: out(bg) = C + T*bg  =>  out(white) - out(black) = final_T on every channel
+    _, foutw = hip_forward(C_, white, g, cam, H, W)
+    T = ex["final_T"].reshape(1, H, W)
+    assert float((foutw[1] - color - T).abs().max()) <= 2e-6
+    assert float(color.min()) >= 0.0 and bool(torch.isfinite(color).all())
+    # backward is linear in dL_dout_color
+    g1 = ss.upstream_grad(W, H, seed=1) * (W * H)
+    g2 = ss.upstream_grad(W, H, seed=2) * (W * H)
+    b1 = hip_backward(C_, fargs, fout, g1, 0.0)
+    b2 = hip_backward(C_, fargs, fout, g2, 0.0)
+    b3 = hip_backward(C_, fargs, fout, 0.5 * g1 - 2.0 * g2, 0.0)
+    for k in (0, 2, 3, 5, 6, 7):
+        lin = 0.5 * b1[k] - 2.0 * b2[k]
+        scale = float(lin.abs().max()) + 1e-30
+        assert float((b3[k] - lin).abs().max()) <= 2e-4 * scale, k
+    assert all(bool(torch.isfinite(t).all()) for t in b1[:8])
+    inv = radii == 0
+    assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())

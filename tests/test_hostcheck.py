@@ -1,0 +1,148 @@
+"""CPU execution of the PRODUCT's __host__ __device__ math (reduced-3dgs_amd/csrc/gauss_math.h, blend_math.h)
+through the test shim tests/hostcheck/hostcheck.hip, against the oracle.  No GPU needed: this catches
+transcription errors in the per-lane arithmetic before any GPU time is spent.  The kernels' cooperative
+parts (LDS staging, DPP reductions, atomics, sorts) are covered by the -m gpu tests only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth_scene as ss
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostcheck", "hostcheck.hip")
+SO = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _lib():
+    hdrs = [os.path.join(HERE, "..", "reduced-3dgs_amd", "csrc", h) for h in ("gauss_math.h", "blend_math.h")]
+    newest = max(os.path.getmtime(p) for p in [SRC] + hdrs)
+    if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available to build the host-check shim")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-o", SO, SRC])
+    return C.CDLL(SO)
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+CASES = [
+    dict(P=500, W=72, H=50, f=60.0, cam_seed=None, gseed=0, degree_mode="all3", lam=0.0, spread=1.0),
+    dict(P=500, W=70, H=45, f=60.0, cam_seed=2, gseed=1, degree_mode="mixed", lam=0.1, spread=1.0),
+    dict(P=400, W=64, H=64, f=50.0, cam_seed=4, gseed=2, degree_mode="all0", lam=0.0, spread=1.35),
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=["deg3", "mixed_sparsity", "deg0_clamp"])
+@pytest.mark.parametrize("precomp", [False, True], ids=["sh_scale_rot", "precomp_colour_cov"])
+def test_device_math_on_host_matches_oracle(kw, precomp):
+    L = _lib()
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=0.12, scale_sigma=0.7)
+    g["means3D"][:, :2] *= kw["spread"]
+    bg = np.array([0.3, 0.5, 0.7], np.float32)
+    rng = np.random.default_rng(5)
+    colors = cov = None
+    sh, scales, rots = g["sh"], g["scales"], g["rotations"]
+    if precomp:
+        colors = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+        o0 = orc.forward(bg, g["means3D"], None, g["opacity"], scales, rots, 1.0, None, cam.world_view_transform,
+                         cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, sh, g["degrees"], cam.camera_center)
+        cov = o0["state"]["cov3D"].copy()
+        cov[o0["radii"] == 0] = np.array([1e-2, 0, 0, 1e-2, 0, 1e-2], np.float32)
+        sh = scales = rots = None
+    out = orc.forward(bg, g["means3D"], colors, g["opacity"], scales, rots, 1.0, cov, cam.world_view_transform,
+                      cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, sh, g["degrees"], cam.camera_center,
+                      want_ambig=True)
+    st = out["state"]
+    M = 0 if sh is None else 16
+    radii = np.zeros(P, np.int32)
+    xy = np.zeros((P, 2), np.float32)
+    depths = np.zeros(P, np.float32)
+    conic_op = np.zeros((P, 4), np.float32)
+    rgb = np.zeros((P, 3), np.float32)
+    cbits = np.zeros(P, np.uint32)
+    tiles = np.zeros(P, np.uint32)
+    rect = np.zeros((P, 4), np.int32)
+    deg = np.ascontiguousarray(g["degrees"].reshape(-1))
+    view, proj, campos = (np.ascontiguousarray(a, np.float32) for a in
+                          (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+    opac = np.ascontiguousarray(g["opacity"].reshape(-1))
+    L.hc_preprocess(C.c_int(P), C.c_int(M), p(deg), p(g["means3D"]), p(scales), C.c_float(1.0), p(rots), p(opac),
+                    p(sh), p(cov), p(colors), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
+                    C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(radii), p(xy), p(depths), p(conic_op), p(rgb),
+                    p(cbits), p(tiles), p(rect))
+    vis = out["radii"] > 0
+    assert vis.sum() > 50
+    # integer outputs + everything computed without exp(): bit-exact
+    np.testing.assert_array_equal(radii, out["radii"])
+    np.testing.assert_array_equal(tiles, st["tiles_touched"])
+    np.testing.assert_array_equal(xy[vis], st["xy"][vis])
+    np.testing.assert_array_equal(depths[vis], st["depths"][vis])
+    np.testing.assert_array_equal(conic_op[vis, :3], st["conic_op"][vis, :3])
+    np.testing.assert_allclose(conic_op[vis, 3], st["conic_op"][vis, 3], rtol=3e-7)  # expf implementations
+    feat = colors if precomp else st["rgb"]
+    np.testing.assert_array_equal(rgb[vis], feat[vis])
+    if not precomp:
+        bits = st["clamped"][:, 0] | (st["clamped"][:, 1] << 1) | (st["clamped"][:, 2] << 2)
+        np.testing.assert_array_equal(cbits[vis], bits[vis])
+    area = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    np.testing.assert_array_equal(area[vis], st["tiles_touched"][vis])
+
+    # ---- blend forward on the oracle's binning -------------------------------------------------
+    N = W * H
+    color = np.zeros((3, H, W), np.float32)
+    final_T = np.zeros(N, np.float32)
+    n_contrib = np.zeros(N, np.uint32)
+    L.hc_blend_fwd(C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(feat),
+                   p(st["conic_op"]), p(bg), p(color), p(final_T), p(n_contrib))
+    ok = out["ambig"].reshape(-1) == 0
+    assert ok.mean() > 0.99
+    assert np.abs(color.reshape(3, -1) - out["color"].reshape(3, -1))[:, ok].max() < 1e-5
+    np.testing.assert_array_equal(n_contrib[ok], st["n_contrib"][ok])
+
+    # ---- blend backward -----------------------------------------------------------------------
+    dl = ss.upstream_grad(W, H, seed=9) * N
+    gr = orc.backward(st, dl, kw["lam"])
+    acc = np.zeros((P, 9), np.float64)
+    L.hc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(bg), p(st["xy"]),
+                   p(st["conic_op"]), p(feat), p(st["final_T"]), p(st["n_contrib"]), p(dl), p(acc))
+
+    def close(name, ref, got, rel=1e-4):
+        scale = np.abs(ref).max() + 1e-30
+        err = np.abs(ref - got).max()
+        assert err <= rel * scale, f"{name}: {err:.3e} vs {scale:.3e}"
+
+    close("dmean2D", gr["dL_dmeans2D"][:, :2], acc[:, :2])
+    close("dconic", gr["dL_dconic"][:, [0, 1, 3]], acc[:, 2:5])
+    close("dcolor", gr["dL_dcolors"], acc[:, 6:9])
+
+    # ---- per-Gaussian backward fed with the oracle's 2D-stage gradients -------------------------
+    d3 = np.zeros((P, 3), np.float32)
+    dcov = np.zeros((P, 6), np.float32)
+    dsh = np.zeros((P, max(M, 1), 3), np.float32)
+    dsc = np.zeros((P, 3), np.float32)
+    drot = np.zeros((P, 4), np.float32)
+    dop = acc[:, 5].astype(np.float32).copy()  # pre-sigmoid-chain opacity gradient = blend-stage sum
+    dm2 = np.ascontiguousarray(gr["dL_dmeans2D"])
+    dcon = np.ascontiguousarray(gr["dL_dconic"])
+    dcol = np.ascontiguousarray(gr["dL_dcolors"])
+    L.hc_preprocess_bwd(C.c_int(P), C.c_int(M), p(deg), p(g["means3D"]), p(radii), p(sh), p(cbits), p(scales),
+                        p(rots), C.c_float(1.0), p(cov), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
+                        C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(dm2), p(st["conic_op"]), p(dcon), p(dcol),
+                        C.c_float(kw["lam"]), p(d3), p(dcov), p(dsh), p(dsc), p(drot), p(dop))
+    close("dmean3D", gr["dL_dmeans3D"], d3, 1e-5)
+    close("dcov3D", gr["dL_dcov3D"], dcov, 1e-5)
+    close("dopacity", gr["dL_dopacity"].reshape(-1), dop)
+    if not precomp:
+        close("dsh", gr["dL_dsh"], dsh, 1e-5)
+        close("dscale", gr["dL_dscales"], dsc, 1e-5)
+        close("drot", gr["dL_drotations"], drot, 1e-5)
