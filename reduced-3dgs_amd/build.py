@@ -6,6 +6,8 @@ Per-translation-unit flags matter for parity:
   * preprocess*.hip : -ffp-contract=off + correctly rounded fp32 divide/sqrt, so the integer outputs
                       (radii, tile rects, tiles_touched, sort order) are reproducible bit-for-bit;
   * blend.hip       : contraction allowed (FMA) + hardware exp: compared to 1e-5 / 1e-4, not bitwise;
+                      -fno-slp-vectorize: SLP packing into v_pk_*_f32 cost 22 VGPRs (130 -> 108, one more
+                      wave per SIMD), ~40 v_mov shuffles and blocked the v_add_f32_dpp fusion of the reductions;
   * -munsafe-fp-atomics: float atomicAdd lowers to global_atomic_add_f32 instead of a CAS loop.
 hipcc cross-compiles without a GPU; the .so travels to the GPU box with the tree.
 """
@@ -25,7 +27,7 @@ UNITS = {
     "preprocess.hip": EXACT,
     "preprocess_bwd.hip": EXACT,
     "binning.hip": [],
-    "blend.hip": ["-ffp-contract=fast"],
+    "blend.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "capi.hip": [],
 }
 HEADERS = ["common.h", "gauss_math.h", "blend_math.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h")]

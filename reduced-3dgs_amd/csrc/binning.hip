@@ -70,55 +70,78 @@ static uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-// Pair emission, one wave per 64 depth-consecutive Gaussians.  Instead of one thread looping over all
-// tiles of its Gaussian (hundreds for a large splat while its neighbours idle), the wave flattens the
-// 64 tile counts into one range and every lane writes every 64th output: coalesced stores, no imbalance.
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, const uint32_t* __restrict__ order,
+// Pair emission, balanced over OUTPUT positions.  The reference loops one thread over all tiles of its
+// Gaussian (rasterizer_impl.cu:106-117); in depth order the nearest -- largest -- splats sit next to each
+// other, so any per-Gaussian (or per-64-Gaussian) work split has a tail: the first GPU version of this
+// kernel spent 234 us waiting for its first few waves.  Here every workgroup owns kEmitPerBlock
+// consecutive output slots: two lanes locate the slot range's first/last source Gaussian by binary
+// search in the inclusive scan, the block stages that <= kEmitPerBlock+1 long slice (end offset, id,
+// tile rect) in LDS, and every lane resolves its slots with an LDS binary search.  Stores are coalesced.
+constexpr int kEmitPerBlock = 1024;
+constexpr int kEmitSlice = kEmitPerBlock + 8;
+
+__device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restrict__ a, uint32_t n, uint32_t pos)
+{
+    uint32_t lo = 0, hi = n;  // smallest j in [0, n) with a[j] > pos (n if none)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] > pos)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, const uint32_t* __restrict__ order,
                                                          const uint32_t* __restrict__ offsets,
-                                                         const uint32_t* __restrict__ tiles,
                                                          const ushort4* __restrict__ rect, int gx,
                                                          uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out)
 {
-    __shared__ uint32_t s_end[4][64];
-    __shared__ uint32_t s_id[4][64];
-    __shared__ ushort4 s_rect[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    uint32_t end, cnt = 0, id = 0;
-    ushort4 rc = make_ushort4(0, 0, 0, 0);
-    if (j < P) {
-        id = order[j];
-        end = offsets[j];
-        cnt = tiles[id];
-        rc = rect[id];
-    } else {
-        end = offsets[P - 1];
+    __shared__ uint32_t s_end[kEmitSlice];
+    __shared__ uint32_t s_id[kEmitSlice];
+    __shared__ ushort4 s_rect[kEmitSlice];
+    __shared__ uint32_t s_j[2];
+    __shared__ uint32_t s_start0;
+    const uint32_t pos0 = blockIdx.x * (uint32_t)kEmitPerBlock;
+    const uint32_t pos1 = min(R, pos0 + (uint32_t)kEmitPerBlock);  // exclusive
+    if (threadIdx.x < 2) {
+        const uint32_t j = upper_bound_global(offsets, (uint32_t)P, threadIdx.x == 0 ? pos0 : pos1 - 1);
+        s_j[threadIdx.x] = j;
+        if (threadIdx.x == 0) s_start0 = j == 0 ? 0u : offsets[j - 1];
     }
-    s_end[wave][lane] = end;
-    s_id[wave][lane] = id;
-    s_rect[wave][lane] = rc;
-    const uint32_t wave_begin = __shfl(end - cnt, 0);
-    const uint32_t wave_end = __shfl(end, 63);
     __syncthreads();
-    const uint32_t total = wave_end - wave_begin;
-    for (uint32_t t = lane; t < total; t += 64) {
-        const uint32_t pos = wave_begin + t;
-        int lo = 0, hi = 63;  // smallest s with s_end[s] > pos
+    const uint32_t j_lo = s_j[0], j_hi = s_j[1];
+    // every Gaussian inside the slice owns >= 1 slot (culled ones sort to the very end), so n <= slots + 1
+    const uint32_t n = min(j_hi - j_lo + 1u, (uint32_t)kEmitSlice);
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+        const uint32_t id = order[j_lo + k];
+        s_end[k] = offsets[j_lo + k];
+        s_id[k] = id;
+        s_rect[k] = rect[id];
+    }
+    __syncthreads();
+    const uint32_t start0 = s_start0;
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (lo + hi) >> 1;
-            if (s_end[wave][mid] > pos)
-                hi = mid;
-            else
-                lo = mid + 1;
+    for (int e = 0; e < kEmitPerBlock / 256; e++) {
+        const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
+        if (pos < pos1) {
+            uint32_t lo = 0, hi = n - 1;  // smallest k with s_end[k] > pos; exists because pos < s_end[n-1]
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_end[mid] > pos)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            const uint32_t start = lo == 0 ? start0 : s_end[lo - 1];
+            const uint32_t local = pos - start;
+            const ushort4 r = s_rect[lo];
+            const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
+            const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
+            tile_out[pos] = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
+            id_out[pos] = s_id[lo];
         }
-        const uint32_t start = lo == 0 ? wave_begin : s_end[wave][lo - 1];
-        const uint32_t local = pos - start;
-        const ushort4 r = s_rect[wave][lo];
-        const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
-        const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x) order, rasterizer_impl.cu:106-117
-        tile_out[pos] = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
-        id_out[pos] = s_id[wave][lo];
     }
 }
 
@@ -145,8 +168,8 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
     const size_t Tn = (size_t)gx * gy;
     R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
     if (R <= 0) return;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.order, g.offsets, g.tiles,
-                       g.rect, gx, b.tile_in, b.gauss_in);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((R + kEmitPerBlock - 1) / kEmitPerBlock), dim3(256), 0, s, P, (uint32_t)R,
+                       g.order, g.offsets, g.rect, gx, b.tile_in, b.gauss_in);
     const int bits = (int)higher_msb((uint32_t)Tn);
     size_t bytes = b.temp_bytes;
     R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,

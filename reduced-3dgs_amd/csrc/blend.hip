@@ -18,6 +18,8 @@
 //     all for entries that touched no pixel of the region.
 //   * workgroup ids are remapped so that consecutive tiles run on the same XCD (shared L2 for the
 //     records of Gaussians straddling neighbouring tiles).
+#include <cstdlib>
+
 #include "blend_math.h"
 #include "common.h"
 
@@ -77,6 +79,16 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
+// pixels per lane: 4 (one wave per 16x16 tile), 2 (two waves per tile) or 1 (four waves per tile).
+// Environment override is a tuning knob for profiling runs; results are identical for every value.
+static int blend_ppl(const char* env, int dflt)
+{
+    const char* v = getenv(env);
+    if (!v) return dflt;
+    const int p = atoi(v);
+    return (p == 1 || p == 2 || p == 4) ? p : dflt;
+}
+
 struct BlendFwdArgs {
     const uint2* ranges;
     const uint32_t* point_list;
@@ -121,19 +133,35 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
         if (inside[q]) live |= 1u << q;
     }
 
+    // software pipeline: the records of chunk k+1 are gathered into registers while chunk k is blended
+    float4 nxa, nxb, nxc;
+    uint32_t nxid = 0;
+    nxa = nxb = nxc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (range.x + lane < range.y) {
+        nxid = a.point_list[range.x + lane];
+        const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+        nxa = g[0];
+        nxb = g[1];
+        nxc = g[2];
+    }
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
         if (__ballot(live != 0) == 0ull) break;  // every pixel of the region saturated
         __syncthreads();
-        const uint32_t idx = base + lane;
-        if (idx < range.y) {
-            const uint32_t id = a.point_list[idx];
-            const float4* g = reinterpret_cast<const float4*>(a.rec + id);
-            s_rec[lane].a = g[0];
-            s_rec[lane].b = g[1];
-            s_rec[lane].c = g[2];
-            s_id[lane] = id;
-        }
+        s_rec[lane].a = nxa;
+        s_rec[lane].b = nxb;
+        s_rec[lane].c = nxc;
+        s_id[lane] = nxid;
         __syncthreads();
+        {
+            const uint32_t idx = base + kChunk + lane;
+            if (idx < range.y) {
+                nxid = a.point_list[idx];
+                const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+                nxa = g[0];
+                nxb = g[1];
+                nxc = g[2];
+            }
+        }
         const int n = (int)min((uint32_t)kChunk, range.y - base);
         for (int j = 0; j < n; j++) {
             const Splat s = load_splat(s_rec[j]);
@@ -182,7 +210,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
 void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
                           ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s)
 {
-    constexpr int PPL = 4;
+    const int PPL = blend_ppl("R3DGS_FWD_PPL", 4);
     BlendFwdArgs a;
     a.ranges = img.ranges;
     a.point_list = b.point_list;
@@ -197,10 +225,15 @@ void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinS
     a.n_contrib = img.n_contrib;
     a.touched = touched;
     a.transmittance = transmittance;
-    if (touched)
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+    if (touched) {
+        if (PPL == 4) hipLaunchKernelGGL((blend_fwd_kernel<4, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+        else if (PPL == 2) hipLaunchKernelGGL((blend_fwd_kernel<2, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((blend_fwd_kernel<1, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+    } else {
+        if (PPL == 4) hipLaunchKernelGGL((blend_fwd_kernel<4, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+        else if (PPL == 2) hipLaunchKernelGGL((blend_fwd_kernel<2, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((blend_fwd_kernel<1, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,16 +303,29 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
     if (lmax == 0) return;
 
     const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
-    for (int cbase = (int)((lmax - 1) / kChunk) * kChunk; cbase >= 0; cbase -= kChunk) {
+    float4 nxa, nxb, nxc;
+    uint32_t nxid = 0;
+    nxa = nxb = nxc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cfirst = (int)((lmax - 1) / kChunk) * kChunk;
+    if ((uint32_t)cfirst + (uint32_t)lane < lmax) {
+        nxid = a.point_list[range.x + (uint32_t)cfirst + (uint32_t)lane];
+        const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+        nxa = g[0];
+        nxb = g[1];
+        nxc = g[2];
+    }
+    for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
         __syncthreads();
-        const uint32_t pos_l = (uint32_t)cbase + (uint32_t)lane;
-        if (pos_l < lmax) {
-            const uint32_t id = a.point_list[range.x + pos_l];
-            const float4* g = reinterpret_cast<const float4*>(a.rec + id);
-            s_rec[lane].a = g[0];
-            s_rec[lane].b = g[1];
-            s_rec[lane].c = g[2];
-            s_id[lane] = id;
+        s_rec[lane].a = nxa;
+        s_rec[lane].b = nxb;
+        s_rec[lane].c = nxc;
+        s_id[lane] = nxid;
+        if (cbase >= kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
+            nxid = a.point_list[range.x + (uint32_t)(cbase - kChunk) + (uint32_t)lane];
+            const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+            nxa = g[0];
+            nxb = g[1];
+            nxc = g[2];
         }
         s_grad[lane * kGradStride + 9] = 0.f;
         __syncthreads();
@@ -326,7 +372,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
 void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b,
                            const ImageState& img, const float* dL_dpix, hipStream_t s)
 {
-    constexpr int PPL = 4;
+    const int PPL = blend_ppl("R3DGS_BWD_PPL", 4);
     BlendBwdArgs a;
     a.ranges = img.ranges;
     a.point_list = b.point_list;
@@ -340,7 +386,9 @@ void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState&
     a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
     a.bg = view.bg;
     a.acc = g.acc;
-    hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
+    if (PPL == 4) hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(a.nblocks), dim3(64), 0, s, a);
+    else if (PPL == 2) hipLaunchKernelGGL((blend_bwd_kernel<2>), dim3(a.nblocks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((blend_bwd_kernel<1>), dim3(a.nblocks), dim3(64), 0, s, a);
 }
 
 }  // namespace r3
