@@ -48,6 +48,21 @@ __device__ __forceinline__ Splat load_splat(const LdsRec& r)
     return s;
 }
 
+__device__ __forceinline__ Splat splat_from_regs(const float4& a, const float4& b, const float4& c)
+{
+    Splat s;
+    s.x = a.x;
+    s.y = a.y;
+    s.cA = a.z;
+    s.cB = a.w;
+    s.cC = b.x;
+    s.op = b.y;
+    s.r = b.z;
+    s.g = b.w;
+    s.b = c.x;
+    return s;
+}
+
 // consecutive logical ids on one XCD: hardware places workgroup b on XCD b % 8 (speed only, never correctness)
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
 {
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
     const uint2 range = a.ranges[tile];
 
-    float pxf[PPL], pyf[PPL];
+    float pxf[PPL], pyf[PPL], qx0[PPL], qy0[PPL];
     FwdPix pix[PPL];
     bool inside[PPL];
     uint32_t live = 0;  // bit q set while pixel q still blends
@@ -124,6 +139,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
     for (int q = 0; q < PPL; q++) {
         int px, py;
         pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
+        qx0[q] = (float)(px - (lane & 7));   // first pixel column / row of quadrant q (wave-uniform)
+        qy0[q] = (float)(py - (lane >> 3));
         pxf[q] = (float)px;
         pyf[q] = (float)py;
         inside[q] = px < a.W && py < a.H;
@@ -151,6 +168,17 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
         s_rec[lane].b = nxb;
         s_rec[lane].c = nxc;
         s_id[lane] = nxid;
+        // region pre-test: lane j decides for entry j which of this wave's quadrants it can reach at all
+        unsigned long long qmask[PPL], anymask = 0ull;
+        {
+            const Splat mine = splat_from_regs(nxa, nxb, nxc);
+            const bool have = base + lane < range.y;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
+                anymask |= qmask[q];
+            }
+        }
         __syncthreads();
         {
             const uint32_t idx = base + kChunk + lane;
@@ -162,15 +190,16 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
                 nxc = g[2];
             }
         }
-        const int n = (int)min((uint32_t)kChunk, range.y - base);
-        for (int j = 0; j < n; j++) {
+        while (anymask) {
+            const int j = __builtin_ctzll(anymask);
+            anymask &= anymask - 1ull;
             const Splat s = load_splat(s_rec[j]);
             const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
             int cnt = 0;
             float tsum = 0.f;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                if (live & (1u << q)) {
+                if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
                     float Tb;
                     const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
                     if (r == 2) live &= ~(1u << q);
@@ -270,13 +299,15 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
     const size_t plane = (size_t)a.W * a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-    float pxf[PPL], pyf[PPL];
+    float pxf[PPL], pyf[PPL], qx0[PPL], qy0[PPL];
     BwdPix pix[PPL];
     uint32_t lmax = 0;
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
         int px, py;
         pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
+        qx0[q] = (float)(px - (lane & 7));
+        qy0[q] = (float)(py - (lane >> 3));
         pxf[q] = (float)px;
         pyf[q] = (float)py;
         const bool inside = px < a.W && py < a.H;
@@ -320,6 +351,16 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
         s_rec[lane].b = nxb;
         s_rec[lane].c = nxc;
         s_id[lane] = nxid;
+        unsigned long long qmask[PPL], anymask = 0ull;
+        {
+            const Splat mine = splat_from_regs(nxa, nxb, nxc);
+            const bool have = (uint32_t)cbase + (uint32_t)lane < lmax;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
+                anymask |= qmask[q];
+            }
+        }
         if (cbase >= kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
             nxid = a.point_list[range.x + (uint32_t)(cbase - kChunk) + (uint32_t)lane];
             const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
@@ -330,14 +371,17 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
         s_grad[lane * kGradStride + 9] = 0.f;
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
-        for (int j = n - 1; j >= 0; j--) {
+        while (anymask) {  // back to front: highest set bit first
+            const int j = 63 - __builtin_clzll(anymask);
+            anymask &= ~(1ull << j);
             const Splat s = load_splat(s_rec[j]);
             const uint32_t pos = (uint32_t)(cbase + j);
             SplatGrad sg;
             sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
             bool any = false;
 #pragma unroll
-            for (int q = 0; q < PPL; q++) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
+            for (int q = 0; q < PPL; q++)
+                if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
             if (__ballot(any) != 0ull) {
                 const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
                 const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);

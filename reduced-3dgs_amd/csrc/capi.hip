@@ -5,7 +5,9 @@
 // :359-504, :508-630 of /root/reference/submodules/diff-gaussian-rasterization).
 // Differences in how the work is issued (results are the same):
 //   * everything runs on the caller's HIP stream; the only host synchronisation is the read-back of
-//     num_rendered, which sizes the caller-owned binning blob (same structural sync as the reference);
+//     num_rendered, which sizes the caller-owned binning blob (same structural sync as the reference, but
+//     R is produced by the first kernel and fetched on a side stream while the depth sort runs, so the GPU
+//     does not idle during the host round trip);
 //   * no per-call hipMalloc/hipFree: all scratch lives in the three caller blobs;
 //   * `debug` makes every stage synchronise and surface its error (the reference's CHECK_CUDA).
 #include "../../include/r3dgs_rasterizer.h"
@@ -93,6 +95,29 @@ struct StageTimer {
     }
 };
 
+// Host-side resources for the num_rendered read-back: a non-blocking side stream, two events and one
+// pinned word, per (host thread, device).  The copy is ordered after the preprocess kernel by an event and
+// runs beside the depth sort, so the structural host round trip of the forward is hidden behind GPU work.
+struct ReadbackCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t after_pre = nullptr, copied = nullptr;
+    uint32_t* pinned = nullptr;
+};
+ReadbackCtx& readback_ctx()
+{
+    thread_local std::unordered_map<int, ReadbackCtx> per_device;
+    int dev = 0;
+    R3_HIP(hipGetDevice(&dev));
+    ReadbackCtx& c = per_device[dev];
+    if (!c.side) {
+        R3_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
+        R3_HIP(hipEventCreateWithFlags(&c.copied, hipEventDisableTiming));
+        R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(uint32_t), hipHostMallocDefault));
+    }
+    return c;
+}
+
 template <class F>
 int guarded(F&& f)
 {
@@ -169,14 +194,17 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     launch_preprocess(in, view, geom, radii, s);
     t0.stop();
     check_launch("preprocess", s, debug);
+    ReadbackCtx& rb = readback_ctx();
+    R3_HIP(hipEventRecord(rb.after_pre, s));
+    R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
+    R3_HIP(hipMemcpyAsync(rb.pinned, &geom.header->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, rb.side));
+    R3_HIP(hipEventRecord(rb.copied, rb.side));
     StageTimer t1(kDepthSort, s);
-    run_depth_sort_and_scan(P, geom, s);
+    run_depth_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
     t1.stop();
+    R3_HIP(hipEventSynchronize(rb.copied));
+    const uint32_t R = *rb.pinned;
     check_launch("depth sort + scan", s, debug);
-
-    uint32_t R = 0;
-    R3_HIP(hipMemcpyAsync(&R, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    R3_HIP(hipStreamSynchronize(s));
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
 
     const size_t tile_temp = cached_tile_temp(R);

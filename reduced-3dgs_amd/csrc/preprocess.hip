@@ -35,6 +35,7 @@ struct PreArgs {
     uint32_t* depth_key;
     uint32_t* tiles;
     uint32_t* visible_count;
+    uint32_t* num_rendered;
     int* radii;
 };
 
@@ -156,8 +157,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
         a.tiles[i] = o.tiles;
         a.depth_key[i] = dkey;
     }
+    // per-wave totals -> two atomics per wave: visible count (SH-sparsity normaliser of the backward) and
+    // num_rendered.  R does not depend on the depth order, so the host can fetch it right after this kernel
+    // and size the binning blob while the GPU is still busy with the depth sort + scan (capi.hip).
     const unsigned long long vmask = __ballot(vis);
-    if (lane == 0 && vmask) atomicAdd(a.visible_count, (uint32_t)__popcll(vmask));
+    uint32_t tsum = o.tiles;
+    for (int off = 32; off > 0; off >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, off);
+    if (lane == 0 && vmask) {
+        atomicAdd(a.visible_count, (uint32_t)__popcll(vmask));
+        atomicAdd(a.num_rendered, tsum);
+    }
 }
 
 void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s)
@@ -170,6 +179,7 @@ void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g
     a.depth_key = g.depth_key;
     a.tiles = g.tiles;
     a.visible_count = &g.header->visible_count;
+    a.num_rendered = &g.header->num_rendered;
     a.radii = radii;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
     if (in.coeffs_num)

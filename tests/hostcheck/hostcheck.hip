@@ -89,13 +89,17 @@ static Splat splat_of(const float* xy, const float* conic_op, const float* rgb, 
     return s;
 }
 
+// use_region != 0: apply the kernels' per-(entry, 8x8 quadrant) pre-test exactly as blend.hip does; the
+// outputs must be identical with and without it.  *skipped / *total count (entry, quadrant) pairs.
 void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
-                  const float* conic_op, const float* bg, float* out_color, float* final_T, unsigned* n_contrib)
+                  const float* conic_op, const float* bg, float* out_color, float* final_T, unsigned* n_contrib,
+                  int use_region, long* skipped, long* total)
 {
     const int gx = (W + kTile - 1) / kTile;
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             const int tile = (py / kTile) * gx + px / kTile;
+            const float qx0 = (float)((px / 8) * 8), qy0 = (float)((py / 8) * 8);
             FwdPix p;
             p.T = 1.f;
             p.C0 = p.C1 = p.C2 = 0.f;
@@ -103,6 +107,14 @@ void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_li
             for (unsigned k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
                 float Tb;
                 const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
+                if (use_region) {
+                    const bool keep = region_may_contribute(s, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+                    if (px % 8 == 0 && py % 8 == 0) {
+                        if (total) ++*total;
+                        if (skipped && !keep) ++*skipped;
+                    }
+                    if (!keep) continue;
+                }
                 if (fwd_step(s, (float)px, (float)py, k - ranges[2 * tile] + 1, p, &Tb) == 2) break;
             }
             const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
@@ -117,7 +129,7 @@ void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_li
 // acc: double[P][9] = mx, my, cA, cB, cC, op, r, g, b  (mx,my already scaled by 0.5W / 0.5H)
 void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
                   const float* xy, const float* conic_op, const float* rgb, const float* final_T,
-                  const unsigned* n_contrib, const float* dL_dpix, double* acc)
+                  const unsigned* n_contrib, const float* dL_dpix, double* acc, int use_region)
 {
     (void)P;
     const int gx = (W + kTile - 1) / kTile;
@@ -138,6 +150,10 @@ void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* p
             for (long pos = (long)p.last - 1; pos >= 0; pos--) {
                 const unsigned id = point_list[ranges[2 * tile] + pos];
                 const Splat s = splat_of(xy, conic_op, rgb, id);
+                if (use_region) {
+                    const float qx0 = (float)((px / 8) * 8), qy0 = (float)((py / 8) * 8);
+                    if (!region_may_contribute(s, qx0, qx0 + 7.f, qy0, qy0 + 7.f)) continue;
+                }
                 SplatGrad g;
                 g.mx = g.my = g.cA = g.cB = g.cC = g.op = g.r = g.g = g.b = 0.f;
                 if (bwd_step(s, (float)px, (float)py, (unsigned)pos, p, g)) {
@@ -154,6 +170,56 @@ void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* p
                 }
             }
         }
+}
+
+// Fuzz the conservativeness of region_may_contribute(): random (also extremely anisotropic) splats against
+// random 8x8 pixel blocks; a violation = the pre-test says "skip" although some pixel's fwd_step would blend.
+// Returns the number of violations; *n_skip counts skipped blocks, *n_tight blocks kept with no contributor.
+long hc_region_fuzz(long n, unsigned seed, long* n_skip, long* n_keep_empty)
+{
+    unsigned long long st = seed * 2654435761ull + 88172645463325252ull;
+    auto rnd = [&]() {  // xorshift64*, uniform in [0,1)
+        st ^= st >> 12;
+        st ^= st << 25;
+        st ^= st >> 27;
+        return (float)(((st * 2685821657736338717ull) >> 40) & 0xFFFFFF) / 16777216.0f;
+    };
+    long bad = 0;
+    for (long it = 0; it < n; it++) {
+        // random covariance: eigenvalues spanning 1e-1 .. 1e5 px^2 (+0.3 low-pass like the rasterizer), any angle
+        const float l1 = expf(rnd() * 13.8f - 2.3f), l2 = l1 * expf(-rnd() * 11.5f);
+        const float th = rnd() * 6.2831853f, c = cosf(th), s_ = sinf(th);
+        const float a = c * c * l1 + s_ * s_ * l2 + 0.3f, b = c * s_ * (l1 - l2), d = s_ * s_ * l1 + c * c * l2 + 0.3f;
+        const float det = a * d - b * b;
+        Splat s;
+        s.cA = d / det;
+        s.cB = -b / det;
+        s.cC = a / det;
+        s.op = rnd() < 0.1f ? rnd() * 0.01f : rnd();
+        const float reach = 4.f * sqrtf(l1) + 12.f;
+        s.x = 100.f + (rnd() * 2.f - 1.f) * reach;
+        s.y = 100.f + (rnd() * 2.f - 1.f) * reach;
+        s.r = s.g = s.b = 0.5f;
+        const float X0 = 96.f, Y0 = 96.f;
+        const bool keep = region_may_contribute(s, X0, X0 + 7.f, Y0, Y0 + 7.f);
+        bool any = false;
+        for (int py = 0; py < 8 && !any; py++)
+            for (int px = 0; px < 8; px++) {
+                FwdPix p;
+                p.T = 1.f;
+                p.C0 = p.C1 = p.C2 = 0.f;
+                p.last = 0;
+                float Tb;
+                if (fwd_step(s, X0 + px, Y0 + py, 1, p, &Tb) != 0) {
+                    any = true;
+                    break;
+                }
+            }
+        if (!keep && any) bad++;
+        if (!keep) ++*n_skip;
+        if (keep && !any) ++*n_keep_empty;
+    }
+    return bad;
 }
 
 void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const int* radii, const float* shs,

@@ -103,7 +103,17 @@ def test_device_math_on_host_matches_oracle(kw, precomp):
     final_T = np.zeros(N, np.float32)
     n_contrib = np.zeros(N, np.uint32)
     L.hc_blend_fwd(C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(feat),
-                   p(st["conic_op"]), p(bg), p(color), p(final_T), p(n_contrib))
+                   p(st["conic_op"]), p(bg), p(color), p(final_T), p(n_contrib), C.c_int(0), None, None)
+    # the kernels' region pre-test (blend_math.h region_may_contribute) must not change a single bit
+    color2, final_T2, n_contrib2 = np.zeros_like(color), np.zeros_like(final_T), np.zeros_like(n_contrib)
+    skipped, total = C.c_long(0), C.c_long(0)
+    L.hc_blend_fwd(C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(feat),
+                   p(st["conic_op"]), p(bg), p(color2), p(final_T2), p(n_contrib2), C.c_int(1), C.byref(skipped),
+                   C.byref(total))
+    np.testing.assert_array_equal(color2, color)
+    np.testing.assert_array_equal(final_T2, final_T)
+    np.testing.assert_array_equal(n_contrib2, n_contrib)
+    assert skipped.value > 0.2 * total.value  # and it must actually remove work
     ok = out["ambig"].reshape(-1) == 0
     assert ok.mean() > 0.99
     assert np.abs(color.reshape(3, -1) - out["color"].reshape(3, -1))[:, ok].max() < 1e-5
@@ -114,7 +124,11 @@ def test_device_math_on_host_matches_oracle(kw, precomp):
     gr = orc.backward(st, dl, kw["lam"])
     acc = np.zeros((P, 9), np.float64)
     L.hc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(bg), p(st["xy"]),
-                   p(st["conic_op"]), p(feat), p(st["final_T"]), p(st["n_contrib"]), p(dl), p(acc))
+                   p(st["conic_op"]), p(feat), p(st["final_T"]), p(st["n_contrib"]), p(dl), p(acc), C.c_int(0))
+    acc2 = np.zeros((P, 9), np.float64)
+    L.hc_blend_bwd(C.c_int(P), C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(bg), p(st["xy"]),
+                   p(st["conic_op"]), p(feat), p(st["final_T"]), p(st["n_contrib"]), p(dl), p(acc2), C.c_int(1))
+    np.testing.assert_array_equal(acc2, acc)
 
     def close(name, ref, got, rel=1e-4):
         scale = np.abs(ref).max() + 1e-30
@@ -146,3 +160,16 @@ def test_device_math_on_host_matches_oracle(kw, precomp):
         close("dsh", gr["dL_dsh"], dsh, 1e-5)
         close("dscale", gr["dL_dscales"], dsc, 1e-5)
         close("drot", gr["dL_drotations"], drot, 1e-5)
+
+
+def test_region_pretest_is_conservative_fuzz():
+    """2M random splats (eigenvalue ratios up to 1e5, opacities down to 1e-4) x one 8x8 block: the kernels'
+    skip test must never fire when any pixel of the block would blend, and should be tight otherwise."""
+    L = _lib()
+    L.hc_region_fuzz.restype = C.c_long
+    skip, keep_empty = C.c_long(0), C.c_long(0)
+    n = 2_000_000
+    bad = L.hc_region_fuzz(C.c_long(n), C.c_uint(1234), C.byref(skip), C.byref(keep_empty))
+    assert bad == 0
+    assert skip.value > 0.3 * n            # the fuzz distribution exercises the skip path
+    assert keep_empty.value < 0.02 * n     # exact minimisation: almost no false keeps
