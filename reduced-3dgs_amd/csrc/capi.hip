@@ -101,7 +101,7 @@ struct StageTimer {
 struct ReadbackCtx {
     hipStream_t side = nullptr;
     hipEvent_t after_pre = nullptr, copied = nullptr;
-    uint32_t* pinned = nullptr;
+    r3::GeomHeader* pinned = nullptr;
 };
 ReadbackCtx& readback_ctx()
 {
@@ -113,7 +113,7 @@ ReadbackCtx& readback_ctx()
         R3_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.copied, hipEventDisableTiming));
-        R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(uint32_t), hipHostMallocDefault));
+        R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(r3::GeomHeader), hipHostMallocDefault));
     }
     return c;
 }
@@ -197,13 +197,16 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     ReadbackCtx& rb = readback_ctx();
     R3_HIP(hipEventRecord(rb.after_pre, s));
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
-    R3_HIP(hipMemcpyAsync(rb.pinned, &geom.header->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, rb.side));
+    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, sizeof(GeomHeader), hipMemcpyDeviceToHost, rb.side));
     R3_HIP(hipEventRecord(rb.copied, rb.side));
     StageTimer t1(kDepthSort, s);
     run_depth_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
     t1.stop();
     R3_HIP(hipEventSynchronize(rb.copied));
-    const uint32_t R = *rb.pinned;
+    uint64_t R64 = 0;
+    for (int k = 0; k < kShards; k++) R64 += rb.pinned->shard[k].num_rendered;
+    if (R64 > 0x7fffffffull) throw Error("num_rendered exceeds 2^31-1");
+    const uint32_t R = (uint32_t)R64;
     check_launch("depth sort + scan", s, debug);
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
 

@@ -24,13 +24,18 @@ namespace r3 {
 constexpr size_t kAlign = 256;
 constexpr int kAccStride = 12;  // floats per Gaussian in the backward accumulator (9 used)
 
+// Per-view counters produced by the preprocess kernel.  One atomic per workgroup, spread over kShards
+// words that sit 128 B apart: the first GPU profile showed 7.8k same-address atomics (one per wave) costing
+// ~90 us -- more than the kernel's whole memory stream.  Consumers add the shards up.
+constexpr int kShards = 32;
 struct GeomHeader {
-    uint32_t visible_count;  // #Gaussians with radii > 0 in this view (rasterizer_impl.cu:549-566)
-    uint32_t num_rendered;   // R
-    uint32_t magic;
-    uint32_t pad[61];
+    struct Shard {
+        uint32_t visible;       // #Gaussians with radii > 0 (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
+        uint32_t num_rendered;  // sum of tiles_touched
+        uint32_t pad[30];
+    } shard[kShards];
 };
-static_assert(sizeof(GeomHeader) == 256, "header is one 256-B line");
+static_assert(sizeof(GeomHeader) == 128 * kShards, "one 128-B line per shard");
 
 struct Carver {
     char* p;

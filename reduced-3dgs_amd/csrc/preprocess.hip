@@ -34,8 +34,7 @@ struct PreArgs {
     ushort4* rect;
     uint32_t* depth_key;
     uint32_t* tiles;
-    uint32_t* visible_count;
-    uint32_t* num_rendered;
+    GeomHeader* header;
     int* radii;
 };
 
@@ -82,7 +81,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
             c6p = c6;
         } else {
             for (int k = 0; k < 3; k++) sc[k] = a.in.scales[3 * i + k];
-            for (int k = 0; k < 4; k++) q[k] = a.in.rotations[4 * i + k];
+            const float4 qv = reinterpret_cast<const float4*>(a.in.rotations)[i];
+            q[0] = qv.x;
+            q[1] = qv.y;
+            q[2] = qv.z;
+            q[3] = qv.w;
         }
         preprocess_one(cam, mx, my, mz, sc, q, c6p, a.in.opacities[i], &o);
     }
@@ -118,7 +121,19 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
     if (wave_needs) {
         const float* src = a.in.shs + span_first;
         float* dst = s_sh[wave];
-        for (int e = lane; e < span_len; e += 64) dst[skew(e)] = src[e];
+        if (((span_first | span_len) & 3) == 0) {  // 16-B aligned span (always true for M = 16): dwordx4 loads
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            for (int e4 = lane; e4 < (span_len >> 2); e4 += 64) {
+                const float4 v = src4[e4];
+                const int e = e4 << 2;
+                dst[skew(e)] = v.x;
+                dst[skew(e + 1)] = v.y;
+                dst[skew(e + 2)] = v.z;
+                dst[skew(e + 3)] = v.w;
+            }
+        } else {
+            for (int e = lane; e < span_len; e += 64) dst[skew(e)] = src[e];
+        }
     }
     __syncthreads();
 
@@ -163,9 +178,23 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
     const unsigned long long vmask = __ballot(vis);
     uint32_t tsum = o.tiles;
     for (int off = 32; off > 0; off >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, off);
-    if (lane == 0 && vmask) {
-        atomicAdd(a.visible_count, (uint32_t)__popcll(vmask));
-        atomicAdd(a.num_rendered, tsum);
+    __shared__ uint32_t s_cnt[kPreBlock / 64][2];
+    if (lane == 0) {
+        s_cnt[wave][0] = (uint32_t)__popcll(vmask);
+        s_cnt[wave][1] = tsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t v = 0, r = 0;
+        for (int k = 0; k < kPreBlock / 64; k++) {
+            v += s_cnt[k][0];
+            r += s_cnt[k][1];
+        }
+        if (v) {
+            GeomHeader::Shard* sh = a.header->shard + (blockIdx.x & (kShards - 1));
+            atomicAdd(&sh->visible, v);
+            atomicAdd(&sh->num_rendered, r);
+        }
     }
 }
 
@@ -178,8 +207,7 @@ void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g
     a.rect = g.rect;
     a.depth_key = g.depth_key;
     a.tiles = g.tiles;
-    a.visible_count = &g.header->visible_count;
-    a.num_rendered = &g.header->num_rendered;
+    a.header = g.header;
     a.radii = radii;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
     if (in.coeffs_num)

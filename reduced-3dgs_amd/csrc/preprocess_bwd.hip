@@ -33,7 +33,7 @@ struct PreBwdArgs {
     const int* radii;
     const GRec* rec;
     const float* acc;
-    const uint32_t* visible_count;
+    const GeomHeader* header;
     float lambda_sh;
     BwdOutputs out;
 };
@@ -92,7 +92,11 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
         project_backward(cam, mx, my, mz, g2x, g2y, dmean);
         if (has_sh) {
             float mult = 0.f;
-            if (a.lambda_sh != 0.f) mult = a.lambda_sh / (float)((int)(*a.visible_count) * 15 * 3);
+            if (a.lambda_sh != 0.f) {
+                uint32_t V = 0;
+                for (int k = 0; k < kShards; k++) V += a.header->shard[k].visible;
+                mult = a.lambda_sh / (float)((int)V * 15 * 3);
+            }
             const int deg = a.in.degrees[i];
             K = (deg + 1) * (deg + 1);
             sh_backward(deg, row, row, mx, my, mz, cam.campos, r.clamp_bits, dcol, mult, dmean);
@@ -159,7 +163,7 @@ void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, con
     a.radii = radii;
     a.rec = g.rec;
     a.acc = g.acc;
-    a.visible_count = &g.header->visible_count;
+    a.header = g.header;
     a.lambda_sh = lambda_sh_sparsity;
     a.out = out;
     const int blocks = (in.P + kBwdBlock - 1) / kBwdBlock;

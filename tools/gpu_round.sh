@@ -27,6 +27,7 @@ fi
 if [ "${PROF:-1}" = "1" ]; then
   ( cd /tmp && timeout ${T_PROF:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o r -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline ) > gpurun_out/prof.log 2>&1; echo "prof rc=$?" >> $S
 fi
+if [ "${LISTCTR:-0}" = "1" ]; then ( cd /tmp && timeout 60 rocprofv3 -L ) > gpurun_out/counters.txt 2>&1; fi
 if [ -n "${PMC:-}" ]; then   # separate counter passes, kernel-trace only (never mixed with sys/hip traces)
   i=0
   IFS=';' read -ra PASSES <<< "$PMC"
