@@ -86,6 +86,19 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// sum over each 16-lane DPP row, result in every lane of the row
+__device__ __forceinline__ float row_sum(float v)
+{
+#define R3_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    R3_DPP_ADD(0xb1);   // quad_perm [1,0,3,2]
+    R3_DPP_ADD(0x4e);   // quad_perm [2,3,0,1]
+    R3_DPP_ADD(0x124);  // row_ror:4
+    R3_DPP_ADD(0x128);  // row_ror:8
+#undef R3_DPP_ADD
+    return v;
+}
+
 template <int PPL>
 __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q, int lane, int* px, int* py)
 {
@@ -190,34 +203,47 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
                 nxc = g[2];
             }
         }
-        while (anymask) {
-            const int j = __builtin_ctzll(anymask);
+        if (anymask) {
+            // walk the surviving entries front to back; the LDS read of the next survivor is issued before
+            // the current one is blended, so its latency hides behind the per-pixel arithmetic
+            int jn = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
-            const Splat s = load_splat(s_rec[j]);
-            const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
-            int cnt = 0;
-            float tsum = 0.f;
+            Splat s_next = load_splat(s_rec[jn]);
+            for (;;) {
+                const Splat s = s_next;
+                const int j = jn;
+                const bool more = anymask != 0ull;
+                if (more) {
+                    jn = __builtin_ctzll(anymask);
+                    anymask &= anymask - 1ull;
+                    s_next = load_splat(s_rec[jn]);
+                }
+                const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
+                int cnt = 0;
+                float tsum = 0.f;
 #pragma unroll
-            for (int q = 0; q < PPL; q++) {
-                if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
-                    float Tb;
-                    const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
-                    if (r == 2) live &= ~(1u << q);
-                    if (COUNTERS && r == 1) {
-                        cnt++;
-                        tsum += Tb;
+                for (int q = 0; q < PPL; q++) {
+                    if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
+                        float Tb;
+                        const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
+                        if (r == 2) live &= ~(1u << q);
+                        if (COUNTERS && r == 1) {
+                            cnt++;
+                            tsum += Tb;
+                        }
                     }
                 }
-            }
-            if (COUNTERS) {  // forward.cu:560-564, one atomic pair per (region, Gaussian) instead of per pixel
-                if (__ballot(cnt != 0) != 0ull) {
-                    const float c = wave_sum_to_lane63((float)cnt);
-                    const float t = wave_sum_to_lane63(tsum);
-                    if (lane == 63) {
-                        atomicAdd(a.touched + s_id[j], (int)c);
-                        atomicAdd(a.transmittance + s_id[j], t);
+                if (COUNTERS) {  // forward.cu:560-564, one atomic pair per (region, Gaussian) instead of per pixel
+                    if (__ballot(cnt != 0) != 0ull) {
+                        const float c = wave_sum_to_lane63((float)cnt);
+                        const float t = wave_sum_to_lane63(tsum);
+                        if (lane == 63) {
+                            atomicAdd(a.touched + s_id[j], (int)c);
+                            atomicAdd(a.transmittance + s_id[j], t);
+                        }
                     }
                 }
+                if (!more) break;
             }
         }
     }
@@ -368,47 +394,62 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
             nxb = g[1];
             nxc = g[2];
         }
-        s_grad[lane * kGradStride + 9] = 0.f;
+#pragma unroll
+        for (int k = 0; k < kGradStride; k++) s_grad[lane * kGradStride + k] = 0.f;
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
-        while (anymask) {  // back to front: highest set bit first
-            const int j = 63 - __builtin_clzll(anymask);
-            anymask &= ~(1ull << j);
-            const Splat s = load_splat(s_rec[j]);
-            const uint32_t pos = (uint32_t)(cbase + j);
-            SplatGrad sg;
-            sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < PPL; q++)
-                if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
-            if (__ballot(any) != 0ull) {
-                const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
-                const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);
-                const float v4 = wave_sum_to_lane63(sg.cC), v5 = wave_sum_to_lane63(sg.op);
-                const float v6 = wave_sum_to_lane63(sg.r), v7 = wave_sum_to_lane63(sg.g);
-                const float v8 = wave_sum_to_lane63(sg.b);
-                if (lane == 63) {
-                    float* d = s_grad + j * kGradStride;
-                    d[0] = v0 * half_w;
-                    d[1] = v1 * half_h;
-                    d[2] = v2;
-                    d[3] = v3;
-                    d[4] = v4;
-                    d[5] = v5;
-                    d[6] = v6;
-                    d[7] = v7;
-                    d[8] = v8;
-                    d[9] = 1.f;
+        if (anymask) {
+            // back to front over the surviving entries (highest set bit first), next record prefetched from LDS
+            int jn = 63 - __builtin_clzll(anymask);
+            anymask &= ~(1ull << jn);
+            Splat s_next = load_splat(s_rec[jn]);
+            for (;;) {
+                const Splat s = s_next;
+                const int j = jn;
+                const bool more = anymask != 0ull;
+                if (more) {
+                    jn = 63 - __builtin_clzll(anymask);
+                    anymask &= ~(1ull << jn);
+                    s_next = load_splat(s_rec[jn]);
                 }
+                const uint32_t pos = (uint32_t)(cbase + j);
+                SplatGrad sg;
+                sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < PPL; q++)
+                    if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
+                if (__ballot(any) != 0ull) {
+                    // 9 sums over the wave: 4 DPP steps leave each 16-lane row's sum in all its lanes, then one
+                    // lane per row adds it into the entry's LDS slot (4 same-address LDS atomics per component)
+                    const float v0 = row_sum(sg.mx), v1 = row_sum(sg.my), v2 = row_sum(sg.cA);
+                    const float v3 = row_sum(sg.cB), v4 = row_sum(sg.cC), v5 = row_sum(sg.op);
+                    const float v6 = row_sum(sg.r), v7 = row_sum(sg.g), v8 = row_sum(sg.b);
+                    if ((lane & 15) == 15) {
+                        float* d = s_grad + j * kGradStride;
+                        atomicAdd(d + 0, v0);
+                        atomicAdd(d + 1, v1);
+                        atomicAdd(d + 2, v2);
+                        atomicAdd(d + 3, v3);
+                        atomicAdd(d + 4, v4);
+                        atomicAdd(d + 5, v5);
+                        atomicAdd(d + 6, v6);
+                        atomicAdd(d + 7, v7);
+                        atomicAdd(d + 8, v8);
+                        d[9] = 1.f;
+                    }
+                }
+                if (!more) break;
             }
         }
         __syncthreads();
         if (lane < n && s_grad[lane * kGradStride + 9] != 0.f) {
             float* dst = a.acc + (size_t)s_id[lane] * kAccStride;
             const float* src = s_grad + lane * kGradStride;
+            atomicAdd(dst + 0, src[0] * half_w);  // viewport factors of backward.cu:498-499, applied once
+            atomicAdd(dst + 1, src[1] * half_h);
 #pragma unroll
-            for (int k = 0; k < 9; k++) atomicAdd(dst + k, src[k]);
+            for (int k = 2; k < 9; k++) atomicAdd(dst + k, src[k]);
         }
     }
 }

@@ -149,9 +149,10 @@ R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& 
     const float dG_ddely = -gdy * s.cC - gdx * s.cB;
     a.mx += dL_dG * dG_ddelx;
     a.my += dL_dG * dG_ddely;
-    a.cA += -0.5f * gdx * dx * dL_dG;
-    a.cB += -0.5f * gdx * dy * dL_dG;
-    a.cC += -0.5f * gdy * dy * dL_dG;
+    const float hx = -0.5f * dL_dG * gdx, hy = -0.5f * dL_dG * gdy;
+    a.cA += hx * dx;
+    a.cB += hx * dy;
+    a.cC += hy * dy;
     a.op += G * dL_dalpha;
     return true;
 }
