@@ -4,20 +4,25 @@
 // /root/reference/submodules/diff-gaussian-rasterization.
 //
 // MI355X-first structure (not the reference's 256-thread block with two barriers per chunk):
-//   * ONE 64-lane wave owns a whole pixel region of a tile and streams the tile's list on its own:
-//     no cross-wave barriers, single-wave workgroups, so the CU's 8-deep wave slots hide the gather
-//     latency.  Each lane carries PPL pixels (PPL 8x8 quadrants of the 16x16 tile), so every LDS
-//     broadcast read of a Gaussian record is amortised over PPL pixels per lane (the LDS pipe, shared
-//     by the CU's 4 SIMDs, would otherwise co-limit with the VALU).
+//   * ONE 64-lane wave owns a pixel region of a tile and streams the tile's list on its own: single-wave
+//     workgroups, no cross-wave barriers, so the CU's wave slots hide each other's gather latency.  A lane
+//     carries PPL pixels (PPL 8x8 quadrants of the 16x16 tile): every LDS broadcast read of a Gaussian record
+//     is amortised over PPL pixels per lane, and the backward's cross-lane reduction over PPL x 64 pixels.
 //   * the list is fetched 64 entries at a time: lane j gathers the 48-byte GRec of entry j (one
-//     cache-line-local load instead of the reference's five scattered arrays) into LDS.
-//   * backward: the 9 partial sums of a Gaussian are first added over the lane's PPL pixels, reduced
-//     across the wave with DPP row operations (no LDS, no atomics), parked in LDS per list entry, and
-//     flushed once per 64-entry chunk with all 64 lanes issuing the global float atomics -- one atomic
-//     per (tile region, Gaussian, component) instead of one per (pixel, Gaussian, component), and none at
-//     all for entries that touched no pixel of the region.
-//   * workgroup ids are remapped so that consecutive tiles run on the same XCD (shared L2 for the
-//     records of Gaussians straddling neighbouring tiles).
+//     cache-line-local load instead of the reference's five scattered arrays) into registers one chunk
+//     ahead of its use, then parks it in LDS.
+//   * while it holds entry j, lane j also runs the exact region pre-test (blend_math.h): more than half of
+//     the reference's bounding-square tile entries reach no pixel of the tile, 72% no pixel of a given
+//     quadrant.  The wave then walks only the surviving entries (bit scan over a wave-uniform mask) and
+//     only their surviving quadrants.  Per-pixel decisions are untouched, so image, n_contrib and gradients
+//     are what they are without the pre-test.
+//   * backward: the 9 partial sums of an entry are added over the lane's pixels, reduced across the wave with
+//     DPP row operations (no LDS traffic, no atomics), parked in LDS per list entry, and flushed once per
+//     64-entry chunk with all 64 lanes issuing the global float atomics: one atomic per (tile region,
+//     Gaussian, component) instead of the reference's one per (pixel, Gaussian, component), none for
+//     entries that touched nothing.
+//   * workgroup ids are remapped so that consecutive tiles run on the same XCD (shared L2 for the records of
+//     Gaussians straddling neighbouring tiles).
 #include <cstdlib>
 
 #include "blend_math.h"
@@ -71,31 +76,25 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
     return (b & 7u) * per + (b >> 3);
 }
 
-// full-wave sum via DPP; result valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-#define R3_DPP_ADD(ctrl, rmask)                                                                          \
+#define R3_DPP_ADD(v, ctrl, rmask) \
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
-    R3_DPP_ADD(0xb1, 0xf);   // quad_perm [1,0,3,2]
-    R3_DPP_ADD(0x4e, 0xf);   // quad_perm [2,3,0,1]
-    R3_DPP_ADD(0x124, 0xf);  // row_ror:4
-    R3_DPP_ADD(0x128, 0xf);  // row_ror:8   -> every lane of a 16-lane row holds the row sum
-    R3_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-    R3_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-#undef R3_DPP_ADD
-    return v;
-}
 
 // sum over each 16-lane DPP row, result in every lane of the row
 __device__ __forceinline__ float row_sum(float v)
 {
-#define R3_DPP_ADD(ctrl) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-    R3_DPP_ADD(0xb1);   // quad_perm [1,0,3,2]
-    R3_DPP_ADD(0x4e);   // quad_perm [2,3,0,1]
-    R3_DPP_ADD(0x124);  // row_ror:4
-    R3_DPP_ADD(0x128);  // row_ror:8
-#undef R3_DPP_ADD
+    R3_DPP_ADD(v, 0xb1, 0xf);   // quad_perm [1,0,3,2]
+    R3_DPP_ADD(v, 0x4e, 0xf);   // quad_perm [2,3,0,1]
+    R3_DPP_ADD(v, 0x124, 0xf);  // row_ror:4
+    R3_DPP_ADD(v, 0x128, 0xf);  // row_ror:8
+    return v;
+}
+
+// full-wave sum; result valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = row_sum(v);
+    R3_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    R3_DPP_ADD(v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
     return v;
 }
 
@@ -107,14 +106,15 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
-// pixels per lane: 4 (one wave per 16x16 tile), 2 (two waves per tile) or 1 (four waves per tile).
-// Environment override is a tuning knob for profiling runs; results are identical for every value.
-static int blend_ppl(const char* env, int dflt)
+// Tuning knobs for profiling runs (results are identical for every value):
+//   R3DGS_FWD_PPL / R3DGS_BWD_PPL : pixels per lane, 4 (one wave per tile), 2 or 1 (four waves per tile)
+//   R3DGS_BWD_RED                 : 0 = DPP reduction to lane 63, 1 = DPP row sums + 4 LDS atomics
+static int env_int(const char* env, int dflt, int lo, int hi)
 {
     const char* v = getenv(env);
     if (!v) return dflt;
     const int p = atoi(v);
-    return (p == 1 || p == 2 || p == 4) ? p : dflt;
+    return (p >= lo && p <= hi) ? p : dflt;
 }
 
 struct BlendFwdArgs {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
     for (int q = 0; q < PPL; q++) {
         int px, py;
         pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
-        qx0[q] = (float)(px - (lane & 7));   // first pixel column / row of quadrant q (wave-uniform)
+        qx0[q] = (float)(px - (lane & 7));  // first pixel column / row of quadrant q (wave-uniform)
         qy0[q] = (float)(py - (lane >> 3));
         pxf[q] = (float)px;
         pyf[q] = (float)py;
@@ -203,47 +203,34 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
                 nxc = g[2];
             }
         }
-        if (anymask) {
-            // walk the surviving entries front to back; the LDS read of the next survivor is issued before
-            // the current one is blended, so its latency hides behind the per-pixel arithmetic
-            int jn = __builtin_ctzll(anymask);
+        while (anymask) {  // surviving entries, front to back
+            const int j = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
-            Splat s_next = load_splat(s_rec[jn]);
-            for (;;) {
-                const Splat s = s_next;
-                const int j = jn;
-                const bool more = anymask != 0ull;
-                if (more) {
-                    jn = __builtin_ctzll(anymask);
-                    anymask &= anymask - 1ull;
-                    s_next = load_splat(s_rec[jn]);
-                }
-                const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
-                int cnt = 0;
-                float tsum = 0.f;
+            const Splat s = load_splat(s_rec[j]);
+            const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
+            int cnt = 0;
+            float tsum = 0.f;
 #pragma unroll
-                for (int q = 0; q < PPL; q++) {
-                    if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
-                        float Tb;
-                        const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
-                        if (r == 2) live &= ~(1u << q);
-                        if (COUNTERS && r == 1) {
-                            cnt++;
-                            tsum += Tb;
-                        }
+            for (int q = 0; q < PPL; q++) {
+                if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
+                    float Tb;
+                    const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
+                    if (r == 2) live &= ~(1u << q);
+                    if (COUNTERS && r == 1) {
+                        cnt++;
+                        tsum += Tb;
                     }
                 }
-                if (COUNTERS) {  // forward.cu:560-564, one atomic pair per (region, Gaussian) instead of per pixel
-                    if (__ballot(cnt != 0) != 0ull) {
-                        const float c = wave_sum_to_lane63((float)cnt);
-                        const float t = wave_sum_to_lane63(tsum);
-                        if (lane == 63) {
-                            atomicAdd(a.touched + s_id[j], (int)c);
-                            atomicAdd(a.transmittance + s_id[j], t);
-                        }
+            }
+            if (COUNTERS) {  // forward.cu:560-564, one atomic pair per (region, Gaussian) instead of per pixel
+                if (__ballot(cnt != 0) != 0ull) {
+                    const float c = wave_sum_to_lane63((float)cnt);
+                    const float t = wave_sum_to_lane63(tsum);
+                    if (lane == 63) {
+                        atomicAdd(a.touched + s_id[j], (int)c);
+                        atomicAdd(a.transmittance + s_id[j], t);
                     }
                 }
-                if (!more) break;
             }
         }
     }
@@ -262,10 +249,20 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
     }
 }
 
-void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
-                          ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s)
+template <int PPL>
+static void launch_fwd_ppl(const BlendFwdArgs& a, bool counters, hipStream_t s)
 {
-    const int PPL = blend_ppl("R3DGS_FWD_PPL", 4);
+    if (counters)
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+}
+
+void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b, ImageState& img,
+                          float* out_color, int* touched, float* transmittance, hipStream_t s)
+{
+    static const int PPL0 = env_int("R3DGS_FWD_PPL", 2, 1, 4);
+    static const int PPL = PPL0 == 3 ? 2 : PPL0;
     BlendFwdArgs a;
     a.ranges = img.ranges;
     a.point_list = b.point_list;
@@ -280,15 +277,12 @@ void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinS
     a.n_contrib = img.n_contrib;
     a.touched = touched;
     a.transmittance = transmittance;
-    if (touched) {
-        if (PPL == 4) hipLaunchKernelGGL((blend_fwd_kernel<4, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-        else if (PPL == 2) hipLaunchKernelGGL((blend_fwd_kernel<2, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((blend_fwd_kernel<1, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-    } else {
-        if (PPL == 4) hipLaunchKernelGGL((blend_fwd_kernel<4, false>), dim3(a.nblocks), dim3(64), 0, s, a);
-        else if (PPL == 2) hipLaunchKernelGGL((blend_fwd_kernel<2, false>), dim3(a.nblocks), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((blend_fwd_kernel<1, false>), dim3(a.nblocks), dim3(64), 0, s, a);
-    }
+    if (PPL == 4)
+        launch_fwd_ppl<4>(a, touched != nullptr, s);
+    else if (PPL == 2)
+        launch_fwd_ppl<2>(a, touched != nullptr, s);
+    else
+        launch_fwd_ppl<1>(a, touched != nullptr, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,7 +303,7 @@ struct BlendBwdArgs {
 
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
-template <int PPL>
+template <int PPL, int RED>
 __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
 {
     __shared__ LdsRec s_rec[kChunk];
@@ -394,39 +388,34 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
             nxb = g[1];
             nxc = g[2];
         }
+        if (RED == 1) {
 #pragma unroll
-        for (int k = 0; k < kGradStride; k++) s_grad[lane * kGradStride + k] = 0.f;
+            for (int k = 0; k < kGradStride; k++) s_grad[lane * kGradStride + k] = 0.f;
+        } else {
+            s_grad[lane * kGradStride + 9] = 0.f;
+        }
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
-        if (anymask) {
-            // back to front over the surviving entries (highest set bit first), next record prefetched from LDS
-            int jn = 63 - __builtin_clzll(anymask);
-            anymask &= ~(1ull << jn);
-            Splat s_next = load_splat(s_rec[jn]);
-            for (;;) {
-                const Splat s = s_next;
-                const int j = jn;
-                const bool more = anymask != 0ull;
-                if (more) {
-                    jn = 63 - __builtin_clzll(anymask);
-                    anymask &= ~(1ull << jn);
-                    s_next = load_splat(s_rec[jn]);
-                }
-                const uint32_t pos = (uint32_t)(cbase + j);
-                SplatGrad sg;
-                sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
-                bool any = false;
+        while (anymask) {  // surviving entries, back to front: highest set bit first
+            const int j = 63 - __builtin_clzll(anymask);
+            anymask &= ~(1ull << j);
+            const Splat s = load_splat(s_rec[j]);
+            const uint32_t pos = (uint32_t)(cbase + j);
+            SplatGrad sg;
+            sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
+            bool any = false;
 #pragma unroll
-                for (int q = 0; q < PPL; q++)
-                    if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
-                if (__ballot(any) != 0ull) {
-                    // 9 sums over the wave: 4 DPP steps leave each 16-lane row's sum in all its lanes, then one
-                    // lane per row adds it into the entry's LDS slot (4 same-address LDS atomics per component)
+            for (int q = 0; q < PPL; q++)
+                if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
+            if (__ballot(any) != 0ull) {
+                float* d = s_grad + j * kGradStride;
+                if (RED == 1) {
+                    // 4 DPP steps leave each 16-lane row's sum in all its lanes; one lane per row adds it into
+                    // the entry's LDS slot (4 same-address LDS atomics per component)
                     const float v0 = row_sum(sg.mx), v1 = row_sum(sg.my), v2 = row_sum(sg.cA);
                     const float v3 = row_sum(sg.cB), v4 = row_sum(sg.cC), v5 = row_sum(sg.op);
                     const float v6 = row_sum(sg.r), v7 = row_sum(sg.g), v8 = row_sum(sg.b);
                     if ((lane & 15) == 15) {
-                        float* d = s_grad + j * kGradStride;
                         atomicAdd(d + 0, v0);
                         atomicAdd(d + 1, v1);
                         atomicAdd(d + 2, v2);
@@ -438,8 +427,25 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
                         atomicAdd(d + 8, v8);
                         d[9] = 1.f;
                     }
+                } else {
+                    const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
+                    const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);
+                    const float v4 = wave_sum_to_lane63(sg.cC), v5 = wave_sum_to_lane63(sg.op);
+                    const float v6 = wave_sum_to_lane63(sg.r), v7 = wave_sum_to_lane63(sg.g);
+                    const float v8 = wave_sum_to_lane63(sg.b);
+                    if (lane == 63) {
+                        d[0] = v0;
+                        d[1] = v1;
+                        d[2] = v2;
+                        d[3] = v3;
+                        d[4] = v4;
+                        d[5] = v5;
+                        d[6] = v6;
+                        d[7] = v7;
+                        d[8] = v8;
+                        d[9] = 1.f;
+                    }
                 }
-                if (!more) break;
             }
         }
         __syncthreads();
@@ -454,10 +460,21 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
     }
 }
 
-void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b,
-                           const ImageState& img, const float* dL_dpix, hipStream_t s)
+template <int PPL>
+static void launch_bwd_ppl(const BlendBwdArgs& a, int red, hipStream_t s)
 {
-    const int PPL = blend_ppl("R3DGS_BWD_PPL", 4);
+    if (red == 1)
+        hipLaunchKernelGGL((blend_bwd_kernel<PPL, 1>), dim3(a.nblocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((blend_bwd_kernel<PPL, 0>), dim3(a.nblocks), dim3(64), 0, s, a);
+}
+
+void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b, const ImageState& img,
+                           const float* dL_dpix, hipStream_t s)
+{
+    static const int PPL0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
+    static const int PPL = PPL0 == 3 ? 4 : PPL0;
+    static const int RED = env_int("R3DGS_BWD_RED", 0, 0, 1);
     BlendBwdArgs a;
     a.ranges = img.ranges;
     a.point_list = b.point_list;
@@ -471,9 +488,12 @@ void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState&
     a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
     a.bg = view.bg;
     a.acc = g.acc;
-    if (PPL == 4) hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else if (PPL == 2) hipLaunchKernelGGL((blend_bwd_kernel<2>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((blend_bwd_kernel<1>), dim3(a.nblocks), dim3(64), 0, s, a);
+    if (PPL == 4)
+        launch_bwd_ppl<4>(a, RED, s);
+    else if (PPL == 2)
+        launch_bwd_ppl<2>(a, RED, s);
+    else
+        launch_bwd_ppl<1>(a, RED, s);
 }
 
 }  // namespace r3
