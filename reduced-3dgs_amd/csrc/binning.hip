@@ -22,6 +22,10 @@
 
 namespace r3 {
 
+// rocPRIM falls back to a ~10-pass merge sort below 1M items by default; the depth sort of P = 500k keys took
+// 130 us that way.  Force the onesweep radix path (4 passes) for everything larger than one block.
+using OnesweepOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 struct GatherTiles {
     const uint32_t* tiles;
     __host__ __device__ uint32_t operator()(uint32_t id) const { return tiles[id]; }
@@ -31,7 +35,7 @@ size_t depth_sort_temp_bytes(size_t P)
 {
     size_t a = 0, b = 0;
     uint32_t* n = nullptr;
-    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, rocprim::counting_iterator<uint32_t>(0), n, P, 0, 32));
+    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(nullptr, a, n, n, rocprim::counting_iterator<uint32_t>(0), n, P, 0, 32));
     auto it = rocprim::make_transform_iterator(n, GatherTiles{n});
     R3_HIP(rocprim::inclusive_scan(nullptr, b, it, n, P, rocprim::plus<uint32_t>()));
     return (a > b ? a : b) + 256;
@@ -41,14 +45,14 @@ size_t tile_sort_temp_bytes(size_t R)
 {
     size_t a = 0;
     uint32_t* n = nullptr;
-    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
+    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
     return a + 256;
 }
 
 void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
 {
     size_t bytes = g.temp_bytes;
-    R3_HIP(rocprim::radix_sort_pairs(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
+    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
                                      g.order, (size_t)P, 0, 32, s));
     bytes = g.temp_bytes;
     auto it = rocprim::make_transform_iterator(g.order, GatherTiles{g.tiles});
@@ -172,7 +176,7 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
                        g.order, g.offsets, g.rect, gx, b.tile_in, b.gauss_in);
     const int bits = (int)higher_msb((uint32_t)Tn);
     size_t bytes = b.temp_bytes;
-    R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
+    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
                                      bits, s));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, img.ranges);
 }

@@ -17,7 +17,8 @@
 //     only their surviving quadrants.  Per-pixel decisions are untouched, so image, n_contrib and gradients
 //     are what they are without the pre-test.
 //   * backward: the 9 partial sums of an entry are added over the lane's pixels, reduced across the wave with
-//     DPP row operations (no LDS traffic, no atomics), parked in LDS per list entry, and flushed once per
+//     DPP row operations (no LDS traffic, no atomics; finishing the last two steps with 4 same-address LDS
+//     float atomics instead was measured 45% slower), parked in LDS per list entry, and flushed once per
 //     64-entry chunk with all 64 lanes issuing the global float atomics: one atomic per (tile region,
 //     Gaussian, component) instead of the reference's one per (pixel, Gaussian, component), none for
 //     entries that touched nothing.
@@ -108,7 +109,6 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
 
 // Tuning knobs for profiling runs (results are identical for every value):
 //   R3DGS_FWD_PPL / R3DGS_BWD_PPL : pixels per lane, 4 (one wave per tile), 2 or 1 (four waves per tile)
-//   R3DGS_BWD_RED                 : 0 = DPP reduction to lane 63, 1 = DPP row sums + 4 LDS atomics
 static int env_int(const char* env, int dflt, int lo, int hi)
 {
     const char* v = getenv(env);
@@ -303,8 +303,9 @@ struct BlendBwdArgs {
 
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
-template <int PPL, int RED>
-__global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
+// 5 waves per SIMD for the 4-pixel-per-lane variant: 100 -> 96 VGPRs, no spills
+template <int PPL>
+__global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBwdArgs a)
 {
     __shared__ LdsRec s_rec[kChunk];
     __shared__ uint32_t s_id[kChunk];
@@ -332,20 +333,11 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
         pyf[q] = (float)py;
         const bool inside = px < a.W && py < a.H;
         BwdPix& p = pix[q];
-        p.acc0 = p.acc1 = p.acc2 = 0.f;
-        p.lc0 = p.lc1 = p.lc2 = p.la = 0.f;
-        p.T = p.T_final = p.bg_dot = 0.f;
-        p.g0 = p.g1 = p.g2 = 0.f;
-        p.last = 0;
+        bwd_pix_init(p, 0.f, 0u, 0.f, 0.f, 0.f, 0.f);
         if (inside) {
             const size_t id = (size_t)a.W * py + px;
-            p.T_final = a.final_T[id];
-            p.T = p.T_final;
-            p.last = a.n_contrib[id];
-            p.g0 = a.dL_dpix[id];
-            p.g1 = a.dL_dpix[plane + id];
-            p.g2 = a.dL_dpix[2 * plane + id];
-            p.bg_dot = bg0 * p.g0 + bg1 * p.g1 + bg2 * p.g2;
+            const float g0 = a.dL_dpix[id], g1 = a.dL_dpix[plane + id], g2 = a.dL_dpix[2 * plane + id];
+            bwd_pix_init(p, a.final_T[id], a.n_contrib[id], g0, g1, g2, bg0 * g0 + bg1 * g1 + bg2 * g2);
         }
         lmax = max(lmax, p.last);
     }
@@ -388,12 +380,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
             nxb = g[1];
             nxc = g[2];
         }
-        if (RED == 1) {
-#pragma unroll
-            for (int k = 0; k < kGradStride; k++) s_grad[lane * kGradStride + k] = 0.f;
-        } else {
-            s_grad[lane * kGradStride + 9] = 0.f;
-        }
+        s_grad[lane * kGradStride + 9] = 0.f;
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
         while (anymask) {  // surviving entries, back to front: highest set bit first
@@ -409,25 +396,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
                 if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
             if (__ballot(any) != 0ull) {
                 float* d = s_grad + j * kGradStride;
-                if (RED == 1) {
-                    // 4 DPP steps leave each 16-lane row's sum in all its lanes; one lane per row adds it into
-                    // the entry's LDS slot (4 same-address LDS atomics per component)
-                    const float v0 = row_sum(sg.mx), v1 = row_sum(sg.my), v2 = row_sum(sg.cA);
-                    const float v3 = row_sum(sg.cB), v4 = row_sum(sg.cC), v5 = row_sum(sg.op);
-                    const float v6 = row_sum(sg.r), v7 = row_sum(sg.g), v8 = row_sum(sg.b);
-                    if ((lane & 15) == 15) {
-                        atomicAdd(d + 0, v0);
-                        atomicAdd(d + 1, v1);
-                        atomicAdd(d + 2, v2);
-                        atomicAdd(d + 3, v3);
-                        atomicAdd(d + 4, v4);
-                        atomicAdd(d + 5, v5);
-                        atomicAdd(d + 6, v6);
-                        atomicAdd(d + 7, v7);
-                        atomicAdd(d + 8, v8);
-                        d[9] = 1.f;
-                    }
-                } else {
+                {
                     const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
                     const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);
                     const float v4 = wave_sum_to_lane63(sg.cC), v5 = wave_sum_to_lane63(sg.op);
@@ -461,12 +430,9 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BlendBwdArgs a)
 }
 
 template <int PPL>
-static void launch_bwd_ppl(const BlendBwdArgs& a, int red, hipStream_t s)
+static void launch_bwd_ppl(const BlendBwdArgs& a, hipStream_t s)
 {
-    if (red == 1)
-        hipLaunchKernelGGL((blend_bwd_kernel<PPL, 1>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((blend_bwd_kernel<PPL, 0>), dim3(a.nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
 }
 
 void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b, const ImageState& img,
@@ -474,7 +440,6 @@ void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState&
 {
     static const int PPL0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
     static const int PPL = PPL0 == 3 ? 4 : PPL0;
-    static const int RED = env_int("R3DGS_BWD_RED", 0, 0, 1);
     BlendBwdArgs a;
     a.ranges = img.ranges;
     a.point_list = b.point_list;
@@ -489,11 +454,11 @@ void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState&
     a.bg = view.bg;
     a.acc = g.acc;
     if (PPL == 4)
-        launch_bwd_ppl<4>(a, RED, s);
+        launch_bwd_ppl<4>(a, s);
     else if (PPL == 2)
-        launch_bwd_ppl<2>(a, RED, s);
+        launch_bwd_ppl<2>(a, s);
     else
-        launch_bwd_ppl<1>(a, RED, s);
+        launch_bwd_ppl<1>(a, s);
 }
 
 }  // namespace r3

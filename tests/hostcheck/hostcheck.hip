@@ -140,13 +140,8 @@ void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* p
             const int tile = (py / kTile) * gx + px / kTile;
             const size_t pix = (size_t)W * py + px;
             BwdPix p;
-            p.acc0 = p.acc1 = p.acc2 = p.lc0 = p.lc1 = p.lc2 = p.la = 0.f;
-            p.T_final = p.T = final_T[pix];
-            p.last = n_contrib[pix];
-            p.g0 = dL_dpix[pix];
-            p.g1 = dL_dpix[plane + pix];
-            p.g2 = dL_dpix[2 * plane + pix];
-            p.bg_dot = bg[0] * p.g0 + bg[1] * p.g1 + bg[2] * p.g2;
+            const float g0 = dL_dpix[pix], g1 = dL_dpix[plane + pix], g2 = dL_dpix[2 * plane + pix];
+            bwd_pix_init(p, final_T[pix], n_contrib[pix], g0, g1, g2, bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
             for (long pos = (long)p.last - 1; pos >= 0; pos--) {
                 const unsigned id = point_list[ranges[2 * tile] + pos];
                 const Splat s = splat_of(xy, conic_op, rgb, id);
