@@ -22,10 +22,6 @@
 
 namespace r3 {
 
-// rocPRIM falls back to a ~10-pass merge sort below 1M items by default; the depth sort of P = 500k keys took
-// 130 us that way.  Force the onesweep radix path (4 passes) for everything larger than one block.
-using OnesweepOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-
 struct GatherTiles {
     const uint32_t* tiles;
     __host__ __device__ uint32_t operator()(uint32_t id) const { return tiles[id]; }
@@ -35,7 +31,7 @@ size_t depth_sort_temp_bytes(size_t P)
 {
     size_t a = 0, b = 0;
     uint32_t* n = nullptr;
-    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(nullptr, a, n, n, rocprim::counting_iterator<uint32_t>(0), n, P, 0, 32));
+    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, rocprim::counting_iterator<uint32_t>(0), n, P, 0, 32));
     auto it = rocprim::make_transform_iterator(n, GatherTiles{n});
     R3_HIP(rocprim::inclusive_scan(nullptr, b, it, n, P, rocprim::plus<uint32_t>()));
     return (a > b ? a : b) + 256;
@@ -45,14 +41,14 @@ size_t tile_sort_temp_bytes(size_t R)
 {
     size_t a = 0;
     uint32_t* n = nullptr;
-    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
+    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
     return a + 256;
 }
 
 void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
 {
     size_t bytes = g.temp_bytes;
-    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
+    R3_HIP(rocprim::radix_sort_pairs(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
                                      g.order, (size_t)P, 0, 32, s));
     bytes = g.temp_bytes;
     auto it = rocprim::make_transform_iterator(g.order, GatherTiles{g.tiles});
@@ -99,7 +95,7 @@ __device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restric
 
 __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, const uint32_t* __restrict__ order,
                                                          const uint32_t* __restrict__ offsets,
-                                                         const ushort4* __restrict__ rect, int gx,
+                                                         const ushort4* __restrict__ rect, int gx, GRec* rec,
                                                          uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out)
 {
     __shared__ uint32_t s_end[kEmitSlice];
@@ -126,6 +122,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
     }
     __syncthreads();
     const uint32_t start0 = s_start0;
+    // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value)
+    for (uint32_t k = threadIdx.x; k < n; k += 256) rec[s_id[k]].pair_start = k == 0 ? start0 : s_end[k - 1];
 #pragma unroll
     for (int e = 0; e < kEmitPerBlock / 256; e++) {
         const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
@@ -173,10 +171,10 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
     R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
     if (R <= 0) return;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((R + kEmitPerBlock - 1) / kEmitPerBlock), dim3(256), 0, s, P, (uint32_t)R,
-                       g.order, g.offsets, g.rect, gx, b.tile_in, b.gauss_in);
+                       g.order, g.offsets, g.rect, gx, g.rec, b.tile_in, b.gauss_in);
     const int bits = (int)higher_msb((uint32_t)Tn);
     size_t bytes = b.temp_bytes;
-    R3_HIP(rocprim::radix_sort_pairs<OnesweepOnly>(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
+    R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
                                      bits, s));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, img.ranges);
 }
@@ -184,18 +182,18 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
 // debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list
 __global__ __launch_bounds__(256) void export_keys_kernel(int R, const uint32_t* __restrict__ tile_sorted,
                                                           const uint32_t* __restrict__ point_list,
-                                                          const GRec* __restrict__ rec, uint64_t* keys)
+                                                          const uint32_t* __restrict__ depth_key, uint64_t* keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)__float_as_uint(rec[point_list[i]].depth);
+    keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)depth_key[point_list[i]];
 }
 
 void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s)
 {
     if (R <= 0) return;
     hipLaunchKernelGGL(export_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, b.point_list,
-                       g.rec, keys_out);
+                       g.depth_key, keys_out);
 }
 
 }  // namespace r3

@@ -17,11 +17,12 @@
 //     only their surviving quadrants.  Per-pixel decisions are untouched, so image, n_contrib and gradients
 //     are what they are without the pre-test.
 //   * backward: the 9 partial sums of an entry are added over the lane's pixels, reduced across the wave with
-//     DPP row operations (no LDS traffic, no atomics; finishing the last two steps with 4 same-address LDS
-//     float atomics instead was measured 45% slower), parked in LDS per list entry, and flushed once per
-//     64-entry chunk with all 64 lanes issuing the global float atomics: one atomic per (tile region,
-//     Gaussian, component) instead of the reference's one per (pixel, Gaussian, component), none for
-//     entries that touched nothing.
+//     DPP row operations (no LDS traffic; finishing the last two steps with 4 same-address LDS float atomics
+//     instead was measured 45% slower), parked in LDS per list entry, and flushed once per 64-entry chunk
+//     with plain stores into the entry's own slot of a per-(tile, Gaussian)-pair slab.  The reference issues
+//     one global float atomic per (pixel, Gaussian, component); a first version here issued one per (tile,
+//     Gaussian, component) and still spent 0.25 of 0.87 ms on them (11.8 M atomics per pass at the BASELINE
+//     shape).  Now there are none: the per-Gaussian kernel sums a Gaussian's slots, which are contiguous.
 //   * workgroup ids are remapped so that consecutive tiles run on the same XCD (shared L2 for the records of
 //     Gaussians straddling neighbouring tiles).
 #include <cstdlib>
@@ -298,7 +299,7 @@ struct BlendBwdArgs {
     int W, H, gx;
     uint32_t nblocks;
     const float* bg;
-    float* acc;  // [P][kAccStride]: mx, my, cA, cB, cC, op, r, g, b
+    float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
 };
 
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
@@ -419,12 +420,20 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
         }
         __syncthreads();
         if (lane < n && s_grad[lane * kGradStride + 9] != 0.f) {
-            float* dst = a.acc + (size_t)s_id[lane] * kAccStride;
+            // park the entry's sums in ITS slot of the per-pair slab: slot = first pair of the Gaussian + row-major
+            // index of this tile inside the Gaussian's tile rect (exactly the emission order of binning.hip).
+            // Plain stores, one owner per slot -- the per-Gaussian kernel adds a Gaussian's slots up in order, so
+            // the backward has no float atomics and is bit-reproducible.
+            const float4 c = s_rec[lane].c;
+            const uint32_t rect_min = __float_as_uint(c.y), width = __float_as_uint(c.z) & 0xffffu;
+            const uint32_t slot = __float_as_uint(c.w) + ((uint32_t)tile_y - (rect_min >> 16)) * width +
+                                  ((uint32_t)tile_x - (rect_min & 0xffffu));
+            float* dst = a.pair_grad + (size_t)slot * kPairGrad;
             const float* src = s_grad + lane * kGradStride;
-            atomicAdd(dst + 0, src[0] * half_w);  // viewport factors of backward.cu:498-499, applied once
-            atomicAdd(dst + 1, src[1] * half_h);
+            dst[0] = src[0] * half_w;  // viewport factors of backward.cu:498-499, applied once
+            dst[1] = src[1] * half_h;
 #pragma unroll
-            for (int k = 2; k < 9; k++) atomicAdd(dst + k, src[k]);
+            for (int k = 2; k < 9; k++) dst[k] = src[k];
         }
     }
 }
@@ -435,7 +444,7 @@ static void launch_bwd_ppl(const BlendBwdArgs& a, hipStream_t s)
     hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
 }
 
-void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b, const ImageState& img,
+void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState& b, const ImageState& img,
                            const float* dL_dpix, hipStream_t s)
 {
     static const int PPL0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
@@ -452,7 +461,7 @@ void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState&
     a.gx = (view.W + kTile - 1) / kTile;
     a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
     a.bg = view.bg;
-    a.acc = g.acc;
+    a.pair_grad = b.pair_grad;
     if (PPL == 4)
         launch_bwd_ppl<4>(a, s);
     else if (PPL == 2)

@@ -344,6 +344,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)gx * gy);
         BinState bin = BinState::carve(binning_buffer, (size_t)R, cached_tile_temp((size_t)R));
+        if (R <= 0) bin.pair_grad = nullptr;
         if (!radii) radii = geom.radii_internal;
 
         FwdInputs in;
@@ -370,8 +371,10 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         view.scale_modifier = scale_modifier;
 
         StageTimer t4(kBlendBwd, s);
-        R3_HIP(hipMemsetAsync(geom.acc, 0, sizeof(float) * (size_t)P * kAccStride, s));
-        if (R > 0) launch_blend_backward(view, geom, bin, img, dL_dpix, s);
+        if (R > 0) {
+            R3_HIP(hipMemsetAsync(bin.pair_grad, 0, sizeof(float) * (size_t)R * kPairGrad, s));
+            launch_blend_backward(view, geom, bin, img, dL_dpix, s);
+        }
         t4.stop();
         check_launch("blend backward", s, debug);
         BwdOutputs out;
@@ -385,7 +388,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         out.dL_drot = dL_drot;
         out.dL_dconic = dL_dconic;
         StageTimer t5(kPreBwd, s);
-        launch_preprocess_backward(in, view, radii, geom, out, lambda_sh_sparsity, s);
+        launch_preprocess_backward(in, view, radii, geom, bin, out, lambda_sh_sparsity, s);
         t5.stop();
         check_launch("preprocess backward", s, debug);
         return 0;

@@ -6,7 +6,7 @@
 // Their internal layout is private to this library and is MI355X-first, not the reference's:
 //   * one 48-byte gather record per Gaussian (GRec) instead of five separate arrays,
 //   * depth-sorted Gaussian order + 32-bit tile keys instead of 64-bit (tile|depth) keys,
-//   * a per-Gaussian gradient accumulator row for the backward.
+//   * a per-(tile, Gaussian)-pair gradient slab for the backward (no float atomics anywhere).
 // The parts the backward needs sit at the FRONT of each blob so that their offsets do not depend on
 // library temp-storage sizes.
 #pragma once
@@ -22,7 +22,8 @@
 namespace r3 {
 
 constexpr size_t kAlign = 256;
-constexpr int kAccStride = 12;  // floats per Gaussian in the backward accumulator (9 used)
+constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the backward blend:
+                              // dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb
 
 // Per-view counters produced by the preprocess kernel.  One atomic per workgroup, spread over kShards
 // words that sit 128 B apart: the first GPU profile showed 7.8k same-address atomics (one per wave) costing
@@ -56,7 +57,6 @@ struct Carver {
 struct GeomState {
     GeomHeader* header;
     GRec* rec;            // [P]
-    float* acc;           // [P * kAccStride]   backward accumulators
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
     uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
     uint32_t* tiles;      // [P]  tiles_touched
@@ -72,7 +72,6 @@ struct GeomState {
         GeomState g;
         g.header = c.take<GeomHeader>(1);
         g.rec = c.take<GRec>(P);
-        g.acc = c.take<float>(P * kAccStride);
         g.rect = c.take<ushort4>(P);
         g.depth_key = c.take<uint32_t>(P);
         g.tiles = c.take<uint32_t>(P);
@@ -90,6 +89,7 @@ struct GeomState {
 
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
+    float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
     uint32_t* tile_sorted; // [R] tile id of each entry
     uint32_t* tile_in;     // [R]
     uint32_t* gauss_in;    // [R]
@@ -101,6 +101,7 @@ struct BinState {
         Carver c(base);
         BinState b;
         b.point_list = c.take<uint32_t>(R);
+        b.pair_grad = c.take<float>(R * kPairGrad);
         b.tile_sorted = c.take<uint32_t>(R);
         b.tile_in = c.take<uint32_t>(R);
         b.gauss_in = c.take<uint32_t>(R);
@@ -224,7 +225,7 @@ void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* 
 
 void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
                           ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s);
-void launch_blend_backward(const ViewParams& view, GeomState& g, const BinState& b,
+void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState& b,
                            const ImageState& img, const float* dL_dpix, hipStream_t s);
 
 struct BwdOutputs {
@@ -239,6 +240,6 @@ struct BwdOutputs {
     float* dL_dconic;    // [P,4] optional (nullptr: not exported)
 };
 void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
-                                const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
+                                const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
 
 }  // namespace r3

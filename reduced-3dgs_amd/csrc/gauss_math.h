@@ -45,9 +45,13 @@ constexpr int kTile = 16;  // config.h BLOCK_X = BLOCK_Y
 struct alignas(16) GRec {
     float x, y, cA, cB;       // pixel-space mean, conic (A,B)
     float cC, op, r, g;       // conic C, activated opacity, colour r,g
-    float b, depth;           // colour b, view-space depth
-    uint32_t clamp_bits;      // bit ch set <=> colour channel was clamped at 0 (forward.cu:155-157)
-    uint32_t rect;            // packed tile rect is kept separately; spare word
+    float b;                  // colour b
+    uint32_t rect_min;        // first tile of the rect: x | y << 16
+    uint32_t width_clamp;     // rect width in tiles | clamp bits << 16 (bit ch: colour channel clamped at 0,
+                              // forward.cu:155-157)
+    uint32_t pair_start;      // index of this Gaussian's first (tile, Gaussian) pair in emission order; written by
+                              // the pair-emission kernel.  Its pairs are [pair_start, pair_start + tiles_touched),
+                              // row-major over the rect -- where the backward parks per-pair gradients.
 };
 
 struct Camera {

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
             r.r = rgb[0];
             r.g = rgb[1];
             r.b = rgb[2];
-            r.depth = o.depth;
-            r.clamp_bits = cbits;
-            r.rect = 0;
+            r.rect_min = (uint32_t)o.rmin[0] | ((uint32_t)o.rmin[1] << 16);
+            r.width_clamp = (uint32_t)(o.rmax[0] - o.rmin[0]) | (cbits << 16);
+            r.pair_start = 0;  // filled in by the pair-emission kernel
             a.rec[i] = r;
             a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
                                      (unsigned short)o.rmax[1]);

@@ -32,7 +32,8 @@ struct PreBwdArgs {
     ViewParams view;
     const int* radii;
     const GRec* rec;
-    const float* acc;
+    const uint32_t* tiles;
+    const float* pair_grad;
     const GeomHeader* header;
     float lambda_sh;
     BwdOutputs out;
@@ -68,18 +69,27 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
     ShRowLdsRW row{lds, lane * 3 * M};
     if (vis) {
         const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
-        const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
-        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-        g2x = a0.x;
-        g2y = a0.y;
-        gcon[0] = a0.z;
-        gcon[1] = a0.w;
-        gcon[2] = a1.x;
-        dop = a1.y;
-        dcol[0] = a1.z;
-        dcol[1] = a1.w;
-        dcol[2] = a2.x;
         const GRec r = a.rec[i];
+        {   // sum this Gaussian's per-pair gradients: contiguous slots, fixed (row-major tile) order
+            float acc9[kPairGrad];
+#pragma unroll
+            for (int k = 0; k < kPairGrad; k++) acc9[k] = 0.f;
+            const uint32_t cnt = a.pair_grad ? a.tiles[i] : 0u;
+            const float* pg = a.pair_grad + (size_t)r.pair_start * kPairGrad;
+            for (uint32_t m = 0; m < cnt; m++, pg += kPairGrad) {
+#pragma unroll
+                for (int k = 0; k < kPairGrad; k++) acc9[k] += pg[k];
+            }
+            g2x = acc9[0];
+            g2y = acc9[1];
+            gcon[0] = acc9[2];
+            gcon[1] = acc9[3];
+            gcon[2] = acc9[4];
+            dop = acc9[5];
+            dcol[0] = acc9[6];
+            dcol[1] = acc9[7];
+            dcol[2] = acc9[8];
+        }
         float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6];
         if (a.in.cov3D_precomp) {
             for (int k = 0; k < 6; k++) c6[k] = a.in.cov3D_precomp[6 * i + k];
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
             }
             const int deg = a.in.degrees[i];
             K = (deg + 1) * (deg + 1);
-            sh_backward(deg, row, row, mx, my, mz, cam.campos, r.clamp_bits, dcol, mult, dmean);
+            sh_backward(deg, row, row, mx, my, mz, cam.campos, r.width_clamp >> 16, dcol, mult, dmean);
         }
         if (a.in.scales) cov3d_backward(sc, cam.scale_modifier, q, dcov6, dscale, dq);
         dop = opacity_backward(dop, r.op);
@@ -155,14 +165,15 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
 }
 
 void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
-                                const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s)
+                                const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s)
 {
     PreBwdArgs a;
     a.in = in;
     a.view = view;
     a.radii = radii;
     a.rec = g.rec;
-    a.acc = g.acc;
+    a.tiles = g.tiles;
+    a.pair_grad = b.pair_grad;  // nullptr when num_rendered == 0
     a.header = g.header;
     a.lambda_sh = lambda_sh_sparsity;
     a.out = out;
