@@ -344,7 +344,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)gx * gy);
         BinState bin = BinState::carve(binning_buffer, (size_t)R, cached_tile_temp((size_t)R));
-        if (R <= 0) bin.pair_grad = nullptr;
+        if (R <= 0) bin.pair_grad = bin.wave_part = nullptr;
         if (!radii) radii = geom.radii_internal;
 
         FwdInputs in;
@@ -374,6 +374,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         if (R > 0) {
             R3_HIP(hipMemsetAsync(bin.pair_grad, 0, sizeof(float) * (size_t)R * kPairGrad, s));
             launch_blend_backward(view, geom, bin, img, dL_dpix, s);
+            launch_pair_reduce(R, geom, bin, s);
         }
         t4.stop();
         check_launch("blend backward", s, debug);

@@ -24,6 +24,7 @@ namespace r3 {
 constexpr size_t kAlign = 256;
 constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the backward blend:
                               // dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb
+constexpr int kAccStride = 12;  // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
 
 // Per-view counters produced by the preprocess kernel.  One atomic per workgroup, spread over kShards
 // words that sit 128 B apart: the first GPU profile showed 7.8k same-address atomics (one per wave) costing
@@ -57,6 +58,7 @@ struct Carver {
 struct GeomState {
     GeomHeader* header;
     GRec* rec;            // [P]
+    float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward)
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
     uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
     uint32_t* tiles;      // [P]  tiles_touched
@@ -72,6 +74,7 @@ struct GeomState {
         GeomState g;
         g.header = c.take<GeomHeader>(1);
         g.rec = c.take<GRec>(P);
+        g.acc = c.take<float>(P * kAccStride);
         g.rect = c.take<ushort4>(P);
         g.depth_key = c.take<uint32_t>(P);
         g.tiles = c.take<uint32_t>(P);
@@ -90,6 +93,7 @@ struct GeomState {
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
+    float* wave_part;      // [(R/64+1) * 2 * kPairGrad] leading / trailing partial run sums of each 64-pair group
     uint32_t* tile_sorted; // [R] tile id of each entry
     uint32_t* tile_in;     // [R]
     uint32_t* gauss_in;    // [R]
@@ -102,6 +106,7 @@ struct BinState {
         BinState b;
         b.point_list = c.take<uint32_t>(R);
         b.pair_grad = c.take<float>(R * kPairGrad);
+        b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
         b.tile_sorted = c.take<uint32_t>(R);
         b.tile_in = c.take<uint32_t>(R);
         b.gauss_in = c.take<uint32_t>(R);
@@ -239,6 +244,7 @@ struct BwdOutputs {
     float* dL_drot;      // [P,4]
     float* dL_dconic;    // [P,4] optional (nullptr: not exported)
 };
+void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s);
 void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
                                 const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
 

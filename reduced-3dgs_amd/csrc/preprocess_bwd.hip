@@ -5,6 +5,8 @@
 // rasterizer_impl.cu:549-571 (the visible count was already produced by the forward; no host sync, no
 // malloc/free in the backward) of /root/reference/submodules/diff-gaussian-rasterization.
 //
+// The 2D-stage gradients arrive as one 9-float row per (tile, Gaussian) pair; pair_reduce_kernel below sums
+// them per Gaussian first (segmented sum, no atomics).
 // HBM-bound streaming kernel: one lane per Gaussian.  The wave's 64 SH rows are staged through LDS with
 // coalesced loads, the dL/dsh rows are built IN PLACE in the same LDS span and written back with
 // coalesced stores -- including the zeros the API contract demands for bands above a Gaussian's degree
@@ -27,13 +29,82 @@ struct ShRowLdsRW {
     __device__ __forceinline__ void put(int e, float v) const { base[bskew(roff + e)] = v; }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Per-Gaussian sums of the per-(tile, Gaussian)-pair gradients written by the backward blend.
+// The slab is in emission order, i.e. a Gaussian's pairs are contiguous, so this is a segmented sum over a
+// sorted key (the Gaussian id of each pair = the unsorted value array of the tile sort).  One lane per pair,
+// coalesced loads, a 6-step segmented scan inside each wave.  A run that lies inside one 64-pair group is
+// final and goes to acc[gid]; a run cut by a group boundary leaves its piece in the group's
+// leading / trailing slot and the per-Gaussian kernel adds the <= (tiles/64 + 2) pieces in order.
+// No atomics, fixed summation order: the backward is bit-reproducible.  (Letting each Gaussian's lane loop
+// over its own pairs instead cost 0.86 ms: the largest splats own 600+ pairs.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const float* __restrict__ pair_grad,
+                                                          const uint32_t* __restrict__ pair_gid,
+                                                          const GRec* __restrict__ rec,
+                                                          const uint32_t* __restrict__ tiles, float* __restrict__ acc,
+                                                          float* __restrict__ wave_part)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = e < R;
+    float v[kPairGrad];
+    uint32_t key = 0xFFFFFFFFu;
+    if (valid) {
+        key = pair_gid[e];
+        const float* src = pair_grad + (size_t)e * kPairGrad;
+#pragma unroll
+        for (int k = 0; k < kPairGrad; k++) v[k] = src[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // inclusive segmented scan over equal-key runs
+        const uint32_t ku = (uint32_t)__shfl_up((int)key, d);
+        const bool take = lane >= d && ku == key;
+#pragma unroll
+        for (int k = 0; k < kPairGrad; k++) {
+            const float vu = __shfl_up(v[k], d);
+            if (take) v[k] += vu;
+        }
+    }
+    const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
+    if (valid && (lane == 63 || knext != key)) {  // last lane of a run: holds the run's sum inside this group
+        const uint32_t gbase = e & ~63u, start = rec[key].pair_start, end = start + tiles[key];
+        if (start >= gbase && end <= gbase + 64u) {
+            float* dst = acc + (size_t)key * kAccStride;
+#pragma unroll
+            for (int k = 0; k < kPairGrad; k++) dst[k] = v[k];
+        } else {
+            float* wp = wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
+            if (start < gbase) {  // continues a run of the previous group: this group's leading piece
+#pragma unroll
+                for (int k = 0; k < kPairGrad; k++) wp[k] = v[k];
+            }
+            if (end > gbase + 64u) {  // continues into the next group: trailing piece
+#pragma unroll
+                for (int k = 0; k < kPairGrad; k++) wp[kPairGrad + k] = v[k];
+            }
+        }
+    }
+}
+
+void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s)
+{
+    if (R <= 0) return;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.pair_grad, b.gauss_in,
+                       g.rec, g.tiles, g.acc, b.wave_part);
+}
+
 struct PreBwdArgs {
     FwdInputs in;
     ViewParams view;
     const int* radii;
     const GRec* rec;
     const uint32_t* tiles;
-    const float* pair_grad;
+    const float* acc;
+    const float* wave_part;  // nullptr when num_rendered == 0
     const GeomHeader* header;
     float lambda_sh;
     BwdOutputs out;
@@ -70,15 +141,25 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
     if (vis) {
         const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
         const GRec r = a.rec[i];
-        {   // sum this Gaussian's per-pair gradients: contiguous slots, fixed (row-major tile) order
+        if (a.wave_part) {  // 2D-stage gradient row: final in acc[], or in <= tiles/64 + 2 ordered pieces
             float acc9[kPairGrad];
+            const uint32_t start = r.pair_start, last = start + a.tiles[i] - 1u;
+            const uint32_t w0 = start >> 6, w1 = last >> 6;
+            if (w0 == w1) {
+                const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
+                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+                acc9[0] = a0.x; acc9[1] = a0.y; acc9[2] = a0.z; acc9[3] = a0.w;
+                acc9[4] = a1.x; acc9[5] = a1.y; acc9[6] = a1.z; acc9[7] = a1.w;
+                acc9[8] = a2.x;
+            } else {
+                const float* wp = a.wave_part + (size_t)w0 * 2 * kPairGrad + kPairGrad;  // trailing piece of w0
 #pragma unroll
-            for (int k = 0; k < kPairGrad; k++) acc9[k] = 0.f;
-            const uint32_t cnt = a.pair_grad ? a.tiles[i] : 0u;
-            const float* pg = a.pair_grad + (size_t)r.pair_start * kPairGrad;
-            for (uint32_t m = 0; m < cnt; m++, pg += kPairGrad) {
+                for (int k = 0; k < kPairGrad; k++) acc9[k] = wp[k];
+                for (uint32_t w = w0 + 1; w <= w1; w++) {  // leading piece of every following group
+                    wp = a.wave_part + (size_t)w * 2 * kPairGrad;
 #pragma unroll
-                for (int k = 0; k < kPairGrad; k++) acc9[k] += pg[k];
+                    for (int k = 0; k < kPairGrad; k++) acc9[k] += wp[k];
+                }
             }
             g2x = acc9[0];
             g2y = acc9[1];
@@ -173,7 +254,8 @@ void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, con
     a.radii = radii;
     a.rec = g.rec;
     a.tiles = g.tiles;
-    a.pair_grad = b.pair_grad;  // nullptr when num_rendered == 0
+    a.acc = g.acc;
+    a.wave_part = b.wave_part;  // nullptr when num_rendered == 0
     a.header = g.header;
     a.lambda_sh = lambda_sh_sparsity;
     a.out = out;
