@@ -100,6 +100,44 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// Transposing wave reduction of the 9 gradient components.  A plain butterfly costs 6 cross-lane adds per
+// component (54, and the two cross-row steps need an extra move each).  Here the first two steps exchange
+// DIFFERENT components between partner lanes (keep one, send the other), halving the live values each time:
+// 9 -> 5 -> 3 registers, which are then summed over the remaining lane bits.  Afterwards lane l holds the wave
+// totals of component (l & 3) in w0, component 4 + (l & 3) in w1 and component 8 in w8
+// (component order: mx, my, cA, cB, cC, op, r, g, b).  38 instead of ~72 VALU/DS instructions per entry.
+__device__ __forceinline__ float dpp_get(float v, const int ctrl_is_quad_1032)
+{
+    return ctrl_is_quad_1032
+               ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true))
+               : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float rows_and_halves_sum(float v)
+{
+    R3_DPP_ADD(v, 0x124, 0xf);  // row_ror:4  (lane & 3 preserved)
+    R3_DPP_ADD(v, 0x128, 0xf);  // row_ror:8
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ void wave_reduce9(const SplatGrad& g, int lane, float& w0, float& w1, float& w8)
+{
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+#define R3_PAIR(odd, a, b, quad1032) (((odd) ? (b) : (a)) + dpp_get((odd) ? (a) : (b), quad1032))
+    const float u0 = R3_PAIR(o1, g.mx, g.my, 1), u1 = R3_PAIR(o1, g.cA, g.cB, 1);
+    const float u2 = R3_PAIR(o1, g.cC, g.op, 1), u3 = R3_PAIR(o1, g.r, g.g, 1);
+    float t8 = g.b + dpp_get(g.b, 1);
+    w0 = R3_PAIR(o2, u0, u1, 0);
+    w1 = R3_PAIR(o2, u2, u3, 0);
+    t8 += dpp_get(t8, 0);
+#undef R3_PAIR
+    w0 = rows_and_halves_sum(w0);
+    w1 = rows_and_halves_sum(w1);
+    w8 = rows_and_halves_sum(t8);
+}
+
 template <int PPL>
 __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q, int lane, int* px, int* py)
 {
@@ -397,24 +435,15 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
                 if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
             if (__ballot(any) != 0ull) {
                 float* d = s_grad + j * kGradStride;
-                {
-                    const float v0 = wave_sum_to_lane63(sg.mx), v1 = wave_sum_to_lane63(sg.my);
-                    const float v2 = wave_sum_to_lane63(sg.cA), v3 = wave_sum_to_lane63(sg.cB);
-                    const float v4 = wave_sum_to_lane63(sg.cC), v5 = wave_sum_to_lane63(sg.op);
-                    const float v6 = wave_sum_to_lane63(sg.r), v7 = wave_sum_to_lane63(sg.g);
-                    const float v8 = wave_sum_to_lane63(sg.b);
-                    if (lane == 63) {
-                        d[0] = v0;
-                        d[1] = v1;
-                        d[2] = v2;
-                        d[3] = v3;
-                        d[4] = v4;
-                        d[5] = v5;
-                        d[6] = v6;
-                        d[7] = v7;
-                        d[8] = v8;
-                        d[9] = 1.f;
-                    }
+                float w0, w1, w8;
+                wave_reduce9(sg, lane, w0, w1, w8);
+                if (lane < 4) {
+                    d[lane] = w0;
+                    d[4 + lane] = w1;
+                }
+                if (lane == 0) {
+                    d[8] = w8;
+                    d[9] = 1.f;
                 }
             }
         }
