@@ -70,27 +70,6 @@ __device__ __forceinline__ Splat splat_from_regs(const float4& a, const float4& 
     return s;
 }
 
-// wave-uniform broadcast of entry j's record out of lane j's registers: v_readlane into SGPRs -- no LDS round
-// trip per entry, and the 9 splat fields then feed the VALU as scalar operands instead of occupying VGPRs
-__device__ __forceinline__ float bcast(float v, int j)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-}
-__device__ __forceinline__ Splat splat_from_lane(const float4& a, const float4& b, const float4& c, int j)
-{
-    Splat s;
-    s.x = bcast(a.x, j);
-    s.y = bcast(a.y, j);
-    s.cA = bcast(a.z, j);
-    s.cB = bcast(a.w, j);
-    s.cC = bcast(b.x, j);
-    s.op = bcast(b.y, j);
-    s.r = bcast(b.z, j);
-    s.g = bcast(b.w, j);
-    s.b = bcast(c.x, j);
-    return s;
-}
-
 // consecutive logical ids on one XCD: hardware places workgroup b on XCD b % 8 (speed only, never correctness)
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
 {
@@ -191,7 +170,7 @@ struct BlendFwdArgs {
     float* transmittance;
 };
 
-template <int PPL, bool COUNTERS, bool RL>
+template <int PPL, bool COUNTERS>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
 {
     __shared__ LdsRec s_rec[kChunk];
@@ -237,13 +216,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
         if (__ballot(live != 0) == 0ull) break;  // every pixel of the region saturated
         __syncthreads();
-        const float4 cura = nxa, curb = nxb, curc = nxc;  // RL: entry j's record stays in lane j's registers
-        if (!RL) {
-            s_rec[lane].a = nxa;
-            s_rec[lane].b = nxb;
-            s_rec[lane].c = nxc;
-        }
-        if (!RL || COUNTERS) s_id[lane] = nxid;
+        s_rec[lane].a = nxa;
+        s_rec[lane].b = nxb;
+        s_rec[lane].c = nxc;
+        if (COUNTERS) s_id[lane] = nxid;
         // region pre-test: lane j decides for entry j which of this wave's quadrants it can reach at all
         unsigned long long qmask[PPL], anymask = 0ull;
         {
@@ -269,7 +245,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
         while (anymask) {  // surviving entries, front to back
             const int j = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
-            const Splat s = RL ? splat_from_lane(cura, curb, curc, j) : load_splat(s_rec[j]);
+            const Splat s = load_splat(s_rec[j]);
             const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
             int cnt = 0;
             float tsum = 0.f;
@@ -315,13 +291,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
 template <int PPL>
 static void launch_fwd_ppl(const BlendFwdArgs& a, bool counters, hipStream_t s)
 {
-    static const int RL = env_int("R3DGS_FWD_RL", 1, 0, 1);
     if (counters)
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else if (RL)
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
 }
 
 void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b, ImageState& img,
@@ -370,7 +343,7 @@ struct BlendBwdArgs {
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
 // 5 waves per SIMD for the 4-pixel-per-lane variant: 100 -> 96 VGPRs, no spills
-template <int PPL, bool RL>
+template <int PPL>
 __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBwdArgs a)
 {
     __shared__ LdsRec s_rec[kChunk];
@@ -424,12 +397,9 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
     }
     for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
         __syncthreads();
-        const float4 cura = nxa, curb = nxb, curc = nxc;  // entry j's record stays in lane j's registers
-        if (!RL) {
-            s_rec[lane].a = nxa;
-            s_rec[lane].b = nxb;
-            s_rec[lane].c = nxc;
-        }
+        s_rec[lane].a = nxa;
+        s_rec[lane].b = nxb;
+        s_rec[lane].c = nxc;
         unsigned long long qmask[PPL], anymask = 0ull;
         {
             const Splat mine = splat_from_regs(nxa, nxb, nxc);
@@ -453,7 +423,7 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
         while (anymask) {  // surviving entries, back to front: highest set bit first
             const int j = 63 - __builtin_clzll(anymask);
             anymask &= ~(1ull << j);
-            const Splat s = RL ? splat_from_lane(cura, curb, curc, j) : load_splat(s_rec[j]);
+            const Splat s = load_splat(s_rec[j]);
             const uint32_t pos = (uint32_t)(cbase + j);
             SplatGrad sg;
             sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
@@ -481,7 +451,7 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
             // index of this tile inside the Gaussian's tile rect (exactly the emission order of binning.hip).
             // Plain stores, one owner per slot -- the per-Gaussian kernel adds a Gaussian's slots up in order, so
             // the backward has no float atomics and is bit-reproducible.
-            const float4 c = curc;
+            const float4 c = s_rec[lane].c;
             const uint32_t rect_min = __float_as_uint(c.y), width = __float_as_uint(c.z) & 0xffffu;
             const uint32_t slot = __float_as_uint(c.w) + ((uint32_t)tile_y - (rect_min >> 16)) * width +
                                   ((uint32_t)tile_x - (rect_min & 0xffffu));
@@ -498,11 +468,7 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
 template <int PPL>
 static void launch_bwd_ppl(const BlendBwdArgs& a, hipStream_t s)
 {
-    static const int RL = env_int("R3DGS_BWD_RL", 1, 0, 1);
-    if (RL)
-        hipLaunchKernelGGL((blend_bwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((blend_bwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
 }
 
 void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState& b, const ImageState& img,

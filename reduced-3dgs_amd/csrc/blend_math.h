@@ -86,8 +86,9 @@ R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& 
 {
     const float dx = s.x - pxf, dy = s.y - pyf;
     const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
-    if (power > 0.0f) return 0;
-    const float alpha = fminf(0.99f, s.op * R3_EXP(power));
+    // the reference's two skips (power > 0, alpha < 1/255) as ONE divergence point: a select instead of a branch
+    // for the first (it can only fire for a degenerate conic), then a single test
+    const float alpha = power > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP(power));
     if (alpha < 1.0f / 255.0f) return 0;
     const float test_T = p.T * (1.0f - alpha);
     if (test_T < 0.0001f) return 2;
@@ -136,13 +137,13 @@ struct SplatGrad {
 // viewport factors (backward.cu:498-499); the caller applies them once after the reduction.
 R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
 {
-    if (pos >= p.last) return false;  // behind this pixel's last contributor (backward.cu:524-526)
     const float dx = s.x - pxf, dy = s.y - pyf;
     const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
-    if (power > 0.0f) return false;
     const float G = R3_EXP(power);
     const float alpha = fminf(0.99f, s.op * G);
-    if (alpha < 1.0f / 255.0f) return false;
+    // the reference's three skips -- entry behind this pixel's last contributor (backward.cu:524-526), power > 0,
+    // alpha < 1/255 -- evaluated together: one divergence point instead of three
+    if (!(pos < p.last && power <= 0.0f && alpha >= 1.0f / 255.0f)) return false;
     const float ra = R3_RCP(1.0f - alpha);
     p.T = p.T * ra;  // T recovered by division (backward.cu:541)
     const float dch = alpha * p.T;
