@@ -142,9 +142,13 @@ def test_golden_cases_forward_backward(C_, golden_dir, name):
     dict(P=10_000, W=400, H=400, f=300.0, cam_seed=None, gseed=0, degree_mode="all0", scale_mu=0.012, lam=0.0),
     dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02, lam=0.1),
     dict(P=3_000, W=203, H=117, f=150.0, cam_seed=5, gseed=6, degree_mode="all3", scale_mu=0.05, lam=0.0, spread=1.4),
-], ids=["cfg0_10k_400x400_deg0", "20k_640x360_mixed_sparsity", "ragged_edges_ewa_clamp"])
+    dict(P=300_000, W=800, H=800, f=600.0, cam_seed=1, gseed=0, degree_mode="all3", scale_mu=0.012, lam=0.0),
+], ids=["cfg0_10k_400x400_deg0", "20k_640x360_mixed_sparsity", "ragged_edges_ewa_clamp",
+        "cfg1_lego_like_300k_800x800_deg3"])
 def test_oracle_parity_larger(C_, kw):
-    """BASELINE.json configs[0] (10k Gaussians, 400x400, degree 0) and two wider cases."""
+    """BASELINE.json configs[0] (10k Gaussians, 400x400, degree 0), two wider cases, and the synthetic stand-in
+    for configs[1] (300k Gaussians, 800x800, degree 3) -- the largest size compared element-wise
+    with the oracle."""
     W, H, P = kw["W"], kw["H"], kw["P"]
     cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
     g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw["scale_mu"])

@@ -36,8 +36,35 @@ template <int IPT, int RB>
 using OS = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<256, IPT>, kernel_config<256, IPT>, RB>, 0>;
 using DefOnesweep = radix_sort_config<default_config, default_config, default_config, 0>;
 
+template <class K>
+int run_k(const char* name, size_t n, int bits)
+{
+    K *kin, *kout; uint32_t *vin, *vout;
+    CK(hipMalloc(&kin, n * sizeof(K))); CK(hipMalloc(&kout, n * sizeof(K))); CK(hipMalloc(&vin, n * 4)); CK(hipMalloc(&vout, n * 4));
+    std::vector<K> h(n); std::mt19937 rng(2);
+    for (auto& x : h) x = (K)(rng() % 6700u);
+    CK(hipMemcpy(kin, h.data(), n * sizeof(K), hipMemcpyHostToDevice));
+    size_t bytes = 0;
+    CK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits));
+    void* tmp; CK(hipMalloc(&tmp, bytes + 256));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) CK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, bits));
+    CK(hipEventRecord(a));
+    for (int i = 0; i < 20; i++) CK(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, bits));
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    printf("%-34s n=%8zu bits=%2d  %8.1f us\n", name, n, bits, 1000.f * ms / 20);
+    return 0;
+}
+
 int main()
 {
+    run_k<uint16_t>("u16 keys default", 3640000, 13);
+    run_k<uint16_t>("u16 keys default 16 bits", 3640000, 16);
+    run_k<uint32_t>("u32 keys default", 3640000, 13);
+    run_k<uint16_t>("u16 keys default (1.8M)", 1800000, 13);
+    run_k<uint32_t>("u32 keys default (1.8M)", 1800000, 13);
+
     const size_t sizes[2] = {500000, 3640000};
     const int bitsv[2] = {32, 13};
     for (int t = 0; t < 2; t++) {
