@@ -163,6 +163,31 @@ def test_oracle_parity_larger(C_, kw):
     check_backward(bout, gr, ref["state"], 16)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=1, W=64, H=48, f=50.0, scale_mu=0.5, mod=1.0),
+    dict(P=63, W=64, H=48, f=50.0, scale_mu=0.2, mod=1.0),
+    dict(P=65, W=130, H=70, f=80.0, scale_mu=0.2, mod=0.7),
+    dict(P=2500, W=96, H=80, f=70.0, scale_mu=1.2, mod=1.0),   # every splat covers most tiles: lists of ~2000
+    dict(P=4000, W=320, H=200, f=200.0, scale_mu=0.08, mod=1.6),
+], ids=["single", "p63", "p65_mod0.7", "dense_long_lists", "mod1.6"])
+def test_edge_sizes_long_lists_and_scale_modifier(C_, kw):
+    W, H, P, mod = kw["W"], kw["H"], kw["P"], kw["mod"]
+    cam = ss.make_camera(W, H, kw["f"], 9)
+    g = ss.make_gaussians(P, cam, seed=11, degree_mode="mixed", scale_mu=kw["scale_mu"], scale_sigma=0.4,
+                          behind_frac=0.0 if P < 10 else 0.02)
+    bg = np.array([0.3, 0.3, 0.3], np.float32)
+    dl = ss.upstream_grad(W, H, seed=6) * (W * H)
+    ref = oracle_forward(bg, g, cam, H, W, mod=mod)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, mod=mod)
+    check_forward(C_, fout, ref, H, W, P)
+    gr = orc.backward(ref["state"], dl, 0.02)
+    bout = hip_backward(C_, fargs, fout, dl, 0.02)
+    check_backward(bout, gr, ref["state"], 16)
+    if kw["scale_mu"] > 1.0:
+        rng_ = ref["state"]["ranges"].astype(np.int64)
+        assert (rng_[:, 1] - rng_[:, 0]).max() > 1500  # really exercises multi-chunk lists
+
+
 def test_precomputed_colour_and_covariance(C_):
     W, H, P = 160, 120, 4000
     cam = ss.make_camera(W, H, 120.0, 7)
@@ -322,5 +347,9 @@ def test_full_size_properties(C_, metric_scene):
         scale = float(lin.abs().max()) + 1e-30
         assert float((b3[k] - lin).abs().max()) <= 2e-4 * scale, k
     assert all(bool(torch.isfinite(t).all()) for t in b1[:8])
+    # the backward has no float atomics: two passes over the same forward state are bit-identical
+    b1_again = hip_backward(C_, fargs, fout, g1, 0.0)
+    for k in range(8):
+        assert torch.equal(b1[k], b1_again[k]), k
     inv = radii == 0
     assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())
