@@ -338,6 +338,7 @@ struct BlendBwdArgs {
     uint32_t nblocks;
     const float* bg;
     float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
+    unsigned char* pair_flag;  // [R] set for rows written in this pass
 };
 
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
@@ -450,7 +451,8 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
             // park the entry's sums in ITS slot of the per-pair slab: slot = first pair of the Gaussian + row-major
             // index of this tile inside the Gaussian's tile rect (exactly the emission order of binning.hip).
             // Plain stores, one owner per slot -- the per-Gaussian kernel adds a Gaussian's slots up in order, so
-            // the backward has no float atomics and is bit-reproducible.
+            // the backward has no float atomics and is bit-reproducible.  Only a 1-byte flag per pair is zeroed
+            // before the pass (3.6 MB instead of the 131 MB slab); rows without flag are never read.
             const float4 c = s_rec[lane].c;
             const uint32_t rect_min = __float_as_uint(c.y), width = __float_as_uint(c.z) & 0xffffu;
             const uint32_t slot = __float_as_uint(c.w) + ((uint32_t)tile_y - (rect_min >> 16)) * width +
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
             dst[1] = src[1] * half_h;
 #pragma unroll
             for (int k = 2; k < 9; k++) dst[k] = src[k];
+            a.pair_flag[slot] = 1;
         }
     }
 }
@@ -489,6 +492,7 @@ void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState&
     a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
     a.bg = view.bg;
     a.pair_grad = b.pair_grad;
+    a.pair_flag = b.pair_flag;
     if (PPL == 4)
         launch_bwd_ppl<4>(a, s);
     else if (PPL == 2)

@@ -372,7 +372,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
 
         StageTimer t4(kBlendBwd, s);
         if (R > 0) {
-            R3_HIP(hipMemsetAsync(bin.pair_grad, 0, sizeof(float) * (size_t)R * kPairGrad, s));
+            R3_HIP(hipMemsetAsync(bin.pair_flag, 0, (size_t)R, s));
             launch_blend_backward(view, geom, bin, img, dL_dpix, s);
             launch_pair_reduce(R, geom, bin, s);
         }

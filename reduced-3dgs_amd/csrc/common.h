@@ -94,6 +94,7 @@ struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
     float* wave_part;      // [(R/64+1) * 2 * kPairGrad] leading / trailing partial run sums of each 64-pair group
+    unsigned char* pair_flag;  // [R] 1 = the backward blend wrote this pair's row (only this is zeroed per pass)
     uint32_t* tile_sorted; // [R] tile id of each entry
     uint32_t* tile_in;     // [R]
     uint32_t* gauss_in;    // [R]
@@ -107,6 +108,7 @@ struct BinState {
         b.point_list = c.take<uint32_t>(R);
         b.pair_grad = c.take<float>(R * kPairGrad);
         b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
+        b.pair_flag = c.take<unsigned char>(R);
         b.tile_sorted = c.take<uint32_t>(R);
         b.tile_in = c.take<uint32_t>(R);
         b.gauss_in = c.take<uint32_t>(R);

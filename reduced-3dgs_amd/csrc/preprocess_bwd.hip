@@ -40,6 +40,7 @@ struct ShRowLdsRW {
 // over its own pairs instead cost 0.86 ms: the largest splats own 600+ pairs.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const float* __restrict__ pair_grad,
+                                                          const unsigned char* __restrict__ pair_flag,
                                                           const uint32_t* __restrict__ pair_gid,
                                                           const GRec* __restrict__ rec,
                                                           const uint32_t* __restrict__ tiles, float* __restrict__ acc,
@@ -50,14 +51,15 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
     const bool valid = e < R;
     float v[kPairGrad];
     uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
     if (valid) {
         key = pair_gid[e];
-        const float* src = pair_grad + (size_t)e * kPairGrad;
+        if (pair_flag[e]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
+            const float* src = pair_grad + (size_t)e * kPairGrad;
 #pragma unroll
-        for (int k = 0; k < kPairGrad; k++) v[k] = src[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
+            for (int k = 0; k < kPairGrad; k++) v[k] = src[k];
+        }
     }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {  // inclusive segmented scan over equal-key runs
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
 void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s)
 {
     if (R <= 0) return;
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.pair_grad, b.gauss_in,
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.pair_grad, b.pair_flag,
+                       b.gauss_in,
                        g.rec, g.tiles, g.acc, b.wave_part);
 }
 
