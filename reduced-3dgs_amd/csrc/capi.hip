@@ -202,7 +202,13 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     StageTimer t1(kDepthSort, s);
     run_depth_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
     t1.stop();
-    R3_HIP(hipEventSynchronize(rb.copied));
+    // spin on the event instead of hipEventSynchronize: a blocking wait parks the host thread, and on an otherwise
+    // idle many-core host its wake-up (deep C-state exit) was observed to cost more than the whole forward
+    for (;;) {
+        const hipError_t q = hipEventQuery(rb.copied);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) R3_HIP(q);
+    }
     uint64_t R64 = 0;
     for (int k = 0; k < kShards; k++) R64 += rb.pinned->shard[k].num_rendered;
     if (R64 > 0x7fffffffull) throw Error("num_rendered exceeds 2^31-1");
