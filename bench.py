@@ -83,7 +83,10 @@ def hold_cpu_awake():
     num_rendered read-back) otherwise pays a C-state exit; one visit of the GPU box measured 7.2 ms/step with
     1.16 ms of GPU work per step.  Returns the open file (keep a reference) or None when unavailable."""
     try:
+        import stat
         import struct
+        if not stat.S_ISCHR(os.stat("/dev/cpu_dma_latency").st_mode):
+            return None
         f = open("/dev/cpu_dma_latency", "wb", buffering=0)
         f.write(struct.pack("i", 0))
         return f
@@ -101,6 +104,9 @@ def main():
     ap.add_argument("--cameras", type=int, default=8)
     args = ap.parse_args()
     pm_qos = hold_cpu_awake()  # noqa: F841  (kept open for the lifetime of the process)
+    # run autograd's backward in the calling thread: no hand-off to a per-device worker thread per iteration
+    # (same reason as above: a parked thread's wake-up can cost more than the 1.2 ms step)
+    torch.autograd.set_multithreading_enabled(False)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
