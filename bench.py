@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--workload", default="metric_500k_1600x1062", choices=list(ss.WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cameras", type=int, default=8)
+    ap.add_argument("--host-diag", action="store_true", help="add host-side per-step timing percentiles")
     args = ap.parse_args()
     pm_qos = hold_cpu_awake()  # noqa: F841  (kept open for the lifetime of the process)
     # run autograd's backward in the calling thread: no hand-off to a per-device worker thread per iteration
@@ -182,9 +183,12 @@ def main():
     _C.profile_read()
     barrier()
     torch.cuda.synchronize()
+    host_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        th = time.perf_counter()
         train_step(args.warmup + i)
+        host_ms.append(1e3 * (time.perf_counter() - th))
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -243,6 +247,11 @@ def main():
         "stages": stages,
         "host": {"cpu_dma_latency_held": pm_qos is not None, "cpus": os.cpu_count()},
     }
+    if args.host_diag:
+        hs = sorted(host_ms)
+        result["host"].update({"loadavg": os.getloadavg(), "affinity": len(os.sched_getaffinity(0)),
+                               "host_ms_per_step_min_med_max": [round(hs[0], 3), round(hs[len(hs) // 2], 3),
+                                                                round(hs[-1], 3)]})
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
