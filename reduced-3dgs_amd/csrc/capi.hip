@@ -8,6 +8,8 @@
 //     num_rendered, which sizes the caller-owned binning blob (same structural sync as the reference, but
 //     R is produced by the first kernel and fetched on a side stream while the depth sort runs, so the GPU
 //     does not idle during the host round trip);
+//   * the SH -> RGB kernel (the forward's HBM-heavy stream) runs on that side stream too, underneath the
+//     launch-latency-bound sorts;
 //   * no per-call hipMalloc/hipFree: all scratch lives in the three caller blobs;
 //   * `debug` makes every stage synchronise and surface its error (the reference's CHECK_CUDA).
 #include "../../include/r3dgs_rasterizer.h"
@@ -54,7 +56,7 @@ size_t cached_tile_temp(size_t R)
 }
 
 // ---- optional per-stage timing with HIP events on the caller's stream (r3dgs_profile_*) ----------
-enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kNumStages };
+enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
 struct Profiler {
     std::mutex mu;
     bool on = false;
@@ -100,7 +102,7 @@ struct StageTimer {
 // runs beside the depth sort, so the structural host round trip of the forward is hidden behind GPU work.
 struct ReadbackCtx {
     hipStream_t side = nullptr;
-    hipEvent_t after_pre = nullptr, copied = nullptr;
+    hipEvent_t after_pre = nullptr, copied = nullptr, colored = nullptr;
     r3::GeomHeader* pinned = nullptr;
 };
 ReadbackCtx& readback_ctx()
@@ -113,6 +115,7 @@ ReadbackCtx& readback_ctx()
         R3_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.copied, hipEventDisableTiming));
+        R3_HIP(hipEventCreateWithFlags(&c.colored, hipEventDisableTiming));
         R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(r3::GeomHeader), hipHostMallocDefault));
     }
     return c;
@@ -199,6 +202,12 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
     R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, sizeof(GeomHeader), hipMemcpyDeviceToHost, rb.side));
     R3_HIP(hipEventRecord(rb.copied, rb.side));
+    {   // SH -> RGB on the side stream, underneath the depth sort + binning of the main stream
+        StageTimer tc(kColor, rb.side);
+        launch_preprocess_color(in, view, geom, rb.side);
+        tc.stop();
+        R3_HIP(hipEventRecord(rb.colored, rb.side));
+    }
     StageTimer t1(kDepthSort, s);
     run_depth_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
     t1.stop();
@@ -225,11 +234,13 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     run_tile_binning(P, (int)R, gx, gy, geom, bin, img, s);
     t2.stop();
     check_launch("tile binning", s, debug);
+    R3_HIP(hipStreamWaitEvent(s, rb.colored, 0));  // the blend needs the colours
     StageTimer t3(kBlendFwd, s);
     launch_blend_forward(view, geom, bin, img, out_color, calculate_mean_transmittance ? out_touched_pixels : nullptr,
                          calculate_mean_transmittance ? out_transmittance : nullptr, s);
     t3.stop();
     check_launch("blend forward", s, debug);
+    if (debug) R3_HIP(hipStreamSynchronize(rb.side));
     return (int)R;
 }
 
@@ -413,8 +424,8 @@ int r3dgs_profile_stage_count(void) { return kNumStages; }
 
 const char* r3dgs_profile_stage_name(int stage)
 {
-    static const char* names[kNumStages] = {"preprocess_fwd", "depth_sort_scan", "tile_binning",
-                                            "blend_fwd",      "blend_bwd",       "preprocess_bwd"};
+    static const char* names[kNumStages] = {"preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd",
+                                            "blend_bwd",      "preprocess_bwd",  "sh_color_overlapped"};
     return (stage >= 0 && stage < kNumStages) ? names[stage] : "";
 }
 

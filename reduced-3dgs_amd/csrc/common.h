@@ -223,6 +223,7 @@ struct FwdInputs {
 };
 
 void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s);
+void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomState& g, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
 // depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])

@@ -4,11 +4,13 @@
 // forward.cu:245-350 variableSHPreprocessCUDA (ragged degree-sorted SH buffer) and
 // rasterizer_impl.cu:62-74 checkFrustum of /root/reference/submodules/diff-gaussian-rasterization.
 //
-// One lane per Gaussian, 256-thread workgroups.  HBM-bound: each wave first copies the SH rows of its
-// 64 Gaussians -- one contiguous span of the [P,M,3] tensor (or of the ragged buffer) -- into LDS with
-// fully coalesced loads, then every lane evaluates its own row out of LDS (bank-skewed index), instead
-// of 64 lanes striding 192 B apart through global memory.  Output is one 48-byte record per visible
-// Gaussian (GRec), the tile rect, the depth sort key and tiles_touched.
+// One lane per Gaussian, 256-thread workgroups, two kernels: geometry (everything the binning needs; its
+// sort keys go to the main stream's depth sort at once) and colour (the HBM-heavy SH stream, launched on a
+// side stream so that it runs underneath that sort).  In the colour kernel each wave first copies the SH rows of
+// its 64 Gaussians -- one contiguous span of the [P,M,3] tensor (or of the ragged buffer) -- into LDS with
+// fully coalesced loads, then every lane evaluates its own row out of LDS (bank-skewed index), instead of 64
+// lanes striding 192 B apart through global memory.  Output is one 48-byte record per visible Gaussian (GRec),
+// the tile rect, the depth sort key and tiles_touched.
 // Built with -ffp-contract=off: radii / rects / tiles_touched are bit-exact against the oracle.
 #include "common.h"
 
@@ -55,25 +57,23 @@ __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const i
     return off + (idx - cumsum[2]) * coeffs[3];
 }
 
-template <bool RAGGED>
-__global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
+// ---- kernel 1: geometry ---------------------------------------------------------------------------
+// cull, projection, conic, radius, tile rect, depth key, per-view counters.  Reads 44 B per Gaussian.  Its
+// outputs are everything the depth sort / binning needs, so the SH -> RGB kernel below can run on a side
+// stream underneath the (launch-latency-bound) sort.
+__global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
 {
-    __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.in.P, M = a.in.M;
+    const int P = a.in.P;
     const int i = blockIdx.x * kPreBlock + tid;
     const bool valid = i < P;
-    const int wave_first = blockIdx.x * kPreBlock + wave * 64;
     const Camera cam = load_camera(a.view);
 
-    float mx = 0.f, my = 0.f, mz = 1.f;
     PreOut o;
     o.radius = 0;
     o.tiles = 0;
     if (valid) {
-        mx = a.in.means3D[3 * i];
-        my = a.in.means3D[3 * i + 1];
-        mz = a.in.means3D[3 * i + 2];
+        const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
         float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6];
         const float* c6p = nullptr;
         if (a.in.cov3D_precomp) {
@@ -88,8 +88,68 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
             q[3] = qv.w;
         }
         preprocess_one(cam, mx, my, mz, sc, q, c6p, a.in.opacities[i], &o);
+        uint32_t dkey = 0xFFFFFFFFu;
+        if (o.radius > 0) {
+            GRec r;
+            r.x = o.px;
+            r.y = o.py;
+            r.cA = o.conic[0];
+            r.cB = o.conic[1];
+            r.cC = o.conic[2];
+            r.op = o.opacity;
+            r.r = r.g = r.b = 0.f;  // filled in by the colour kernel
+            r.rect_min = (uint32_t)o.rmin[0] | ((uint32_t)o.rmin[1] << 16);
+            r.width_clamp = (uint32_t)(o.rmax[0] - o.rmin[0]);  // clamp bits OR-ed in by the colour kernel
+            r.pair_start = 0;                                      // filled in by the pair-emission kernel
+            a.rec[i] = r;
+            a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
+                                     (unsigned short)o.rmax[1]);
+            dkey = __float_as_uint(o.depth);
+        }
+        a.radii[i] = o.radius;
+        a.tiles[i] = o.tiles;
+        a.depth_key[i] = dkey;
     }
-    const bool vis = o.radius > 0;
+    // per-workgroup totals -> one atomic pair per workgroup on a sharded counter: visible count (SH-sparsity
+    // normaliser of the backward) and num_rendered.  R does not depend on the depth order, so the host can fetch it
+    // right after this kernel and size the binning blob while the GPU is busy with the depth sort (capi.hip).
+    const unsigned long long vmask = __ballot(o.radius > 0);
+    uint32_t tsum = o.tiles;
+    for (int off = 32; off > 0; off >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, off);
+    __shared__ uint32_t s_cnt[kPreBlock / 64][2];
+    if (lane == 0) {
+        s_cnt[wave][0] = (uint32_t)__popcll(vmask);
+        s_cnt[wave][1] = tsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t v = 0, r = 0;
+        for (int k = 0; k < kPreBlock / 64; k++) {
+            v += s_cnt[k][0];
+            r += s_cnt[k][1];
+        }
+        if (v) {
+            GeomHeader::Shard* sh = a.header->shard + (blockIdx.x & (kShards - 1));
+            atomicAdd(&sh->visible, v);
+            atomicAdd(&sh->num_rendered, r);
+        }
+    }
+}
+
+// ---- kernel 2: colour -------------------------------------------------------------------------------
+// SH -> RGB (forward.cu:105-159, ragged variant :19-100) or copy of the precomputed colours into the
+// records of the visible Gaussians.  Streams the SH tensor (192 B per Gaussian at degree 3): the wave's 64 rows
+// are one contiguous span, staged through LDS with dwordx4 loads, evaluated per lane from LDS.
+template <bool RAGGED>
+__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a)
+{
+    __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.in.P, M = a.in.M;
+    const int i = blockIdx.x * kPreBlock + tid;
+    const bool valid = i < P;
+    const int wave_first = blockIdx.x * kPreBlock + wave * 64;
+    const bool vis = valid && a.tiles[i] > 0;
     const bool need_sh = vis && (a.in.colors_precomp == nullptr);
 
     // ---- per-lane SH row placement inside the wave's contiguous span --------------------------
@@ -137,64 +197,24 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(PreArgs a)
     }
     __syncthreads();
 
-    if (valid) {
-        uint32_t dkey = 0xFFFFFFFFu;
-        if (vis) {
-            float rgb[3];
-            uint32_t cbits = 0;
-            if (need_sh) {
-                ShRowLds row{s_sh[wave], roff};
-                sh_to_rgb(deg, row, mx, my, mz, cam.campos, rgb, &cbits);
-            } else {
-                rgb[0] = a.in.colors_precomp[3 * i];
-                rgb[1] = a.in.colors_precomp[3 * i + 1];
-                rgb[2] = a.in.colors_precomp[3 * i + 2];
-            }
-            GRec r;
-            r.x = o.px;
-            r.y = o.py;
-            r.cA = o.conic[0];
-            r.cB = o.conic[1];
-            r.cC = o.conic[2];
-            r.op = o.opacity;
-            r.r = rgb[0];
-            r.g = rgb[1];
-            r.b = rgb[2];
-            r.rect_min = (uint32_t)o.rmin[0] | ((uint32_t)o.rmin[1] << 16);
-            r.width_clamp = (uint32_t)(o.rmax[0] - o.rmin[0]) | (cbits << 16);
-            r.pair_start = 0;  // filled in by the pair-emission kernel
-            a.rec[i] = r;
-            a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
-                                     (unsigned short)o.rmax[1]);
-            dkey = __float_as_uint(o.depth);
+    if (vis) {
+        float rgb[3];
+        uint32_t cbits = 0;
+        if (need_sh) {
+            const float campos[3] = {a.view.campos[0], a.view.campos[1], a.view.campos[2]};
+            ShRowLds row{s_sh[wave], roff};
+            sh_to_rgb(deg, row, a.in.means3D[3 * i], a.in.means3D[3 * i + 1], a.in.means3D[3 * i + 2], campos, rgb,
+                      &cbits);
+        } else {
+            rgb[0] = a.in.colors_precomp[3 * i];
+            rgb[1] = a.in.colors_precomp[3 * i + 1];
+            rgb[2] = a.in.colors_precomp[3 * i + 2];
         }
-        a.radii[i] = o.radius;
-        a.tiles[i] = o.tiles;
-        a.depth_key[i] = dkey;
-    }
-    // per-wave totals -> two atomics per wave: visible count (SH-sparsity normaliser of the backward) and
-    // num_rendered.  R does not depend on the depth order, so the host can fetch it right after this kernel
-    // and size the binning blob while the GPU is still busy with the depth sort + scan (capi.hip).
-    const unsigned long long vmask = __ballot(vis);
-    uint32_t tsum = o.tiles;
-    for (int off = 32; off > 0; off >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, off);
-    __shared__ uint32_t s_cnt[kPreBlock / 64][2];
-    if (lane == 0) {
-        s_cnt[wave][0] = (uint32_t)__popcll(vmask);
-        s_cnt[wave][1] = tsum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t v = 0, r = 0;
-        for (int k = 0; k < kPreBlock / 64; k++) {
-            v += s_cnt[k][0];
-            r += s_cnt[k][1];
-        }
-        if (v) {
-            GeomHeader::Shard* sh = a.header->shard + (blockIdx.x & (kShards - 1));
-            atomicAdd(&sh->visible, v);
-            atomicAdd(&sh->num_rendered, r);
-        }
+        GRec* r = a.rec + i;
+        r->r = rgb[0];
+        r->g = rgb[1];
+        r->b = rgb[2];
+        if (cbits) r->width_clamp |= cbits << 16;  // same lane wrote the width in the geometry kernel
     }
 }
 
@@ -210,10 +230,25 @@ void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g
     a.header = g.header;
     a.radii = radii;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
+    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, a);
+}
+
+void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomState& g, hipStream_t s)
+{
+    PreArgs a;
+    a.in = in;
+    a.view = view;
+    a.rec = g.rec;
+    a.rect = g.rect;
+    a.depth_key = g.depth_key;
+    a.tiles = g.tiles;
+    a.header = g.header;
+    a.radii = nullptr;
+    const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
     if (in.coeffs_num)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(blocks), dim3(kPreBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(blocks), dim3(kPreBlock), 0, s, a);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2
