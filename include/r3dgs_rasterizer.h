@@ -105,6 +105,17 @@ int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer,
                          char* image_buffer, uint64_t* keys, uint32_t* point_list, uint32_t* ranges /*[Tn][2]*/,
                          uint32_t* n_contrib, float* final_T, uint32_t* tiles_touched, void* stream);
 
+/* Next-tier operator: one camera's contribution to `calculate_colours_variance`
+ * (reduced_3dgs.cu:143-198 + reduced_3dgs/sh_culling.cu:6-90), fused into one per-Gaussian kernel.  Call after
+ * r3dgs_forward(..., calculate_mean_transmittance = 1) of that camera with its radii / out_touched_pixels /
+ * out_transmittance.  Updates in place: wSum[P], wSumSq[P], mean[P,3], variance[P,3],
+ * colourDistancesAccum[P,max_sh_deg] (all zero before the first camera).  The caller finishes with
+ * colourDistancesAccum / wSum, variance / wSum, mean (reduced_3dgs.cu:202). */
+int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg, const float* means3D,
+                                     const float* cam_pos, const float* shs, const int* radii,
+                                     const int* touched_pixels, const float* transmittance, float* wSum, float* wSumSq,
+                                     float* mean, float* variance, float* colourDistancesAccum, void* stream);
+
 /* Optional per-stage timing (not in the reference; it times with torch.cuda.Event pairs from Python,
  * train.py:52-53, gaussian_renderer/__init__.py:95-98).  When enabled, every forward/backward records a
  * HIP event pair around each stage ON THE CALLER'S STREAM.  r3dgs_profile_read() waits for the recorded

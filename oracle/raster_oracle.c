@@ -742,3 +742,36 @@ void orc_preprocess_bwd(int P, int M, const int* degs, const float* means, const
         dL_dopacity[i] = (float)((double)dL_dopacity[i] * ((double)o * (1.0 - (double)o)));
     }
 }
+
+/* -------------------------------------------------------------------------
+ * SH-band culling statistics -- next-tier operator `calculate_colours_variance`
+ * (DGR/reduced_3dgs.cu:41-203).  Per-camera, per-Gaussian part:
+ * DGR/reduced_3dgs/sh_culling.cu:6-57 computeColorFromSH: colour truncated after band k for
+ * k = 0..deg (note: +0.5 is added right after the DC term there, unlike forward.cu:151), slots above the
+ * Gaussian's own degree stay 0.  `stride` = max_sh_deg + 1 slots of 3 floats (the reference hard-codes 4).
+ * ------------------------------------------------------------------------- */
+void orc_truncated_colours(int P, int M, int stride, const int* degs, const float* means, const float* campos,
+                           const float* shs, float* colours /* [P][stride][3], pre-zeroed */)
+{
+    for (int i = 0; i < P; i++) {
+        const float* p = means + 3 * i;
+        const float* sh = shs + 3 * (size_t)M * i;
+        float d[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+        float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+        int deg = degs[i];
+        if (deg > stride - 1) deg = stride - 1;
+        float Y[16];
+        sh_basis(deg, x, y, z, Y);
+        for (int ch = 0; ch < 3; ch++) {
+            float r = Y[0] * sh[ch];
+            r += 0.5f;
+            colours[((size_t)i * stride + 0) * 3 + ch] = fmaxf_(r, 0.0f);
+            int k = 1;
+            for (int band = 1; band <= deg; band++) {
+                for (; k < (band + 1) * (band + 1); k++) r = r + Y[k] * sh[3 * k + ch];
+                colours[((size_t)i * stride + band) * 3 + ch] = fmaxf_(r, 0.0f);
+            }
+        }
+    }
+}

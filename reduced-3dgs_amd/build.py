@@ -27,6 +27,7 @@ UNITS = {
     "preprocess.hip": EXACT,
     "preprocess_bwd.hip": EXACT,
     "binning.hip": [],
+    "colour_variance.hip": EXACT,
     "blend.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "capi.hip": [],
 }

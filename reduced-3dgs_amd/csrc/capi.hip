@@ -413,6 +413,26 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
     });
 }
 
+int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg, const float* means3D,
+                                     const float* cam_pos, const float* shs, const int* radii,
+                                     const int* touched_pixels, const float* transmittance, float* wSum, float* wSumSq,
+                                     float* mean, float* variance, float* colourDistancesAccum, void* stream)
+{
+    return guarded([&]() {
+        if (P <= 0) return 0;
+        if (max_sh_deg < 1 || max_sh_deg > 3) throw r3::Error("max_sh_deg must be in [1,3]");
+        if (M < (max_sh_deg + 1) * (max_sh_deg + 1) || M > 16) throw r3::Error("SH tensor too small for max_sh_deg");
+        if (!D || !means3D || !cam_pos || !shs || !radii || !touched_pixels || !transmittance || !wSum || !wSumSq ||
+            !mean || !variance || !colourDistancesAccum)
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        r3::launch_colour_variance_accumulate(P, D, M, max_sh_deg, means3D, cam_pos, shs, radii, touched_pixels,
+                                              transmittance, wSum, wSumSq, mean, variance, colourDistancesAccum, s);
+        r3::check_launch("colour variance accumulate", s, false);
+        return 0;
+    });
+}
+
 int r3dgs_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof.mu);

@@ -247,6 +247,10 @@ struct BwdOutputs {
     float* dL_drot;      // [P,4]
     float* dL_dconic;    // [P,4] optional (nullptr: not exported)
 };
+void launch_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg, const float* means3D,
+                                       const float* cam_pos, const float* shs, const int* radii, const int* touched,
+                                       const float* transmittance, float* wSum, float* wSumSq, float* mean,
+                                       float* variance, float* accum, hipStream_t s);
 void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s);
 void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
                                 const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);

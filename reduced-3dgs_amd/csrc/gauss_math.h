@@ -235,6 +235,33 @@ R3_HD void sh_to_rgb(int deg, const ShRow& sh, float mx, float my, float mz, con
     *clamp_bits = bits;
 }
 
+// reduced_3dgs/sh_culling.cu:6-57: colour truncated after band k, k = 0..min(deg, nslots-1); the +0.5 is added
+// right after the DC term there.  out[3*k + ch]; slots above the Gaussian's own degree are left untouched
+// (the caller zero-fills).
+template <class ShRow>
+R3_HD void sh_truncated_colours(int deg, int nslots, const ShRow& sh, float mx, float my, float mz, const float* campos,
+                                float* out)
+{
+    float dx = mx - campos[0], dy = my - campos[1], dz = mz - campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len;
+    dy = dy / len;
+    dz = dz / len;
+    if (deg > nslots - 1) deg = nslots - 1;
+    float Y[16];
+    sh_basis(deg, dx, dy, dz, Y);
+    for (int ch = 0; ch < 3; ch++) {
+        float r = Y[0] * sh.at(ch);
+        r += 0.5f;
+        out[ch] = fmax_(r, 0.0f);
+        int k = 1;
+        for (int band = 1; band <= deg; band++) {
+            for (; k < (band + 1) * (band + 1); k++) r = r + Y[k] * sh.at(3 * k + ch);
+            out[3 * band + ch] = fmax_(r, 0.0f);
+        }
+    }
+}
+
 struct PreOut {
     int radius;        // 0 => culled
     int rmin[2], rmax[2];

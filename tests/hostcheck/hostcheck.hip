@@ -217,6 +217,16 @@ long hc_region_fuzz(long n, unsigned seed, long* n_skip, long* n_keep_empty)
     return bad;
 }
 
+void hc_truncated_colours(int P, int M, int nslots, const int* degs, const float* means, const float* campos,
+                          const float* shs, float* colours /* [P][nslots][3], pre-zeroed */)
+{
+    for (int i = 0; i < P; i++) {
+        ShRowPlain row{shs + 3 * (size_t)M * i};
+        sh_truncated_colours(degs[i], nslots, row, means[3 * i], means[3 * i + 1], means[3 * i + 2], campos,
+                             colours + 3 * (size_t)nslots * i);
+    }
+}
+
 void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const int* radii, const float* shs,
                        const unsigned* clamp_bits, const float* scales, const float* rots, float mod,
                        const float* cov_pre, const float* view, const float* proj, const float* campos, int W, int H,
