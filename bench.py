@@ -114,12 +114,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # R3DGS_BENCH_SINGLE_DEVICE=1 (+ R3DGS_BENCH_BACKEND=gloo): functional dry run of the N>1 code path on a box with
+    # one GPU (all ranks share cuda:0, exchange through gloo) -- never a performance number
+    same_dev = os.environ.get("R3DGS_BENCH_SINGLE_DEVICE") == "1"
+    dev_index = 0 if (world == 1 or same_dev) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+        backend = os.environ.get("R3DGS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    device = torch.device("cuda", dev_index)
 
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _C
