@@ -28,10 +28,13 @@ UNITS = {
     "preprocess_bwd.hip": EXACT,
     "binning.hip": [],
     "colour_variance.hip": EXACT,
+    "reduction_ops.hip": EXACT,
+    "knn.hip": EXACT,
     "blend.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "capi.hip": [],
 }
-HEADERS = ["common.h", "gauss_math.h", "blend_math.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h")]
+HEADERS = ["common.h", "gauss_math.h", "blend_math.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h"),
+           os.path.join("..", "..", "include", "r3dgs_reduction.h")]
 
 
 def _newest(paths):

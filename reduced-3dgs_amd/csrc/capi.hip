@@ -246,6 +246,8 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
 
 }  // namespace
 
+int r3::guarded_call(const std::function<int()>& f) { return guarded(f); }
+
 extern "C" {
 
 const char* r3dgs_version(void) { return "r3dgs-hip gfx950 0.1"; }

@@ -14,6 +14,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <stdexcept>
 #include <string>
 
@@ -150,6 +151,9 @@ size_t tile_sort_temp_bytes(size_t R);
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+
+// Runs f, turning exceptions into (-1, r3dgs_last_error()); defined in capi.hip, shared by every extern "C" TU.
+int guarded_call(const std::function<int()>& f);
 
 #define R3_HIP(expr)                                                                                   \
     do {                                                                                               \

@@ -1,0 +1,372 @@
+// knn.hip -- exact K nearest neighbours of a point cloud (r3dgs_knn, include/r3dgs_reduction.h); replaces
+// SimpleKNN::knn / knn_index2 of /root/reference/submodules/simple-knn/simple_knn.cu:179-224, :468-513.
+//
+// What the reference computes: per point, the K smallest squared distances to the OTHER points (by index) and
+// their indices; `knn` returns the mean of the 3 smallest.  How it gets there (one thread per point walking
+// 128-point Morton boxes outward, K-best lists read-modify-written in global memory, three host syncs for the
+// bounding box) is not reproduced.  Here:
+//   1. bounding box by a block reduce + ordered-int atomics, no host read-back;
+//   2. 30-bit Morton codes, rocPRIM radix sort of (code, index);
+//   3. points gathered into sorted order as float4 {x,y,z,index}; one AABB per 64 consecutive points (= one wave);
+//   4. one WAVE per 64 consecutive queries.  Each lane keeps its K-best list in an LDS column (bank = lane, so the
+//      column scans are conflict-free).  The wave first scans its own and adjacent boxes (seed), then every lane
+//      tests a different box's AABB against the wave's AABB and current worst distance (64 box tests per step);
+//      surviving boxes are staged through LDS and scored by all lanes with broadcast reads.
+// The result is canonical: ascending by (distance, index), ties at the K-th place resolved by the smaller index.
+// Compiled without FMA contraction so that the box lower bounds (monotone in every rounding step) can never exceed
+// a contained point's distance computed by the same expression: the search is exact in fp32.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/r3dgs_reduction.h"
+#include "common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxK = 112;      // LDS: K * 64 lanes * 8 B + 1 KB staging <= 64 KB per wave
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct KnnWork {
+    int* bbox;            // 6 ordered-int encoded floats: min xyz, max xyz
+    uint32_t* code;       // [P]
+    uint32_t* code_sorted;
+    uint32_t* index;      // [P] iota
+    uint32_t* index_sorted;
+    float4* sorted;       // [P] {x,y,z,as_float(index)} in Morton order
+    float4* box_min;      // [nb]
+    float4* box_max;      // [nb]
+    char* temp;
+    static KnnWork carve(char* base, size_t P, size_t temp_bytes)
+    {
+        KnnWork w;
+        char* p = base;
+        auto take = [&](size_t bytes) {
+            char* r = p;
+            p += (bytes + 255) / 256 * 256;
+            return r;
+        };
+        const size_t nb = (P + kWave - 1) / kWave;
+        w.bbox = reinterpret_cast<int*>(take(256));
+        w.code = reinterpret_cast<uint32_t*>(take(4 * P));
+        w.code_sorted = reinterpret_cast<uint32_t*>(take(4 * P));
+        w.index = reinterpret_cast<uint32_t*>(take(4 * P));
+        w.index_sorted = reinterpret_cast<uint32_t*>(take(4 * P));
+        w.sorted = reinterpret_cast<float4*>(take(16 * P));
+        w.box_min = reinterpret_cast<float4*>(take(16 * nb));
+        w.box_max = reinterpret_cast<float4*>(take(16 * nb));
+        w.temp = take(temp_bytes);
+        (void)p;
+        return w;
+    }
+};
+
+size_t sort_temp_bytes(size_t P)
+{
+    size_t bytes = 0;
+    R3_HIP(rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, P, 0, 30, (hipStream_t)0));
+    return bytes;
+}
+
+// float <-> int whose signed order matches the float order (so atomicMin/atomicMax work on floats)
+__device__ inline int f2ord(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ inline float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__device__ inline float wave_min(float v)
+{
+    for (int off = 32; off; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ inline float wave_max(float v)
+{
+    for (int off = 32; off; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ void bbox_init_kernel(int* bbox)
+{
+    if (threadIdx.x < 3) bbox[threadIdx.x] = f2ord(kFltMax);
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = f2ord(-kFltMax);
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restrict__ pts, int* __restrict__ bbox)
+{
+    float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)
+        for (int a = 0; a < 3; a++) {
+            const float v = pts[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    for (int a = 0; a < 3; a++) {
+        mn[a] = wave_min(mn[a]);
+        mx[a] = wave_max(mx[a]);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&bbox[a], f2ord(mn[a]));
+            atomicMax(&bbox[3 + a], f2ord(mx[a]));
+        }
+}
+
+__device__ inline uint32_t spread10(uint32_t x)
+{
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(int P, const float* __restrict__ pts, const int* __restrict__ bbox,
+                                                     uint32_t* __restrict__ code, uint32_t* __restrict__ index)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = ord2f(bbox[a]), hi = ord2f(bbox[3 + a]);
+        const float ext = hi - lo;
+        float t = ext > 0.f ? (pts[3 * i + a] - lo) / ext : 0.f;
+        t = fminf(fmaxf(t, 0.f), 1.f);            // also maps NaN to 0
+        q[a] = (uint32_t)(t * 1023.f);
+    }
+    code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    index[i] = (uint32_t)i;
+}
+
+// one wave per box: gather its 64 points into sorted order and reduce their AABB
+__global__ __launch_bounds__(256) void gather_boxes_kernel(int P, const float* __restrict__ pts,
+                                                           const uint32_t* __restrict__ index_sorted,
+                                                           float4* __restrict__ sorted, float4* __restrict__ box_min,
+                                                           float4* __restrict__ box_max)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < P;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+        const uint32_t id = index_sorted[i];
+        x = pts[3 * id];
+        y = pts[3 * id + 1];
+        z = pts[3 * id + 2];
+        sorted[i] = make_float4(x, y, z, __uint_as_float(id));
+    }
+    const float mnx = wave_min(live ? x : kFltMax), mny = wave_min(live ? y : kFltMax), mnz = wave_min(live ? z : kFltMax);
+    const float mxx = wave_max(live ? x : -kFltMax), mxy = wave_max(live ? y : -kFltMax),
+                mxz = wave_max(live ? z : -kFltMax);
+    if ((threadIdx.x & 63) == 0 && live) {
+        box_min[i >> 6] = make_float4(mnx, mny, mnz, 0.f);
+        box_max[i >> 6] = make_float4(mxx, mxy, mxz, 0.f);
+    }
+}
+
+__device__ inline float gap(float lo_a, float hi_a, float lo_b, float hi_b)
+{
+    // distance between the intervals [lo_a,hi_a] and [lo_b,hi_b] (0 if they overlap)
+    return fmaxf(0.f, fmaxf(lo_b - hi_a, lo_a - hi_b));
+}
+
+struct Best {
+    float* d;       // LDS column base of this lane: d[j * 64]
+    int* id;
+    int K;
+    float wd;       // worst (largest by (distance, index)) entry of the list
+    int wid, wslot;
+
+    __device__ inline void reset()
+    {
+        for (int j = 0; j < K; j++) {
+            d[j * kWave] = kFltMax;
+            id[j * kWave] = 0x7fffffff;   // sorts after every real index; rewritten to -1 on output
+        }
+        wd = kFltMax;
+        wid = 0x7fffffff;
+        wslot = 0;
+    }
+    __device__ inline bool better(float cd, int cid) const { return cd < wd || (cd == wd && cid < wid); }
+    __device__ inline void insert(float cd, int cid)
+    {
+        d[wslot * kWave] = cd;
+        id[wslot * kWave] = cid;
+        float nd = -1.f;
+        int nid = -1, ns = 0;
+        for (int j = 0; j < K; j++) {
+            const float v = d[j * kWave];
+            const int vi = id[j * kWave];
+            if (v > nd || (v == nd && vi > nid)) {
+                nd = v;
+                nid = vi;
+                ns = j;
+            }
+        }
+        wd = nd;
+        wid = nid;
+        wslot = ns;
+    }
+};
+
+// MEAN3: write (d0 + d1 + d2) / 3 instead of the lists (K == 3).
+template <bool MEAN3>
+__global__ __launch_bounds__(kWave) void knn_kernel(int P, int K, const float4* __restrict__ sorted,
+                                                    const float4* __restrict__ box_min,
+                                                    const float4* __restrict__ box_max, float* __restrict__ dists,
+                                                    int* __restrict__ indices, float* __restrict__ mean3)
+{
+    extern __shared__ char smem[];
+    float4* s_cand = reinterpret_cast<float4*>(smem);                        // 64 staged candidates
+    float* s_d = reinterpret_cast<float*>(smem + kWave * sizeof(float4));    // [K][64]
+    int* s_id = reinterpret_cast<int*>(s_d + (size_t)K * kWave);             // [K][64]
+
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int nb = (P + kWave - 1) / kWave;
+    const int qi = b * kWave + lane;
+    const bool live = qi < P;
+    const float4 q = live ? sorted[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int my_id = live ? (int)__float_as_uint(q.w) : -1;
+    const float4 wmin = box_min[b], wmax = box_max[b];
+
+    Best best{s_d + lane, s_id + lane, K, 0.f, 0, 0};
+    best.reset();
+
+    auto scan_box = [&](int c) {
+        // stage box c (wave-uniform c), then every lane whose own bound admits it scores its 64 points
+        const int ci = c * kWave + lane;
+        __syncthreads();
+        s_cand[lane] = ci < P ? sorted[ci] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        __syncthreads();
+        const float4 cmin = box_min[c], cmax = box_max[c];
+        const float gx = gap(q.x, q.x, cmin.x, cmax.x), gy = gap(q.y, q.y, cmin.y, cmax.y),
+                    gz = gap(q.z, q.z, cmin.z, cmax.z);
+        const float lb = (gx * gx + gy * gy) + gz * gz;
+        if (!live || lb > best.wd) return;
+        const int n = min(kWave, P - c * kWave);
+        for (int j = 0; j < n; j++) {
+            const float4 p = s_cand[j];
+            const int cid = (int)__float_as_uint(p.w);
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (cid != my_id && best.better(d2, cid)) best.insert(d2, cid);
+        }
+    };
+
+    // ---- seed: own box and its Morton neighbours, enough points to fill the list ----
+    const int s = (K + kWave) / kWave;
+    const int seed_lo = max(0, b - s), seed_hi = min(nb - 1, b + s);
+    scan_box(b);
+    for (int o = 1; o <= s; o++) {
+        if (b + o <= seed_hi) scan_box(b + o);
+        if (b - o >= seed_lo) scan_box(b - o);
+    }
+
+    // ---- sweep: 64 box tests per step, nearest chunks (in Morton order) first ----
+    const int nchunks = (nb + kWave - 1) / kWave;
+    const int cb = b / kWave;
+    for (int t = 0; t <= 2 * nchunks; t++) {
+        const int chunk = cb + ((t + 1) >> 1) * ((t & 1) ? 1 : -1);
+        if (chunk < 0 || chunk >= nchunks) continue;
+        const int c = chunk * kWave + lane;
+        float lb = kFltMax;
+        if (c < nb && (c < seed_lo || c > seed_hi)) {
+            const float4 cmin = box_min[c], cmax = box_max[c];
+            const float gx = gap(wmin.x, wmax.x, cmin.x, cmax.x), gy = gap(wmin.y, wmax.y, cmin.y, cmax.y),
+                        gz = gap(wmin.z, wmax.z, cmin.z, cmax.z);
+            lb = (gx * gx + gy * gy) + gz * gz;
+        }
+        float reject = wave_max(live ? best.wd : -1.f);
+        unsigned long long todo = __ballot(lb <= reject && c < nb && (c < seed_lo || c > seed_hi));
+        while (todo) {
+            const int bit = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float lb_bit = __shfl(lb, bit);
+            if (lb_bit > reject) continue;      // the bound shrank since the ballot
+            scan_box(chunk * kWave + bit);
+            reject = wave_max(live ? best.wd : -1.f);
+        }
+    }
+
+    if (!live) return;
+    // ---- output: selection sort of the column, ascending by (distance, index) ----
+    float out_d[3] = {kFltMax, kFltMax, kFltMax};
+    float last_d = -1.f;
+    int last_id = -1;
+    for (int r = 0; r < K; r++) {
+        float bd = kFltMax;
+        int bid = 0x7fffffff;
+        for (int j = 0; j < K; j++) {
+            const float v = best.d[j * kWave];
+            const int vi = best.id[j * kWave];
+            const bool after_last = v > last_d || (v == last_d && vi > last_id);
+            if (after_last && (v < bd || (v == bd && vi < bid))) {
+                bd = v;
+                bid = vi;
+            }
+        }
+        last_d = bd;
+        last_id = bid;
+        if (MEAN3) {
+            if (r < 3) out_d[r] = bd;
+        } else {
+            dists[(size_t)my_id * K + r] = bd;
+            indices[(size_t)my_id * K + r] = bid == 0x7fffffff ? -1 : bid;
+        }
+    }
+    if (MEAN3) mean3[my_id] = ((out_d[0] + out_d[1]) + out_d[2]) / 3.0f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3dgs_knn_max_k(void) { return kMaxK; }
+
+size_t r3dgs_knn_workspace_bytes(int P)
+{
+    size_t out = 0;
+    r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        const size_t temp = sort_temp_bytes((size_t)P);
+        KnnWork w = KnnWork::carve(nullptr, (size_t)P, temp);
+        out = (size_t)reinterpret_cast<uintptr_t>(w.temp) + temp + 256;
+        return 0;
+    });
+    return out;
+}
+
+int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, float* mean_dist3, char* workspace,
+              void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        if (mean_dist3) K = 3;
+        if (K < 1 || K > kMaxK) throw r3::Error("K must be in [1, " + std::to_string(kMaxK) + "]");
+        if (!points || !workspace || (!mean_dist3 && (!dists || !indices)))
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        size_t temp = sort_temp_bytes((size_t)P);
+        KnnWork w = KnnWork::carve(workspace, (size_t)P, temp);
+        const int nb = (P + kWave - 1) / kWave;
+        const int g256 = (P + 255) / 256;
+        bbox_init_kernel<<<1, 64, 0, s>>>(w.bbox);
+        bbox_kernel<<<g256 < 1024 ? g256 : 1024, 256, 0, s>>>(P, points, w.bbox);
+        morton_kernel<<<g256, 256, 0, s>>>(P, points, w.bbox, w.code, w.index);
+        R3_HIP(rocprim::radix_sort_pairs(w.temp, temp, w.code, w.code_sorted, w.index, w.index_sorted, (size_t)P, 0, 30,
+                                         s));
+        gather_boxes_kernel<<<g256, 256, 0, s>>>(P, points, w.index_sorted, w.sorted, w.box_min, w.box_max);
+        const size_t lds = kWave * sizeof(float4) + (size_t)K * kWave * 8;
+        if (mean_dist3)
+            knn_kernel<true><<<nb, kWave, lds, s>>>(P, K, w.sorted, w.box_min, w.box_max, nullptr, nullptr, mean_dist3);
+        else
+            knn_kernel<false><<<nb, kWave, lds, s>>>(P, K, w.sorted, w.box_min, w.box_max, dists, indices, nullptr);
+        r3::check_launch("knn", s, false);
+        return 0;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,400 @@
+// reduction_ops.hip -- the redundancy-score and codebook operators around the rasterizer,
+// declared in include/r3dgs_reduction.h.  What the reference does (/root/reference/submodules/
+// diff-gaussian-rasterization): reduced_3dgs.cu:205-340 on the host, reduced_3dgs/redundancy_score.cu and
+// reduced_3dgs/kmeans.cu on the device.  How it is issued here:
+//   * pixel size: ONE launch, the camera loop runs inside the kernel with the matrices and image sizes read
+//     through wave-uniform loads (the reference launches per camera and does two .item() host syncs per camera);
+//   * intersection / scatter-min: one lane per (Gaussian, neighbour) PAIR, so the index rows and the mask bytes
+//     are read/written fully coalesced; the per-Gaussian count is a ballot+popcount per wave segment;
+//   * k-means: assignment and accumulation fused in one pass over the values, per-block partials (no same-address
+//     global atomics), the convergence flag lives on the device so the whole loop is enqueued without a host sync.
+// Compiled with -ffp-contract=off and correctly rounded divide/sqrt (build.py EXACT): operation order follows
+// the scalar reference (GLM evaluation order for the matrix products).
+#include "../../include/r3dgs_reduction.h"
+
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// GLM mat4 * vec4 on the raw floats: (col0*x + col1*y) + (col2*z + col3*w); m[4c+r].
+struct V4 {
+    float x, y, z, w;
+};
+__device__ inline V4 mat4_mul(const float* __restrict__ m, float x, float y, float z, float w)
+{
+    V4 r;
+    r.x = (m[0] * x + m[4] * y) + (m[8] * z + m[12] * w);
+    r.y = (m[1] * x + m[5] * y) + (m[9] * z + m[13] * w);
+    r.z = (m[2] * x + m[6] * y) + (m[10] * z + m[14] * w);
+    r.w = (m[3] * x + m[7] * y) + (m[11] * z + m[15] * w);
+    return r;
+}
+
+// redundancy_score.cu:46-97, all cameras in one pass.
+__global__ __launch_bounds__(kBlock) void min_pixel_size_kernel(int P, int C, const float* __restrict__ w2ndc,
+                                                                const float* __restrict__ w2ndc_inv,
+                                                                const float* __restrict__ means3D,
+                                                                const int* __restrict__ image_height,
+                                                                const int* __restrict__ image_width,
+                                                                float* __restrict__ pixel_sizes)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    float best = 10000.f;
+    for (int c = 0; c < C; c++) {
+        const float* m = w2ndc + 16 * c;        // wave-uniform addresses -> scalar loads
+        const float* mi = w2ndc_inv + 16 * c;
+        const V4 hom = mat4_mul(m, px, py, pz, 1.f);
+        float pw = 1.0f / (hom.w + 0.0000001f);
+        const float nx = hom.x * pw, ny = hom.y * pw, depth = hom.z * pw;
+        const bool inside = nx <= 1.f && ny <= 1.f && depth <= 1.f && nx >= -1.f && ny >= -1.f && depth >= 0.f;
+        if (!inside) continue;
+        const int W = image_width[c], H = image_height[c];
+        float ex = 0.f, ey = 0.f;
+        if (W > H)
+            ex = 2.f / (float)W;
+        else
+            ey = 2.f / (float)H;
+        const V4 e = mat4_mul(mi, ex, ey, depth, 1.f);
+        pw = 1.f / (e.w + 0.0000001f);
+        const float e0 = e.x * pw, e1 = e.y * pw, e2 = e.z * pw;
+        const V4 s = mat4_mul(mi, 0.f, 0.f, depth, 1.f);
+        pw = 1.f / (s.w + 0.0000001f);
+        const float d0 = e0 - s.x * pw, d1 = e1 - s.y * pw, d2 = e2 - s.z * pw;
+        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        best = fminf(best, len);  // CUDA min(float,float): a NaN operand yields the other one
+    }
+    pixel_sizes[idx] = best;
+}
+
+// redundancy_score.cu:121-159 with the rotation of :185-207 rebuilt in registers (the reference materialises a
+// [P,3,3] tensor first).  One lane per pair; pairs of a Gaussian are contiguous, so a wave holds whole runs.
+__global__ __launch_bounds__(kBlock) void intersection_kernel(int P, int knn, const float* __restrict__ means3D,
+                                                              const float* __restrict__ scales,
+                                                              const float* __restrict__ rotations,
+                                                              const int* __restrict__ neighbours,
+                                                              const float* __restrict__ sphere_radius,
+                                                              int* __restrict__ redundancy,
+                                                              uint8_t* __restrict__ mask)
+{
+    const long long total = (long long)P * knn;
+    const long long pair = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = pair < total;
+    bool hit = false;
+    int g = 0;
+    if (live) {
+        g = (int)(pair / knn);
+        const int n = neighbours[pair];
+        const float r = rotations[4 * g], x = rotations[4 * g + 1], y = rotations[4 * g + 2], z = rotations[4 * g + 3];
+        const float d0 = means3D[3 * g] - means3D[3 * n];
+        const float d1 = means3D[3 * g + 1] - means3D[3 * n + 1];
+        const float d2 = means3D[3 * g + 2] - means3D[3 * n + 2];
+        const float rad = sphere_radius[g];
+        const float a0 = scales[3 * n] + rad, a1 = scales[3 * n + 1] + rad, a2 = scales[3 * n + 2] + rad;
+        // vec3 * mat3 = (dot(col0, v), dot(col1, v), dot(col2, v)), dot = (x*x' + y*y') + z*z'
+        const float l0 = ((1.f - 2.f * (y * y + z * z)) * d0 + (2.f * (x * y + r * z)) * d1) + (2.f * (x * z - r * y)) * d2;
+        const float l1 = ((2.f * (x * y - r * z)) * d0 + (1.f - 2.f * (x * x + z * z)) * d1) + (2.f * (y * z + r * x)) * d2;
+        const float l2 = ((2.f * (x * z + r * y)) * d0 + (2.f * (y * z - r * x)) * d1) + (1.f - 2.f * (x * x + y * y)) * d2;
+        const float v = ((l0 * l0) * (1.f / (a0 * a0)) + (l1 * l1) * (1.f / (a1 * a1))) + (l2 * l2) * (1.f / (a2 * a2));
+        hit = v < 1.f;
+        mask[pair] = hit ? 1 : 0;
+    }
+    // count per Gaussian: lanes of one Gaussian form a contiguous segment of the wave
+    const unsigned long long hits = __ballot(hit);
+    if (live) {
+        const long long wave_base = pair - (threadIdx.x & 63);
+        const long long seg_lo = (long long)g * knn - wave_base, seg_hi = seg_lo + knn;
+        const int lo = seg_lo < 0 ? 0 : (int)seg_lo, hi = seg_hi > 64 ? 64 : (int)seg_hi;
+        if ((int)(threadIdx.x & 63) == lo) {
+            const unsigned long long seg = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            const int c = __popcll(hits & seg);
+            if (lo == (int)seg_lo && hi == (int)seg_hi)
+                redundancy[g] = c;            // the whole run is in this wave: plain store, no zero-fill needed
+            else if (c)
+                atomicAdd(&redundancy[g], c);  // run cut by a wave boundary (redundancy zeroed by the launcher)
+        }
+    }
+}
+
+// runs cut by a wave boundary accumulate with atomics, so those entries must start at zero
+__global__ __launch_bounds__(kBlock) void zero_cut_runs_kernel(int P, int knn, int* __restrict__ redundancy)
+{
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= P) return;
+    const long long a = (long long)g * knn, b = a + knn - 1;
+    if ((a >> 6) != (b >> 6)) redundancy[g] = 0;
+}
+
+// redundancy_score.cu:6-27, one lane per pair.
+__global__ __launch_bounds__(kBlock) void fill_int_kernel(int n, int v, int* __restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void min_redundancy_kernel(long long total, int knn,
+                                                                const int* __restrict__ redundancy,
+                                                                const int* __restrict__ neighbours,
+                                                                const uint8_t* __restrict__ mask,
+                                                                int* __restrict__ min_redundancy)
+{
+    const long long pair = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (pair >= total || !mask[pair]) return;
+    atomicMin(&min_redundancy[neighbours[pair]], redundancy[pair / knn]);
+}
+
+// ---- 1-D k-means (reduced_3dgs/kmeans.cu) --------------------------------------------------------------------
+constexpr int kMaxCenters = 1024;
+constexpr int kKmBlocks = 1024;     // fixed grid: per-block partials [kKmBlocks][n_centers]
+constexpr int kKmPerThread = 4;
+
+struct KmeansWork {
+    float* centers;   // [n_centers] current centres
+    float* psum;      // [kKmBlocks][n_centers]
+    int* pcnt;        // [kKmBlocks][n_centers]
+    int* done;        // convergence flag
+    int* iters;       // updates run
+    static KmeansWork carve(char* base, int n_centers)
+    {
+        KmeansWork w;
+        char* p = base;
+        auto take = [&](size_t bytes) {
+            char* r = p;
+            p += (bytes + 255) / 256 * 256;
+            return r;
+        };
+        w.centers = reinterpret_cast<float*>(take(sizeof(float) * n_centers));
+        w.psum = reinterpret_cast<float*>(take(sizeof(float) * (size_t)kKmBlocks * n_centers));
+        w.pcnt = reinterpret_cast<int*>(take(sizeof(int) * (size_t)kKmBlocks * n_centers));
+        w.done = reinterpret_cast<int*>(take(256));
+        w.iters = w.done + 1;
+        return w;
+    }
+    static size_t bytes(int n_centers)
+    {
+        KmeansWork w = carve(nullptr, n_centers);
+        return (size_t)reinterpret_cast<uintptr_t>(w.done) + 256 + 256;
+    }
+};
+
+// updateIdsCUDA (kmeans.cu:73-105): first centre with strictly smaller sqrt((c-v)^2).  sqrt is monotone, so a
+// centre whose squared distance is not below the incumbent's cannot win; the sqrt is only formed otherwise.
+struct Nearest {
+    float d2, d;
+    int id;
+};
+__device__ inline void nearest_step(Nearest& b, float v, float c, int i)
+{
+    const float diff = c - v;
+    const float d2 = diff * diff;
+    if (d2 < b.d2) {
+        const float d = sqrtf(d2);
+        if (d < b.d) {
+            b.d = d;
+            b.d2 = d2;
+            b.id = i;
+        }
+    }
+}
+
+// ACCUMULATE: also the per-block sums of updateCentersCUDA (kmeans.cu:12-53); ids may be NULL then.
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock) void kmeans_assign_kernel(int n, int n_centers, const float* __restrict__ values,
+                                                               const float* __restrict__ centers,
+                                                               int* __restrict__ ids, float* __restrict__ psum,
+                                                               int* __restrict__ pcnt, const int* __restrict__ done)
+{
+    if (ACCUMULATE && *done) return;
+    __shared__ float s_c[kMaxCenters];
+    __shared__ float s_sum[ACCUMULATE ? kMaxCenters : 1];
+    __shared__ int s_cnt[ACCUMULATE ? kMaxCenters : 1];
+    for (int i = threadIdx.x; i < n_centers; i += kBlock) {
+        s_c[i] = centers[i];
+        if (ACCUMULATE) {
+            s_sum[i] = 0.f;
+            s_cnt[i] = 0;
+        }
+    }
+    __syncthreads();
+    const int stride = gridDim.x * kBlock * kKmPerThread;
+    for (int base = blockIdx.x * kBlock * kKmPerThread; base < n; base += stride) {
+        float v[kKmPerThread];
+        Nearest b[kKmPerThread];
+#pragma unroll
+        for (int k = 0; k < kKmPerThread; k++) {
+            const int i = base + k * kBlock + threadIdx.x;
+            v[k] = i < n ? values[i] : 0.f;
+            b[k] = {INFINITY, INFINITY, 0};
+        }
+        for (int c = 0; c < n_centers; c++) {
+            const float cv = s_c[c];
+#pragma unroll
+            for (int k = 0; k < kKmPerThread; k++) nearest_step(b[k], v[k], cv, c);
+        }
+#pragma unroll
+        for (int k = 0; k < kKmPerThread; k++) {
+            const int i = base + k * kBlock + threadIdx.x;
+            if (i < n) {
+                if (ids) ids[i] = b[k].id;
+                if (ACCUMULATE) {
+                    atomicAdd(&s_sum[b[k].id], v[k]);
+                    atomicAdd(&s_cnt[b[k].id], 1);
+                }
+            }
+        }
+    }
+    if (ACCUMULATE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_centers; i += kBlock) {
+            psum[(size_t)blockIdx.x * n_centers + i] = s_sum[i];
+            pcnt[(size_t)blockIdx.x * n_centers + i] = s_cnt[i];
+        }
+    }
+}
+
+// reduced_3dgs.cu:318-324: centre = sum / size, NaN (empty cluster) -> 0, shift = sum |old - new|, stop below tol.
+__global__ __launch_bounds__(kMaxCenters) void kmeans_update_kernel(int n_centers, int n_blocks,
+                                                                    const float* __restrict__ psum,
+                                                                    const int* __restrict__ pcnt,
+                                                                    float* __restrict__ centers, float tol,
+                                                                    int* __restrict__ done, int* __restrict__ iters)
+{
+    if (*done) return;
+    __shared__ float s_shift[kMaxCenters / 64];
+    const int c = threadIdx.x;
+    float shift = 0.f;
+    if (c < n_centers) {
+        float s = 0.f;
+        int cnt = 0;
+        for (int b = 0; b < n_blocks; b++) {
+            s += psum[(size_t)b * n_centers + c];
+            cnt += pcnt[(size_t)b * n_centers + c];
+        }
+        float nc = s / (float)cnt;
+        if (nc != nc) nc = 0.f;
+        shift = fabsf(centers[c] - nc);
+        centers[c] = nc;
+    }
+    for (int off = 32; off; off >>= 1) shift += __shfl_down(shift, off);
+    if ((threadIdx.x & 63) == 0) s_shift[threadIdx.x >> 6] = shift;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x + 63) / 64; w++) t += s_shift[w];
+        *iters += 1;
+        if (t < tol) *done = 1;
+    }
+}
+
+__global__ void kmeans_finish_kernel(int n_centers, const float* __restrict__ centers, float* __restrict__ out,
+                                     const int* __restrict__ iters, int* __restrict__ iters_out)
+{
+    for (int i = threadIdx.x; i < n_centers; i += blockDim.x) out[i] = centers[i];
+    if (threadIdx.x == 0 && iters_out) *iters_out = *iters;
+}
+
+int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+int r3dgs_min_pixel_size(int P, int n_cameras, const float* w2ndc, const float* w2ndc_inv, const float* means3D,
+                         const int* image_height, const int* image_width, float* pixel_sizes, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        if (n_cameras < 0) throw r3::Error("n_cameras must be >= 0");
+        if (!means3D || !pixel_sizes || (n_cameras && (!w2ndc || !w2ndc_inv || !image_height || !image_width)))
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        min_pixel_size_kernel<<<grid_for(P), kBlock, 0, s>>>(P, n_cameras, w2ndc, w2ndc_inv, means3D, image_height,
+                                                             image_width, pixel_sizes);
+        r3::check_launch("min pixel size", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_sphere_ellipsoid_intersection(int P, int knn, const float* means3D, const float* scales,
+                                        const float* rotations, const int* neighbours, const float* sphere_radius,
+                                        int* redundancy, uint8_t* mask, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        if (knn < 0) throw r3::Error("knn must be >= 0");
+        if (!redundancy) throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (knn == 0) {
+            fill_int_kernel<<<grid_for(P), kBlock, 0, s>>>(P, 0, redundancy);
+            r3::check_launch("intersection (no neighbours)", s, false);
+            return 0;
+        }
+        if (!means3D || !scales || !rotations || !neighbours || !sphere_radius || !mask)
+            throw r3::Error("a required pointer is NULL");
+        zero_cut_runs_kernel<<<grid_for(P), kBlock, 0, s>>>(P, knn, redundancy);
+        intersection_kernel<<<grid_for((long long)P * knn), kBlock, 0, s>>>(P, knn, means3D, scales, rotations,
+                                                                              neighbours, sphere_radius, redundancy,
+                                                                              mask);
+        r3::check_launch("sphere/ellipsoid intersection", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_min_redundancy(int P, int knn, const int* redundancy, const int* neighbours, const uint8_t* mask,
+                         int* min_redundancy, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        if (knn < 0) throw r3::Error("knn must be >= 0");
+        if (!min_redundancy || (knn && (!redundancy || !neighbours || !mask)))
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        fill_int_kernel<<<grid_for(P), kBlock, 0, s>>>(P, P, min_redundancy);
+        if (knn)
+            min_redundancy_kernel<<<grid_for((long long)P * knn), kBlock, 0, s>>>((long long)P * knn, knn, redundancy,
+                                                                                    neighbours, mask, min_redundancy);
+        r3::check_launch("min redundancy", s, false);
+        return 0;
+    });
+}
+
+size_t r3dgs_kmeans_workspace_bytes(int n_centers)
+{
+    if (n_centers < 1 || n_centers > kMaxCenters) return 0;
+    return KmeansWork::bytes(n_centers);
+}
+
+int r3dgs_kmeans(int n_values, int n_centers, const float* values, const float* centers_in, float tol,
+                 int max_iterations, int* ids, float* centers_out, int* iterations_run, char* workspace, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (n_centers < 1 || n_centers > kMaxCenters) throw r3::Error("n_centers must be in [1,1024]");
+        if (n_values < 0 || max_iterations < 0) throw r3::Error("negative size");
+        if (!centers_in || !centers_out || !workspace || (n_values && (!values || !ids)))
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        KmeansWork w = KmeansWork::carve(workspace, n_centers);
+        R3_HIP(hipMemcpyAsync(w.centers, centers_in, sizeof(float) * n_centers, hipMemcpyDeviceToDevice, s));
+        R3_HIP(hipMemsetAsync(w.done, 0, 256, s));
+        const long long per_block = (long long)kBlock * kKmPerThread;
+        int blocks = (int)((n_values + per_block - 1) / per_block);
+        blocks = blocks < 1 ? 1 : (blocks > kKmBlocks ? kKmBlocks : blocks);
+        const int upd_threads = (n_centers + 63) / 64 * 64;
+        for (int it = 0; it < max_iterations; it++) {
+            kmeans_assign_kernel<true><<<blocks, kBlock, 0, s>>>(n_values, n_centers, values, w.centers, nullptr,
+                                                                 w.psum, w.pcnt, w.done);
+            kmeans_update_kernel<<<1, upd_threads, 0, s>>>(n_centers, blocks, w.psum, w.pcnt, w.centers, tol, w.done,
+                                                           w.iters);
+        }
+        if (n_values)
+            kmeans_assign_kernel<false><<<blocks, kBlock, 0, s>>>(n_values, n_centers, values, w.centers, ids, nullptr,
+                                                                  nullptr, nullptr);
+        kmeans_finish_kernel<<<1, 256, 0, s>>>(n_centers, w.centers, centers_out, w.iters, iterations_run);
+        r3::check_launch("kmeans", s, false);
+        return 0;
+    });
+}
+
+}  // extern "C"

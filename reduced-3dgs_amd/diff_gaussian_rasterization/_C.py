@@ -45,6 +45,16 @@ _lib.r3dgs_export_binning.argtypes = [_i, _i, _i, _i] + [_vp] * 10
 
 _lib.r3dgs_colour_variance_accumulate.restype = _i
 _lib.r3dgs_colour_variance_accumulate.argtypes = [_i, _vp, _i, _i] + [_vp] * 12
+_lib.r3dgs_min_pixel_size.restype = _i
+_lib.r3dgs_min_pixel_size.argtypes = [_i, _i] + [_vp] * 7
+_lib.r3dgs_sphere_ellipsoid_intersection.restype = _i
+_lib.r3dgs_sphere_ellipsoid_intersection.argtypes = [_i, _i] + [_vp] * 8
+_lib.r3dgs_min_redundancy.restype = _i
+_lib.r3dgs_min_redundancy.argtypes = [_i, _i] + [_vp] * 5
+_lib.r3dgs_kmeans_workspace_bytes.restype = C.c_size_t
+_lib.r3dgs_kmeans_workspace_bytes.argtypes = [_i]
+_lib.r3dgs_kmeans.restype = _i
+_lib.r3dgs_kmeans.argtypes = [_i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.r3dgs_profile_enable.argtypes = [_i]
 _lib.r3dgs_profile_stage_name.restype = C.c_char_p
 _lib.r3dgs_profile_stage_name.argtypes = [_i]
@@ -261,14 +271,6 @@ def rasterize_gaussians_counters(*args):
     return out + (touched, transm)
 
 
-def _next_tier(name, where):
-    def fn(*_a, **_k):
-        raise NotImplementedError(f"_C.{name} ({where}) is outside the rasterizer hot path and not built yet "
-                                  "(SURVEY.md 8f 'next' rows)")
-    fn.__name__ = name
-    return fn
-
-
 def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotations, cam_viewmatrices, cam_projmatrices,
                                tan_fovxs, tan_fovys, image_height, image_width, sh, degrees, max_sh_deg):
     """Reduced3DGS::calculateColourVariance (reduced_3dgs.cu:41-203) ->
@@ -308,9 +310,89 @@ def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotation
     return accum / wSum, variance / wSum.view(-1, 1, 1), mean
 
 
-# exported so that `from diff_gaussian_rasterization._C import ...` in scene/__init__.py:20,
-# scene/gaussian_model.py:23 and generate_results.py:10 resolves; they raise when called.
-sphere_ellipsoid_intersection = _next_tier("sphere_ellipsoid_intersection", "reduced_3dgs.cu:205-237")
-allocate_minimum_redundancy_value = _next_tier("allocate_minimum_redundancy_value", "reduced_3dgs.cu:267-285")
-find_minimum_projected_pixel_size = _next_tier("find_minimum_projected_pixel_size", "reduced_3dgs.cu:239-263")
-kmeans_cuda = _next_tier("kmeans_cuda", "reduced_3dgs.cu:288-339")
+def _dev_u8(t, dev):
+    if t.device != dev:
+        raise RuntimeError("all tensors must live on the same GPU")
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8) if t.is_contiguous() else t.contiguous().view(torch.uint8)
+    if t.dtype != torch.uint8:
+        raise RuntimeError("expected a bool tensor")
+    return t.contiguous()
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensors must be on a GPU (no CPU path)")
+    return t.device
+
+
+def find_minimum_projected_pixel_size(w2ndc_transforms, w2ndc_transforms_inverse, means3D, image_height, image_width):
+    """Reduced3DGS::calculatePixelSize (reduced_3dgs.cu:240-264) -> pixel_values[P,1] (10000 where unseen).
+    One launch for all cameras; the image sizes stay on the device."""
+    dev = _need_gpu(means3D, "find_minimum_projected_pixel_size")
+    P = int(means3D.size(0))
+    out = torch.empty((P, 1), dtype=torch.float32, device=dev)
+    if P:
+        m, mi = _dev_f32(w2ndc_transforms, dev), _dev_f32(w2ndc_transforms_inverse, dev)
+        Hs, Ws = _dev_i32(image_height, dev), _dev_i32(image_width, dev)
+        with torch.cuda.device(dev):
+            _check(_lib.r3dgs_min_pixel_size(P, int(w2ndc_transforms.size(0)), _ptr(m), _ptr(mi), _ptr(_dev_f32(means3D, dev)),
+                                             _ptr(Hs), _ptr(Ws), _ptr(out), _stream()),
+                   "find_minimum_projected_pixel_size")
+    return out
+
+
+def sphere_ellipsoid_intersection(means3D, scales, rotations, neighbours_indices, sphere_radius, knn):
+    """Reduced3DGS::intersectionTest (reduced_3dgs.cu:205-238) -> (redundancy_values int32[P,1],
+    intersection_mask bool[P,knn])."""
+    dev = _need_gpu(means3D, "sphere_ellipsoid_intersection")
+    P, knn = int(means3D.size(0)), int(knn)
+    red = torch.empty((P, 1), dtype=torch.int32, device=dev)
+    mask = torch.empty((P, knn), dtype=torch.bool, device=dev)
+    if P:
+        nbr = _dev_i32(neighbours_indices, dev)
+        if nbr.numel() != P * knn:
+            raise RuntimeError("neighbours_indices must hold P * knn entries")
+        with torch.cuda.device(dev):
+            _check(_lib.r3dgs_sphere_ellipsoid_intersection(
+                P, knn, _ptr(_dev_f32(means3D, dev)), _ptr(_dev_f32(scales, dev)), _ptr(_dev_f32(rotations, dev)),
+                _ptr(nbr), _ptr(_dev_f32(sphere_radius, dev)), _ptr(red), mask.data_ptr() if knn else None,
+                _stream()), "sphere_ellipsoid_intersection")
+    return red, mask
+
+
+def allocate_minimum_redundancy_value(redundancy_values, neighbours_indices, intersection_mask, knn):
+    """Reduced3DGS::assignFinalRedundancyValue (reduced_3dgs.cu:268-287) -> (minimum_redundancy_values int32[P,1],)."""
+    dev = _need_gpu(redundancy_values, "allocate_minimum_redundancy_value")
+    P, knn = int(redundancy_values.size(0)), int(knn)
+    out = torch.empty((P, 1), dtype=torch.int32, device=dev)
+    if P:
+        nbr, msk = _dev_i32(neighbours_indices, dev), _dev_u8(intersection_mask, dev)
+        if nbr.numel() != P * knn or msk.numel() != P * knn:
+            raise RuntimeError("neighbours_indices / intersection_mask must hold P * knn entries")
+        with torch.cuda.device(dev):
+            _check(_lib.r3dgs_min_redundancy(P, knn, _ptr(_dev_i32(redundancy_values, dev)), _ptr(nbr), _ptr(msk),
+                                             _ptr(out), _stream()), "allocate_minimum_redundancy_value")
+    return (out,)
+
+
+def kmeans_cuda(values, centers, tol, max_iterations, _want_iterations=False):
+    """Reduced3DGS::kmeans (reduced_3dgs.cu:290-340) -> (ids int32[n,1], centers fp32[n_centers]).  The whole Lloyd
+    loop is enqueued at once with the convergence flag on the device (the reference reads the shift back every
+    iteration)."""
+    dev = _need_gpu(values, "kmeans_cuda")
+    n, nc = int(values.size(0)), int(centers.size(0))
+    ids = torch.zeros((n, 1), dtype=torch.int32, device=dev)
+    new_centers = torch.empty((nc,), dtype=torch.float32, device=dev)
+    iters = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = _lib.r3dgs_kmeans_workspace_bytes(nc)
+    if ws_bytes == 0:
+        raise RuntimeError("kmeans_cuda: the number of centers must be in [1, 1024]")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(_lib.r3dgs_kmeans(n, nc, _ptr(_dev_f32(values, dev)), _ptr(_dev_f32(centers, dev)), float(tol),
+                                 int(max_iterations), _ptr(ids), _ptr(new_centers), _ptr(iters), _ptr(ws),
+                                 _stream()), "kmeans_cuda")
+    if _want_iterations:
+        return ids, new_centers, iters
+    return ids, new_centers

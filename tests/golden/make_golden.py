@@ -9,6 +9,8 @@ Fixtures are data (inputs + expected outputs); no reference source travels.
                      + the scene/cameras.py:54-58 composition                      (reference Python)
  ref_loss_grad.npz : utils/loss_utils.py:17-66 l1_loss/ssim value and d(loss)/d(image) of
                      0.8*L1 + 0.2*(1-SSIM) (train.py:109-110) -- a realistic dL_dout_color
+ ref_pixel_size.npz: scene/__init__.py:103-141 find_minimum_projected_pixel_size_python -- the reference's own torch
+                     version of the find_minimum_projected_pixel_size operator, run on CPU      (reference Python)
  oracle_case_*.npz : outputs of the repo's own CPU oracle on small seeded scenes (regression
                      anchors + GPU parity targets that do not need a compiler on the GPU box)
 """
@@ -92,8 +94,61 @@ def oracle_cases():
             final_T=st["final_T"], **{k: v for k, v in gr.items()})
 
 
+def ref_pixel_size():
+    """Runs the reference's torch restatement of its pixel-size operator (it hard-codes device="cuda" for two
+    helper tensors, so torch.ones is wrapped to drop the device argument; its CUDA-only imports are stubbed)."""
+    import types
+    for name, attrs in {"simple_knn": [], "simple_knn._C": ["distIndex2", "distCUDA2"],
+                        "plyfile": ["PlyData", "PlyElement"],
+                        "diff_gaussian_rasterization": ["GaussianRasterizationSettings", "GaussianRasterizer"],
+                        "diff_gaussian_rasterization._C": [
+                            "calculate_colours_variance", "kmeans_cuda", "sphere_ellipsoid_intersection",
+                            "allocate_minimum_redundancy_value", "find_minimum_projected_pixel_size"]}.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, None)
+            sys.modules[name] = m
+    import scene as ref_scene
+
+    cams = []
+    for i, (W, H, f) in enumerate([(400, 300, 350.0), (300, 400, 330.0), (640, 360, 500.0), (256, 256, 200.0)]):
+        cams.append(ss.make_camera(W, H, f, seed=20 + i))
+    g = ss.make_gaussians(3000, ss.make_camera(400, 300, 350.0), seed=5, behind_frac=0.05)
+    xyz = g["means3D"]
+
+    class _Cam:
+        pass
+
+    tcams = []
+    for c in cams:
+        t = _Cam()
+        t.full_proj_transform = torch.tensor(c.full_proj_transform)
+        t.image_width, t.image_height = c.image_width, c.image_height
+        tcams.append(t)
+    gauss = types.SimpleNamespace(get_opacity=torch.zeros(xyz.shape[0], 1), get_xyz=torch.tensor(xyz),
+                                  num_primitives=xyz.shape[0])
+    fake = types.SimpleNamespace(gaussians=gauss, getTrainCameras=lambda: tcams)
+    real_ones = torch.ones
+    torch.ones = lambda *a, **k: real_ones(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        sizes = ref_scene.Scene.find_minimum_projected_pixel_size_python(fake)
+    finally:
+        torch.ones = real_ones
+    np.savez_compressed(os.path.join(HERE, "ref_pixel_size.npz"), means3D=xyz,
+                        w2ndc=np.stack([c.full_proj_transform for c in cams]),
+                        w2ndc_inv=np.stack([torch.tensor(c.full_proj_transform).inverse().numpy() for c in cams]),
+                        image_height=np.array([c.image_height for c in cams], np.int32),
+                        image_width=np.array([c.image_width for c in cams], np.int32),
+                        pixel_sizes=sizes.numpy())
+
+
 if __name__ == "__main__":
+    if "--only-pixel-size" in sys.argv:
+        ref_pixel_size()
+        sys.exit(0)
     ref_sh()
+    ref_pixel_size()
     ref_camera()
     ref_loss()
     oracle_cases()

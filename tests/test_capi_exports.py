@@ -26,9 +26,11 @@ def lib():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "r3dgs_rasterizer.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(r3dgs_[a-z_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b(r3dgs_[a-z0-9_]+)\s*\(", hdr))
+    assert {"r3dgs_min_pixel_size", "r3dgs_sphere_ellipsoid_intersection", "r3dgs_min_redundancy", "r3dgs_kmeans",
+            "r3dgs_knn"} <= names
     names.discard("r3dgs_alloc_fn")
     assert {"r3dgs_forward", "r3dgs_backward", "r3dgs_inference_forward", "r3dgs_mark_visible",
             "r3dgs_export_binning", "r3dgs_last_error", "r3dgs_version"} <= names
@@ -39,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_no_torch_or_hip_types_in_the_abi():
-    hdr = open(os.path.join(ROOT, "include", "r3dgs_rasterizer.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     assert "torch" not in code and "at::" not in code and "hipStream_t" not in code and "#include <hip" not in code
 
@@ -74,6 +76,14 @@ def test_python_surface_mirrors_the_reference(lib):
     for name in ("calculate_colours_variance", "sphere_ellipsoid_intersection",
                  "allocate_minimum_redundancy_value", "find_minimum_projected_pixel_size", "kmeans_cuda"):
         assert callable(getattr(_C, name))  # importable (scene/__init__.py:20, scene/gaussian_model.py:23)
+    red = {"sphere_ellipsoid_intersection": 6, "allocate_minimum_redundancy_value": 4,
+           "find_minimum_projected_pixel_size": 5, "kmeans_cuda": 4, "calculate_colours_variance": 14}
+    for name, n in red.items():        # positional signatures of reduced_3dgs.h:19-60
+        params = [p for p in inspect.signature(getattr(_C, name)).parameters.values() if not p.name.startswith("_")]
+        assert len(params) == n, name
+    from simple_knn import _C as knn   # submodules/simple-knn/ext.cpp:15-19
+    assert [len(inspect.signature(getattr(knn, f)).parameters) for f in ("distCUDA2", "distIndex2", "distIndexQ")] \
+        == [1, 2, 4]
     import torch
     rast = dgr.GaussianRasterizer(None)
     with pytest.raises(Exception, match="SHs or precomputed colors"):

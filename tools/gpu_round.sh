@@ -12,9 +12,14 @@ if [ "${SMOKE:-1}" = "1" ]; then
   ( timeout ${T_SMOKE:-300} python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> $S
 fi
 if [ "${TESTS:-1}" = "1" ]; then
-  ( timeout ${T_TEST:-420} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $S
+  ( timeout ${T_TEST:-420} python -m pytest ${PYTEST_TARGET:-tests} -m gpu -x -q ${PYTEST_ARGS:-} ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $S
 fi
-( timeout ${T_BENCH:-240} python bench.py --steps ${STEPS:-20} --warmup 5 ) > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> $S
+if [ "${BENCH:-1}" = "1" ]; then
+  ( timeout ${T_BENCH:-240} python bench.py --steps ${STEPS:-20} --warmup 5 ) > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> $S
+fi
+if [ -n "${EXTRA:-}" ]; then   # one extra in-repo python script (e.g. tools/reduction_bench.py)
+  ( timeout ${T_EXTRA:-240} python $EXTRA ) > gpurun_out/extra.log 2>&1; echo "extra rc=$?" >> $S
+fi
 # tuning sweeps: "NAME=VALUE NAME=VALUE;NAME=VALUE" -> one short bench per ';'-separated env set
 if [ -n "${SWEEP:-}" ]; then
   IFS=';' read -ra SETS <<< "$SWEEP"
@@ -36,6 +41,6 @@ if [ -n "${PMC:-}" ]; then   # separate counter passes, kernel-trace only (never
     i=$((i+1))
   done
 fi
-cat $S; echo ---; tail -5 gpurun_out/smoke.log 2>/dev/null; echo ---; tail -30 gpurun_out/pytest_gpu.log 2>/dev/null; echo ---; tail -1 gpurun_out/bench.log
+cat $S; echo ---; tail -5 gpurun_out/smoke.log 2>/dev/null; echo ---; tail -30 gpurun_out/pytest_gpu.log 2>/dev/null; echo ---; tail -1 gpurun_out/bench.log 2>/dev/null; echo ---; tail -${EXTRA_TAIL:-30} gpurun_out/extra.log 2>/dev/null
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" 2>/dev/null | head -1); if [ -n "$f" ]; then echo "--- $f"; head -22 "$f" | cut -c1-200; fi
 exit 0
