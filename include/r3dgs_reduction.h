@@ -42,11 +42,13 @@ int r3dgs_min_redundancy(int P, int knn, const int* redundancy, const int* neigh
 
 /* 1-D k-means (Lloyd) with n_centers <= 1024 centres (the reference supports exactly 256): repeat
  * {assign each value to the first nearest centre; centre = mean of its values, 0 if empty} until the summed
- * centre shift < tol or max_iterations, then a final assignment (reduced_3dgs.cu:305-338).  The convergence test
- * stays on the device: all iterations are enqueued and become no-ops once converged.
- * workspace: r3dgs_kmeans_workspace_bytes(n_centers) bytes of device scratch.  ids[n_values],
- * centers_out[n_centers] are written; iterations_run (device int, may be NULL) receives the number of updates. */
-size_t r3dgs_kmeans_workspace_bytes(int n_centers);
+ * centre shift < tol or max_iterations, then a final assignment (reduced_3dgs.cu:305-338).  The values are sorted
+ * once; an update is one pass over the sorted values (binary search per value, prefix-sum differences per
+ * cluster).  The convergence test stays on the device: all updates are enqueued and become no-ops once converged.
+ * workspace: r3dgs_kmeans_workspace_bytes(n_values, n_centers) bytes of device scratch (0 is returned, with
+ * r3dgs_last_error set, when no GPU is present to size the sort).  ids[n_values], centers_out[n_centers] are
+ * written; iterations_run (device int, may be NULL) receives the number of updates.  Values must not be NaN. */
+size_t r3dgs_kmeans_workspace_bytes(int n_values, int n_centers);
 int r3dgs_kmeans(int n_values, int n_centers, const float* values, const float* centers_in, float tol,
                  int max_iterations, int* ids, float* centers_out, int* iterations_run, char* workspace,
                  void* stream);

@@ -30,6 +30,7 @@ UNITS = {
     "colour_variance.hip": EXACT,
     "reduction_ops.hip": EXACT,
     "knn.hip": EXACT,
+    "kmeans.hip": EXACT,
     "blend.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "capi.hip": [],
 }

@@ -8,10 +8,11 @@
 //   1. bounding box by a block reduce + ordered-int atomics, no host read-back;
 //   2. 30-bit Morton codes, rocPRIM radix sort of (code, index);
 //   3. points gathered into sorted order as float4 {x,y,z,index}; one AABB per 64 consecutive points (= one wave);
-//   4. one WAVE per 64 consecutive queries.  Each lane keeps its K-best list in an LDS column (bank = lane, so the
-//      column scans are conflict-free).  The wave first scans its own and adjacent boxes (seed), then every lane
+//   4. one WAVE per 64 consecutive queries.  Each lane keeps its K-best list as a max-heap in an LDS column (bank =
+//      lane, so the accesses are conflict-free whatever path a lane's sift takes).  The wave first scans its own and adjacent boxes (seed), then every lane
 //      tests a different box's AABB against the wave's AABB and current worst distance (64 box tests per step);
-//      surviving boxes are staged through LDS and scored by all lanes with broadcast reads.
+//      surviving boxes are staged through LDS and scored by all lanes with broadcast reads in a divergence-free
+//      pass that only records which points beat the lane's worst entry; the (rare) insertions follow per lane.
 // The result is canonical: ascending by (distance, index), ties at the K-th place resolved by the smaller index.
 // Compiled without FMA contraction so that the box lower bounds (monotone in every rounding step) can never exceed
 // a contained point's distance computed by the same expression: the search is exact in fp32.
@@ -25,6 +26,7 @@
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kSparse = 12;     // <= this many wanting queries: score a box with lanes = points instead of lanes = queries
 constexpr int kMaxK = 112;      // LDS: K * 64 lanes * 8 B + 1 KB staging <= 64 KB per wave
 constexpr float kFltMax = 3.402823466e+38f;
 
@@ -97,6 +99,7 @@ __global__ void bbox_init_kernel(int* bbox)
 
 __global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restrict__ pts, int* __restrict__ bbox)
 {
+    __shared__ float s_red[4][6];
     float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)
         for (int a = 0; a < 3; a++) {
@@ -110,9 +113,17 @@ __global__ __launch_bounds__(256) void bbox_kernel(int P, const float* __restric
     }
     if ((threadIdx.x & 63) == 0)
         for (int a = 0; a < 3; a++) {
-            atomicMin(&bbox[a], f2ord(mn[a]));
-            atomicMax(&bbox[3 + a], f2ord(mx[a]));
+            s_red[threadIdx.x >> 6][a] = mn[a];
+            s_red[threadIdx.x >> 6][3 + a] = mx[a];
         }
+    __syncthreads();
+    if (threadIdx.x < 6) {              // one atomic per block and component (same-address atomics serialise)
+        const int a = threadIdx.x;
+        float v = s_red[0][a];
+        for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, s_red[w][a]) : fmaxf(v, s_red[w][a]);
+        if (a < 3) atomicMin(&bbox[a], f2ord(v));
+        else atomicMax(&bbox[a], f2ord(v));
+    }
 }
 
 __device__ inline uint32_t spread10(uint32_t x)
@@ -172,12 +183,14 @@ __device__ inline float gap(float lo_a, float hi_a, float lo_b, float hi_b)
     return fmaxf(0.f, fmaxf(lo_b - hi_a, lo_a - hi_b));
 }
 
+// K-best list of one lane: a max-heap by (distance, index) in an LDS column (slot j at d[j * 64]); the root is the
+// current worst entry and is mirrored in registers.
 struct Best {
-    float* d;       // LDS column base of this lane: d[j * 64]
+    float* d;
     int* id;
     int K;
-    float wd;       // worst (largest by (distance, index)) entry of the list
-    int wid, wslot;
+    float wd;
+    int wid;
 
     __device__ inline void reset()
     {
@@ -187,27 +200,37 @@ struct Best {
         }
         wd = kFltMax;
         wid = 0x7fffffff;
-        wslot = 0;
     }
     __device__ inline bool better(float cd, int cid) const { return cd < wd || (cd == wd && cid < wid); }
+    static __device__ inline bool greater(float ad, int ai, float bd, int bi) { return ad > bd || (ad == bd && ai > bi); }
+    // replace the root by (cd, cid) -- the caller checked better() -- and sift it down
     __device__ inline void insert(float cd, int cid)
     {
-        d[wslot * kWave] = cd;
-        id[wslot * kWave] = cid;
-        float nd = -1.f;
-        int nid = -1, ns = 0;
-        for (int j = 0; j < K; j++) {
-            const float v = d[j * kWave];
-            const int vi = id[j * kWave];
-            if (v > nd || (v == nd && vi > nid)) {
-                nd = v;
-                nid = vi;
-                ns = j;
+        int i = 0;
+        for (;;) {
+            const int l = 2 * i + 1;
+            if (l >= K) break;
+            int c = l;
+            float dc = d[l * kWave];
+            int ic = id[l * kWave];
+            if (l + 1 < K) {
+                const float dr = d[(l + 1) * kWave];
+                const int ir = id[(l + 1) * kWave];
+                if (greater(dr, ir, dc, ic)) {
+                    c = l + 1;
+                    dc = dr;
+                    ic = ir;
+                }
             }
+            if (!greater(dc, ic, cd, cid)) break;
+            d[i * kWave] = dc;
+            id[i * kWave] = ic;
+            i = c;
         }
-        wd = nd;
-        wid = nid;
-        wslot = ns;
+        d[i * kWave] = cd;
+        id[i * kWave] = cid;
+        wd = d[0];
+        wid = id[0];
     }
 };
 
@@ -232,28 +255,63 @@ __global__ __launch_bounds__(kWave) void knn_kernel(int P, int K, const float4* 
     const int my_id = live ? (int)__float_as_uint(q.w) : -1;
     const float4 wmin = box_min[b], wmax = box_max[b];
 
-    Best best{s_d + lane, s_id + lane, K, 0.f, 0, 0};
+    Best best{s_d + lane, s_id + lane, K, 0.f, 0};
     best.reset();
 
     auto scan_box = [&](int c) {
-        // stage box c (wave-uniform c), then every lane whose own bound admits it scores its 64 points
-        const int ci = c * kWave + lane;
-        __syncthreads();
-        s_cand[lane] = ci < P ? sorted[ci] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        __syncthreads();
+        // box c is wave-uniform.  Which lanes' own bound admits it?
         const float4 cmin = box_min[c], cmax = box_max[c];
         const float gx = gap(q.x, q.x, cmin.x, cmax.x), gy = gap(q.y, q.y, cmin.y, cmax.y),
                     gz = gap(q.z, q.z, cmin.z, cmax.z);
         const float lb = (gx * gx + gy * gy) + gz * gz;
-        if (!live || lb > best.wd) return;
+        const bool need = live && lb <= best.wd;
+        unsigned long long needing = __ballot(need);
+        if (!needing) return;
+        const int ci = c * kWave + lane;
         const int n = min(kWave, P - c * kWave);
+        const float4 mine = ci < P ? sorted[ci] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        __syncthreads();
+        s_cand[lane] = mine;
+        __syncthreads();
+        auto insert_passing = [&](unsigned long long pass) {   // re-checked: the worst entry shrinks as the list fills
+            while (pass) {
+                const int j = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const float4 p = s_cand[j];
+                const int cid = (int)__float_as_uint(p.w);
+                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (best.better(d2, cid)) best.insert(d2, cid);
+            }
+        };
+        if (__popcll(needing) <= kSparse) {
+            // few queries want this box: lanes = its 64 points, one step per wanting query
+            const int cid = (int)__float_as_uint(mine.w);
+            while (needing) {
+                const int ql = __builtin_ctzll(needing);
+                needing &= needing - 1;
+                const float qx = __shfl(q.x, ql), qy = __shfl(q.y, ql), qz = __shfl(q.z, ql);
+                const float qwd = __shfl(best.wd, ql);
+                const int qwid = __shfl(best.wid, ql), qid = __shfl(my_id, ql);
+                const float dx = mine.x - qx, dy = mine.y - qy, dz = mine.z - qz;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                const unsigned long long pass =
+                    __ballot(lane < n && cid != qid && (d2 < qwd || (d2 == qwd && cid < qwid)));
+                if (lane == ql) insert_passing(pass);
+            }
+            return;
+        }
+        if (!need) return;
+        // many queries want it: lanes = queries; a divergence-free pass records which points beat the worst entry
+        unsigned long long pass = 0;
         for (int j = 0; j < n; j++) {
             const float4 p = s_cand[j];
             const int cid = (int)__float_as_uint(p.w);
             const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
             const float d2 = (dx * dx + dy * dy) + dz * dz;
-            if (cid != my_id && best.better(d2, cid)) best.insert(d2, cid);
+            if (cid != my_id && best.better(d2, cid)) pass |= 1ull << j;
         }
+        insert_passing(pass);
     };
 
     // ---- seed: own box and its Morton neighbours, enough points to fill the list ----
@@ -354,7 +412,7 @@ int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, flo
         const int nb = (P + kWave - 1) / kWave;
         const int g256 = (P + 255) / 256;
         bbox_init_kernel<<<1, 64, 0, s>>>(w.bbox);
-        bbox_kernel<<<g256 < 1024 ? g256 : 1024, 256, 0, s>>>(P, points, w.bbox);
+        bbox_kernel<<<g256 < 256 ? g256 : 256, 256, 0, s>>>(P, points, w.bbox);
         morton_kernel<<<g256, 256, 0, s>>>(P, points, w.bbox, w.code, w.index);
         R3_HIP(rocprim::radix_sort_pairs(w.temp, temp, w.code, w.code_sorted, w.index, w.index_sorted, (size_t)P, 0, 30,
                                          s));

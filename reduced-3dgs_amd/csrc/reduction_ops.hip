@@ -1,13 +1,10 @@
-// reduction_ops.hip -- the redundancy-score and codebook operators around the rasterizer,
-// declared in include/r3dgs_reduction.h.  What the reference does (/root/reference/submodules/
-// diff-gaussian-rasterization): reduced_3dgs.cu:205-340 on the host, reduced_3dgs/redundancy_score.cu and
-// reduced_3dgs/kmeans.cu on the device.  How it is issued here:
+// reduction_ops.hip -- the redundancy-score operators around the rasterizer, declared in
+// include/r3dgs_reduction.h.  What the reference does (/root/reference/submodules/diff-gaussian-rasterization):
+// reduced_3dgs.cu:205-287 on the host, reduced_3dgs/redundancy_score.cu on the device.  How it is issued here:
 //   * pixel size: ONE launch, the camera loop runs inside the kernel with the matrices and image sizes read
 //     through wave-uniform loads (the reference launches per camera and does two .item() host syncs per camera);
 //   * intersection / scatter-min: one lane per (Gaussian, neighbour) PAIR, so the index rows and the mask bytes
-//     are read/written fully coalesced; the per-Gaussian count is a ballot+popcount per wave segment;
-//   * k-means: assignment and accumulation fused in one pass over the values, per-block partials (no same-address
-//     global atomics), the convergence flag lives on the device so the whole loop is enqueued without a host sync.
+//     are read/written fully coalesced; the per-Gaussian count is a ballot+popcount per wave segment.
 // Compiled with -ffp-contract=off and correctly rounded divide/sqrt (build.py EXACT): operation order follows
 // the scalar reference (GLM evaluation order for the matrix products).
 #include "../../include/r3dgs_reduction.h"
@@ -145,156 +142,6 @@ __global__ __launch_bounds__(kBlock) void min_redundancy_kernel(long long total,
     atomicMin(&min_redundancy[neighbours[pair]], redundancy[pair / knn]);
 }
 
-// ---- 1-D k-means (reduced_3dgs/kmeans.cu) --------------------------------------------------------------------
-constexpr int kMaxCenters = 1024;
-constexpr int kKmBlocks = 1024;     // fixed grid: per-block partials [kKmBlocks][n_centers]
-constexpr int kKmPerThread = 4;
-
-struct KmeansWork {
-    float* centers;   // [n_centers] current centres
-    float* psum;      // [kKmBlocks][n_centers]
-    int* pcnt;        // [kKmBlocks][n_centers]
-    int* done;        // convergence flag
-    int* iters;       // updates run
-    static KmeansWork carve(char* base, int n_centers)
-    {
-        KmeansWork w;
-        char* p = base;
-        auto take = [&](size_t bytes) {
-            char* r = p;
-            p += (bytes + 255) / 256 * 256;
-            return r;
-        };
-        w.centers = reinterpret_cast<float*>(take(sizeof(float) * n_centers));
-        w.psum = reinterpret_cast<float*>(take(sizeof(float) * (size_t)kKmBlocks * n_centers));
-        w.pcnt = reinterpret_cast<int*>(take(sizeof(int) * (size_t)kKmBlocks * n_centers));
-        w.done = reinterpret_cast<int*>(take(256));
-        w.iters = w.done + 1;
-        return w;
-    }
-    static size_t bytes(int n_centers)
-    {
-        KmeansWork w = carve(nullptr, n_centers);
-        return (size_t)reinterpret_cast<uintptr_t>(w.done) + 256 + 256;
-    }
-};
-
-// updateIdsCUDA (kmeans.cu:73-105): first centre with strictly smaller sqrt((c-v)^2).  sqrt is monotone, so a
-// centre whose squared distance is not below the incumbent's cannot win; the sqrt is only formed otherwise.
-struct Nearest {
-    float d2, d;
-    int id;
-};
-__device__ inline void nearest_step(Nearest& b, float v, float c, int i)
-{
-    const float diff = c - v;
-    const float d2 = diff * diff;
-    if (d2 < b.d2) {
-        const float d = sqrtf(d2);
-        if (d < b.d) {
-            b.d = d;
-            b.d2 = d2;
-            b.id = i;
-        }
-    }
-}
-
-// ACCUMULATE: also the per-block sums of updateCentersCUDA (kmeans.cu:12-53); ids may be NULL then.
-template <bool ACCUMULATE>
-__global__ __launch_bounds__(kBlock) void kmeans_assign_kernel(int n, int n_centers, const float* __restrict__ values,
-                                                               const float* __restrict__ centers,
-                                                               int* __restrict__ ids, float* __restrict__ psum,
-                                                               int* __restrict__ pcnt, const int* __restrict__ done)
-{
-    if (ACCUMULATE && *done) return;
-    __shared__ float s_c[kMaxCenters];
-    __shared__ float s_sum[ACCUMULATE ? kMaxCenters : 1];
-    __shared__ int s_cnt[ACCUMULATE ? kMaxCenters : 1];
-    for (int i = threadIdx.x; i < n_centers; i += kBlock) {
-        s_c[i] = centers[i];
-        if (ACCUMULATE) {
-            s_sum[i] = 0.f;
-            s_cnt[i] = 0;
-        }
-    }
-    __syncthreads();
-    const int stride = gridDim.x * kBlock * kKmPerThread;
-    for (int base = blockIdx.x * kBlock * kKmPerThread; base < n; base += stride) {
-        float v[kKmPerThread];
-        Nearest b[kKmPerThread];
-#pragma unroll
-        for (int k = 0; k < kKmPerThread; k++) {
-            const int i = base + k * kBlock + threadIdx.x;
-            v[k] = i < n ? values[i] : 0.f;
-            b[k] = {INFINITY, INFINITY, 0};
-        }
-        for (int c = 0; c < n_centers; c++) {
-            const float cv = s_c[c];
-#pragma unroll
-            for (int k = 0; k < kKmPerThread; k++) nearest_step(b[k], v[k], cv, c);
-        }
-#pragma unroll
-        for (int k = 0; k < kKmPerThread; k++) {
-            const int i = base + k * kBlock + threadIdx.x;
-            if (i < n) {
-                if (ids) ids[i] = b[k].id;
-                if (ACCUMULATE) {
-                    atomicAdd(&s_sum[b[k].id], v[k]);
-                    atomicAdd(&s_cnt[b[k].id], 1);
-                }
-            }
-        }
-    }
-    if (ACCUMULATE) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < n_centers; i += kBlock) {
-            psum[(size_t)blockIdx.x * n_centers + i] = s_sum[i];
-            pcnt[(size_t)blockIdx.x * n_centers + i] = s_cnt[i];
-        }
-    }
-}
-
-// reduced_3dgs.cu:318-324: centre = sum / size, NaN (empty cluster) -> 0, shift = sum |old - new|, stop below tol.
-__global__ __launch_bounds__(kMaxCenters) void kmeans_update_kernel(int n_centers, int n_blocks,
-                                                                    const float* __restrict__ psum,
-                                                                    const int* __restrict__ pcnt,
-                                                                    float* __restrict__ centers, float tol,
-                                                                    int* __restrict__ done, int* __restrict__ iters)
-{
-    if (*done) return;
-    __shared__ float s_shift[kMaxCenters / 64];
-    const int c = threadIdx.x;
-    float shift = 0.f;
-    if (c < n_centers) {
-        float s = 0.f;
-        int cnt = 0;
-        for (int b = 0; b < n_blocks; b++) {
-            s += psum[(size_t)b * n_centers + c];
-            cnt += pcnt[(size_t)b * n_centers + c];
-        }
-        float nc = s / (float)cnt;
-        if (nc != nc) nc = 0.f;
-        shift = fabsf(centers[c] - nc);
-        centers[c] = nc;
-    }
-    for (int off = 32; off; off >>= 1) shift += __shfl_down(shift, off);
-    if ((threadIdx.x & 63) == 0) s_shift[threadIdx.x >> 6] = shift;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < (int)(blockDim.x + 63) / 64; w++) t += s_shift[w];
-        *iters += 1;
-        if (t < tol) *done = 1;
-    }
-}
-
-__global__ void kmeans_finish_kernel(int n_centers, const float* __restrict__ centers, float* __restrict__ out,
-                                     const int* __restrict__ iters, int* __restrict__ iters_out)
-{
-    for (int i = threadIdx.x; i < n_centers; i += blockDim.x) out[i] = centers[i];
-    if (threadIdx.x == 0 && iters_out) *iters_out = *iters;
-}
-
 int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -356,43 +203,6 @@ int r3dgs_min_redundancy(int P, int knn, const int* redundancy, const int* neigh
             min_redundancy_kernel<<<grid_for((long long)P * knn), kBlock, 0, s>>>((long long)P * knn, knn, redundancy,
                                                                                     neighbours, mask, min_redundancy);
         r3::check_launch("min redundancy", s, false);
-        return 0;
-    });
-}
-
-size_t r3dgs_kmeans_workspace_bytes(int n_centers)
-{
-    if (n_centers < 1 || n_centers > kMaxCenters) return 0;
-    return KmeansWork::bytes(n_centers);
-}
-
-int r3dgs_kmeans(int n_values, int n_centers, const float* values, const float* centers_in, float tol,
-                 int max_iterations, int* ids, float* centers_out, int* iterations_run, char* workspace, void* stream)
-{
-    return r3::guarded_call([&]() {
-        if (n_centers < 1 || n_centers > kMaxCenters) throw r3::Error("n_centers must be in [1,1024]");
-        if (n_values < 0 || max_iterations < 0) throw r3::Error("negative size");
-        if (!centers_in || !centers_out || !workspace || (n_values && (!values || !ids)))
-            throw r3::Error("a required pointer is NULL");
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        KmeansWork w = KmeansWork::carve(workspace, n_centers);
-        R3_HIP(hipMemcpyAsync(w.centers, centers_in, sizeof(float) * n_centers, hipMemcpyDeviceToDevice, s));
-        R3_HIP(hipMemsetAsync(w.done, 0, 256, s));
-        const long long per_block = (long long)kBlock * kKmPerThread;
-        int blocks = (int)((n_values + per_block - 1) / per_block);
-        blocks = blocks < 1 ? 1 : (blocks > kKmBlocks ? kKmBlocks : blocks);
-        const int upd_threads = (n_centers + 63) / 64 * 64;
-        for (int it = 0; it < max_iterations; it++) {
-            kmeans_assign_kernel<true><<<blocks, kBlock, 0, s>>>(n_values, n_centers, values, w.centers, nullptr,
-                                                                 w.psum, w.pcnt, w.done);
-            kmeans_update_kernel<<<1, upd_threads, 0, s>>>(n_centers, blocks, w.psum, w.pcnt, w.centers, tol, w.done,
-                                                           w.iters);
-        }
-        if (n_values)
-            kmeans_assign_kernel<false><<<blocks, kBlock, 0, s>>>(n_values, n_centers, values, w.centers, ids, nullptr,
-                                                                  nullptr, nullptr);
-        kmeans_finish_kernel<<<1, 256, 0, s>>>(n_centers, w.centers, centers_out, w.iters, iterations_run);
-        r3::check_launch("kmeans", s, false);
         return 0;
     });
 }

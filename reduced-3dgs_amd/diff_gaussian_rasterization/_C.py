@@ -52,7 +52,7 @@ _lib.r3dgs_sphere_ellipsoid_intersection.argtypes = [_i, _i] + [_vp] * 8
 _lib.r3dgs_min_redundancy.restype = _i
 _lib.r3dgs_min_redundancy.argtypes = [_i, _i] + [_vp] * 5
 _lib.r3dgs_kmeans_workspace_bytes.restype = C.c_size_t
-_lib.r3dgs_kmeans_workspace_bytes.argtypes = [_i]
+_lib.r3dgs_kmeans_workspace_bytes.argtypes = [_i, _i]
 _lib.r3dgs_kmeans.restype = _i
 _lib.r3dgs_kmeans.argtypes = [_i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.r3dgs_profile_enable.argtypes = [_i]
@@ -377,19 +377,19 @@ def allocate_minimum_redundancy_value(redundancy_values, neighbours_indices, int
 
 
 def kmeans_cuda(values, centers, tol, max_iterations, _want_iterations=False):
-    """Reduced3DGS::kmeans (reduced_3dgs.cu:290-340) -> (ids int32[n,1], centers fp32[n_centers]).  The whole Lloyd
-    loop is enqueued at once with the convergence flag on the device (the reference reads the shift back every
-    iteration)."""
+    """Reduced3DGS::kmeans (reduced_3dgs.cu:290-340) -> (ids int32[n,1], centers fp32[n_centers]).  Values sorted
+    once, one binary-search pass per update; the whole Lloyd loop is enqueued at once with the convergence flag on
+    the device (the reference scans all centres per value and reads the shift back every iteration)."""
     dev = _need_gpu(values, "kmeans_cuda")
     n, nc = int(values.size(0)), int(centers.size(0))
     ids = torch.zeros((n, 1), dtype=torch.int32, device=dev)
     new_centers = torch.empty((nc,), dtype=torch.float32, device=dev)
     iters = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws_bytes = _lib.r3dgs_kmeans_workspace_bytes(nc)
-    if ws_bytes == 0:
-        raise RuntimeError("kmeans_cuda: the number of centers must be in [1, 1024]")
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
+        ws_bytes = _lib.r3dgs_kmeans_workspace_bytes(n, nc)
+        if ws_bytes == 0:
+            raise RuntimeError(f"kmeans_cuda: {_lib.r3dgs_last_error().decode()}")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         _check(_lib.r3dgs_kmeans(n, nc, _ptr(_dev_f32(values, dev)), _ptr(_dev_f32(centers, dev)), float(tol),
                                  int(max_iterations), _ptr(ids), _ptr(new_centers), _ptr(iters), _ptr(ws),
                                  _stream()), "kmeans_cuda")

@@ -206,6 +206,39 @@ def test_gpu_kmeans_edge_cases():
         _C.kmeans_cuda(v.cpu(), torch.zeros(2), 1e-4, 1)                 # no CPU path
 
 
+@pytest.mark.gpu
+def test_gpu_kmeans_tie_semantics():
+    """The first-index rule of updateIdsCUDA under exact ties, duplicate / near-duplicate / infinite centres."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    rng = np.random.default_rng(21)
+    one = np.float32(1.0000001)
+    hand_c = np.array([5, one, np.nextafter(one, np.float32(2)), 5, -3, 0, -0.0, 1e30, np.inf, -np.inf, 2.5, 2.5],
+                      np.float32)
+    hand_v = np.array([100, -100, 1, 1.0000001, 1.0000002, 3.75, 0, -1.5, 4.99, 1e30, 3e38, -3e38, np.inf, -np.inf,
+                       1e-30, 2.5, 1.75], np.float32)
+    cases = [(hand_v, hand_c)]
+    for k in range(4):                                 # coarse grids: most values are equidistant from two centres
+        nc = [7, 256, 300, 1024][k]
+        c = (rng.integers(-40, 40, nc) / 4).astype(np.float32)
+        v = (rng.integers(-400, 400, 50_000) / 8).astype(np.float32)
+        cases.append((v, c))
+    c = rng.normal(0, 1, 256).astype(np.float32)
+    c[100:110] = c[5] + (np.arange(10) * 1e-7).astype(np.float32)       # a cluster of near-duplicate centres
+    cases.append((rng.normal(0, 3, 100_000).astype(np.float32), c))
+    for v, c in cases:
+        ids, cen = _C.kmeans_cuda(_dev(v).view(-1, 1), _dev(c), 1e-4, 0)
+        assert np.array_equal(cen.cpu().numpy(), c, equal_nan=True)
+        assert np.array_equal(ids.cpu().numpy()[:, 0], ro.kmeans_assign(v, c))
+    # and through updates: every intermediate centre set comes from this rule, compare the whole trajectory
+    v, c = cases[2]
+    for its in (1, 2, 5):
+        ids, cen = _C.kmeans_cuda(_dev(v).view(-1, 1), _dev(c), 0.0, its)
+        o_ids, o_cen, _ = ro.kmeans(v, c, 0.0, its)
+        np.testing.assert_allclose(cen.cpu().numpy(), o_cen, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(ids.cpu().numpy()[:, 0], ro.kmeans_assign(v, cen.cpu().numpy()))
+
+
 def _check_knn(points, K):
     from simple_knn._C import distIndex2
     P = points.shape[0]

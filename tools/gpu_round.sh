@@ -32,6 +32,10 @@ fi
 if [ "${PROF:-1}" = "1" ]; then
   ( cd /tmp && timeout ${T_PROF:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o r -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline ) > gpurun_out/prof.log 2>&1; echo "prof rc=$?" >> $S
 fi
+if [ -n "${EXTRA_PROF:-}" ]; then   # kernel stats of an extra in-repo script
+  ( cd /tmp && timeout ${T_PROF:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_extra -o r -- python $ROOT/$EXTRA_PROF ) > gpurun_out/prof_extra.log 2>&1; echo "prof_extra rc=$?" >> $S
+  f=$(find gpurun_out/prof_extra -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/extra_kernel_stats.csv
+fi
 if [ "${LISTCTR:-0}" = "1" ]; then ( cd /tmp && timeout 60 rocprofv3 -L ) > gpurun_out/counters.txt 2>&1; fi
 if [ -n "${PMC:-}" ]; then   # separate counter passes, kernel-trace only (never mixed with sys/hip traces)
   i=0
@@ -43,4 +47,5 @@ if [ -n "${PMC:-}" ]; then   # separate counter passes, kernel-trace only (never
 fi
 cat $S; echo ---; tail -5 gpurun_out/smoke.log 2>/dev/null; echo ---; tail -30 gpurun_out/pytest_gpu.log 2>/dev/null; echo ---; tail -1 gpurun_out/bench.log 2>/dev/null; echo ---; tail -${EXTRA_TAIL:-30} gpurun_out/extra.log 2>/dev/null
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" 2>/dev/null | head -1); if [ -n "$f" ]; then echo "--- $f"; head -22 "$f" | cut -c1-200; fi
+if [ -f gpurun_out/extra_kernel_stats.csv ] && [ -n "${EXTRA_PROF:-}" ]; then echo "--- extra kernel stats"; head -${EXTRA_STATS_LINES:-25} gpurun_out/extra_kernel_stats.csv | cut -c1-220; fi
 exit 0
