@@ -55,6 +55,186 @@ void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
     R3_HIP(rocprim::inclusive_scan(g.temp, bytes, it, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
 }
 
+// ---- bucketed depth sort ---------------------------------------------------------------------------------------
+// The generic device sort above is launch-latency bound at this size (block sort + 9 merge passes, ~125 us for
+// 500k keys).  The keys are view depths, so: (1) histogram over kDepthBuckets equal-width intervals of
+// [min depth, max depth] (the range comes from the preprocess kernel), exclusive scan by the last workgroup to
+// finish; (2) scatter (key, id) into the bucket regions; (3) one workgroup per bucket sorts its pairs in LDS as
+// 64-bit (key << 32 | id) words.  The bucket function is monotone in the key, so concatenating the sorted buckets
+// is the stable sort by depth bits the reference's 64-bit key sort implies.  A bucket larger than kBucketCap
+// (e.g. a fronto-parallel plane of splats) raises header.sort_overflow; the host sees it with the num_rendered
+// read-back and reruns the generic path.
+constexpr int kHistPerThread = 8;
+constexpr int kHistPerBlock = 256 * kHistPerThread;
+
+struct DepthRange {
+    float zmin, scale;
+};
+__device__ inline DepthRange load_depth_range(const GeomHeader* hdr)
+{
+    uint32_t mx = 0, mi = 0;
+    for (int k = 0; k < kShards; k++) {   // wave-uniform scalar loads
+        mx = max(mx, hdr->shard[k].depth_max);
+        mi = max(mi, hdr->shard[k].depth_inv_min);
+    }
+    DepthRange r;
+    const float zmax = __uint_as_float(mx), zmin = __uint_as_float(~mi);
+    r.zmin = zmin;
+    r.scale = zmax > zmin ? (float)kDepthBuckets / (zmax - zmin) : 0.f;   // no visible Gaussian: nothing is looked up
+    return r;
+}
+__device__ inline int depth_bucket(uint32_t key, DepthRange r)
+{
+    if (key == 0xFFFFFFFFu) return kDepthBuckets;   // culled
+    const int b = (int)((__uint_as_float(key) - r.zmin) * r.scale);
+    return min(max(b, 0), kDepthBuckets - 1);
+}
+
+__global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key, GeomHeader* hdr,
+                                                         DepthSortScratch* ds)
+{
+    __shared__ uint32_t hist[kDepthBuckets + 1];
+    __shared__ uint32_t s_part[256];
+    __shared__ bool s_last;
+    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
+    const DepthRange rng = load_depth_range(hdr);
+    __syncthreads();
+    const int base = blockIdx.x * kHistPerBlock;
+    for (int k = 0; k < kHistPerThread; k++) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < P) atomicAdd(&hist[depth_bucket(key[i], rng)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256)
+        if (hist[b]) atomicAdd(&ds->count[b], hist[b]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ds->done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // last workgroup: exclusive scan of the 1025 counts (4-5 per thread, then a block scan) + overflow flag
+    __threadfence();
+    constexpr int kPer = (kDepthBuckets + 1 + 255) / 256;
+    uint32_t c[kPer], sum = 0, big = 0;
+    for (int k = 0; k < kPer; k++) {
+        const int b = threadIdx.x * kPer + k;
+        c[k] = b <= kDepthBuckets ? __hip_atomic_load(&ds->count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (b < kDepthBuckets) big = max(big, c[k]);
+        sum += c[k];
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (int k = 0; k < kPer; k++) {
+        const int b = threadIdx.x * kPer + k;
+        if (b <= kDepthBuckets) ds->start[b] = run;
+        run += c[k];
+    }
+    if (threadIdx.x == 255) ds->start[kDepthBuckets + 1] = s_part[255];
+    if (big > (uint32_t)kBucketCap) hdr->shard[0].sort_overflow = 1u;
+}
+
+__global__ __launch_bounds__(256) void depth_scatter_kernel(int P, const uint32_t* __restrict__ key,
+                                                            const GeomHeader* hdr, DepthSortScratch* ds,
+                                                            uint32_t* __restrict__ out_key,
+                                                            uint32_t* __restrict__ out_id,
+                                                            uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[kDepthBuckets + 1];   // count, then the workgroup's base slot inside the bucket
+    __shared__ uint32_t rank[kDepthBuckets + 1];
+    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) {
+        hist[b] = 0;
+        rank[b] = 0;
+    }
+    const DepthRange rng = load_depth_range(hdr);
+    __syncthreads();
+    const int base = blockIdx.x * kHistPerBlock;
+    uint32_t kv[kHistPerThread];
+    int kb[kHistPerThread];
+    for (int k = 0; k < kHistPerThread; k++) {
+        const int i = base + k * 256 + threadIdx.x;
+        kb[k] = -1;
+        if (i < P) {
+            kv[k] = key[i];
+            kb[k] = depth_bucket(kv[k], rng);
+            atomicAdd(&hist[kb[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256)
+        if (hist[b]) hist[b] = ds->start[b] + atomicAdd(&ds->cursor[b], hist[b]);
+    __syncthreads();
+    for (int k = 0; k < kHistPerThread; k++)
+        if (kb[k] >= 0) {
+            const uint32_t slot = hist[kb[k]] + atomicAdd(&rank[kb[k]], 1u);   // any order: the bucket is sorted next
+            const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
+            if (kb[k] == kDepthBuckets) {
+                order[slot] = id;   // culled: zero tiles each, their order is immaterial -- final position already
+            } else {
+                out_key[slot] = kv[k];
+                out_id[slot] = id;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortScratch* __restrict__ ds,
+                                                                const uint32_t* __restrict__ in_key,
+                                                                const uint32_t* __restrict__ in_id,
+                                                                uint32_t* __restrict__ order)
+{
+    __shared__ unsigned long long s[kBucketCap];
+    const int b = blockIdx.x;
+    const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
+    if (n == 0) return;
+    // A bucket that overflows the LDS (sort_overflow is set and the host reruns the generic sort) is passed through
+    // unsorted: `order` must hold valid ids either way, the scan that follows gathers through it.
+    if (n > (uint32_t)kBucketCap) {
+        for (uint32_t r = threadIdx.x; r < n; r += 256) order[start + r] = in_id[start + r];
+        return;
+    }
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t r = threadIdx.x; r < N; r += 256)
+        s[r] = r < n ? ((unsigned long long)in_key[start + r] << 32) | in_id[start + r] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;   // lo has bit j clear
+                const unsigned long long a = s[lo], c = s[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > c) == up) {
+                    s[lo] = c;
+                    s[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t r = threadIdx.x; r < n; r += 256) order[start + r] = (uint32_t)s[r];
+}
+
+void run_depth_histogram(int P, GeomState& g, hipStream_t s)
+{
+    const int blocks = (P + kHistPerBlock - 1) / kHistPerBlock;
+    depth_hist_kernel<<<blocks, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort);
+}
+
+void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)
+{
+    const int blocks = (P + kHistPerBlock - 1) / kHistPerBlock;
+    depth_scatter_kernel<<<blocks, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort, g.key_sorted, g.bucket_id, g.order);
+    depth_bucket_sort_kernel<<<kDepthBuckets, 256, 0, s>>>(g.dsort, g.key_sorted, g.bucket_id, g.order);
+    size_t bytes = g.temp_bytes;
+    auto it = rocprim::make_transform_iterator(g.order, GatherTiles{g.tiles});
+    R3_HIP(rocprim::inclusive_scan(g.temp, bytes, it, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
+}
+
 // rasterizer_impl.cu:43-58 getHigherMsb
 static uint32_t higher_msb(uint32_t n)
 {

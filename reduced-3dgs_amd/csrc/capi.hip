@@ -14,6 +14,7 @@
 //   * `debug` makes every stage synchronise and surface its error (the reference's CHECK_CUDA).
 #include "../../include/r3dgs_rasterizer.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -166,7 +167,13 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     ImageState img = ImageState::carve(iptr, (size_t)width * height, (size_t)gx * gy);
     if (!radii) radii = geom.radii_internal;
 
-    R3_HIP(hipMemsetAsync(geom.header, 0, sizeof(GeomHeader), s));
+    // header + depth-sort scratch are adjacent: one fill clears both
+    R3_HIP(hipMemsetAsync(geom.header, 0,
+                          (size_t)(reinterpret_cast<char*>(geom.dsort + 1) - reinterpret_cast<char*>(geom.header)), s));
+    static const bool generic_sort = [] {   // R3DGS_DEPTH_SORT=generic forces the rocPRIM path (A/B runs, tests)
+        const char* v = getenv("R3DGS_DEPTH_SORT");
+        return v && std::string(v) == "generic";
+    }();
 
     FwdInputs in;
     in.P = P;
@@ -197,6 +204,8 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     launch_preprocess(in, view, geom, radii, s);
     t0.stop();
     check_launch("preprocess", s, debug);
+    StageTimer t1(kDepthSort, s);
+    if (!generic_sort) run_depth_histogram(P, geom, s);   // also decides sort_overflow, which travels with the header
     ReadbackCtx& rb = readback_ctx();
     R3_HIP(hipEventRecord(rb.after_pre, s));
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
@@ -208,8 +217,10 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
         tc.stop();
         R3_HIP(hipEventRecord(rb.colored, rb.side));
     }
-    StageTimer t1(kDepthSort, s);
-    run_depth_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
+    if (generic_sort)
+        run_depth_sort_and_scan(P, geom, s);
+    else
+        run_depth_bucket_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
     t1.stop();
     // spin on the event instead of hipEventSynchronize: a blocking wait parks the host thread, and on an otherwise
     // idle many-core host its wake-up (deep C-state exit) was observed to cost more than the whole forward
@@ -222,6 +233,12 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     for (int k = 0; k < kShards; k++) R64 += rb.pinned->shard[k].num_rendered;
     if (R64 > 0x7fffffffull) throw Error("num_rendered exceeds 2^31-1");
     const uint32_t R = (uint32_t)R64;
+    if (!generic_sort && rb.pinned->shard[0].sort_overflow) {
+        // a depth bucket did not fit one workgroup's LDS (many splats at one depth): redo with the generic sort
+        StageTimer t1b(kDepthSort, s);
+        run_depth_sort_and_scan(P, geom, s);
+        t1b.stop();
+    }
     check_launch("depth sort + scan", s, debug);
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
 

@@ -35,10 +35,24 @@ struct GeomHeader {
     struct Shard {
         uint32_t visible;       // #Gaussians with radii > 0 (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
         uint32_t num_rendered;  // sum of tiles_touched
-        uint32_t pad[30];
+        uint32_t depth_max;     // max depth bits over the visible Gaussians          } both by atomicMax, so the
+        uint32_t depth_inv_min; // max of ~(depth bits), i.e. ~min                    } zero-filled header is neutral
+        uint32_t sort_overflow; // shard 0 only: a depth bucket exceeds kBucketCap -> the host reruns the generic sort
+        uint32_t pad[27];
     } shard[kShards];
 };
 static_assert(sizeof(GeomHeader) == 128 * kShards, "one 128-B line per shard");
+
+// Bucketed depth sort (binning.hip): kDepthBuckets equal-width depth intervals between the view's min and max
+// depth, each sorted by one workgroup in LDS.  Zeroed together with the header at the start of every pass.
+constexpr int kDepthBuckets = 1024;
+constexpr int kBucketCap = 4096;   // (key, id) pairs one workgroup sorts in LDS (32 KB)
+struct DepthSortScratch {
+    uint32_t count[kDepthBuckets + 1];   // [kDepthBuckets] = the culled Gaussians
+    uint32_t cursor[kDepthBuckets + 1];
+    uint32_t start[kDepthBuckets + 2];   // exclusive scan of count, written by the histogram kernel's last block
+    uint32_t done;
+};
 
 struct Carver {
     char* p;
@@ -58,12 +72,14 @@ struct Carver {
 
 struct GeomState {
     GeomHeader* header;
+    DepthSortScratch* dsort;  // directly behind the header: one memset clears both
     GRec* rec;            // [P]
     float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward)
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
     uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
     uint32_t* tiles;      // [P]  tiles_touched
-    uint32_t* key_sorted; // [P]
+    uint32_t* key_sorted; // [P]  keys grouped by depth bucket (bucketed sort) / sorted keys (generic sort)
+    uint32_t* bucket_id;  // [P]  Gaussian ids grouped by depth bucket
     uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
     uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
     int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
@@ -74,12 +90,14 @@ struct GeomState {
         Carver c(base);
         GeomState g;
         g.header = c.take<GeomHeader>(1);
+        g.dsort = c.take<DepthSortScratch>(1);
         g.rec = c.take<GRec>(P);
         g.acc = c.take<float>(P * kAccStride);
         g.rect = c.take<ushort4>(P);
         g.depth_key = c.take<uint32_t>(P);
         g.tiles = c.take<uint32_t>(P);
         g.key_sorted = c.take<uint32_t>(P);
+        g.bucket_id = c.take<uint32_t>(P);
         g.order = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.radii_internal = c.take<int>(P);
@@ -231,7 +249,9 @@ void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomSt
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
 // depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])
-void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);
+void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);          // generic (rocPRIM) path
+void run_depth_histogram(int P, GeomState& g, hipStream_t s);              // bucketed path, step 1 (sets sort_overflow)
+void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s);   // bucketed path, steps 2-4
 void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s);
 void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s);
 

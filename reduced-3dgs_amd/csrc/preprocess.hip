@@ -113,25 +113,37 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
     // per-workgroup totals -> one atomic pair per workgroup on a sharded counter: visible count (SH-sparsity
     // normaliser of the backward) and num_rendered.  R does not depend on the depth order, so the host can fetch it
     // right after this kernel and size the binning blob while the GPU is busy with the depth sort (capi.hip).
+    // The depth range of the visible Gaussians rides along (bucketed depth sort, binning.hip).
     const unsigned long long vmask = __ballot(o.radius > 0);
     uint32_t tsum = o.tiles;
-    for (int off = 32; off > 0; off >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, off);
-    __shared__ uint32_t s_cnt[kPreBlock / 64][2];
+    uint32_t dmax = o.radius > 0 ? __float_as_uint(o.depth) : 0u, dinv = o.radius > 0 ? ~__float_as_uint(o.depth) : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        tsum += (uint32_t)__shfl_xor((int)tsum, off);
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
+        dinv = max(dinv, (uint32_t)__shfl_xor((int)dinv, off));
+    }
+    __shared__ uint32_t s_cnt[kPreBlock / 64][4];
     if (lane == 0) {
         s_cnt[wave][0] = (uint32_t)__popcll(vmask);
         s_cnt[wave][1] = tsum;
+        s_cnt[wave][2] = dmax;
+        s_cnt[wave][3] = dinv;
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t v = 0, r = 0;
+        uint32_t v = 0, r = 0, mx = 0, mi = 0;
         for (int k = 0; k < kPreBlock / 64; k++) {
             v += s_cnt[k][0];
             r += s_cnt[k][1];
+            mx = max(mx, s_cnt[k][2]);
+            mi = max(mi, s_cnt[k][3]);
         }
         if (v) {
             GeomHeader::Shard* sh = a.header->shard + (blockIdx.x & (kShards - 1));
             atomicAdd(&sh->visible, v);
             atomicAdd(&sh->num_rendered, r);
+            atomicMax(&sh->depth_max, mx);
+            atomicMax(&sh->depth_inv_min, mi);
         }
     }
 }

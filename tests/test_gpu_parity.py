@@ -163,6 +163,35 @@ def test_oracle_parity_larger(C_, kw):
     check_backward(bout, gr, ref["state"], 16)
 
 
+@pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])
+def test_depth_sort_ties_and_bucket_overflow(C_, mode):
+    """Depth-sort corner cases of the bucketed sort (binning.hip): `plane` puts 20k splats at ONE depth (a single
+    bucket far above its LDS capacity -> the generic-sort fallback, and every tie is decided by the Gaussian index,
+    rasterizer_impl.cu:110-113); `few_depths` has 7 distinct depths (huge buckets next to empty ones);
+    `two_far_apart` stretches the depth range so that nearly everything lands in the first bucket."""
+    W, H, P = 320, 240, 20_000
+    cam = ss.make_camera(W, H, 250.0)          # R = I, T = 0: view depth == world z exactly
+    g = ss.make_gaussians(P, cam, seed=12, degree_mode="mixed", scale_mu=0.02, behind_frac=0.02)
+    z = g["means3D"][:, 2]
+    front = z > 0.2
+    rng = np.random.default_rng(5)
+    if mode == "plane":
+        z[front] = 5.0
+    elif mode == "few_depths":
+        z[front] = rng.choice(np.array([2.0, 2.5, 3.0, 4.0, 6.0, 9.0, 11.5], np.float32), int(front.sum()))
+    else:
+        z[front] = (3.0 + 0.01 * rng.random(int(front.sum()))).astype(np.float32)
+        z[np.nonzero(front)[0][:3]] = 90.0
+    bg = np.array([0.2, 0.3, 0.1], np.float32)
+    dl = ss.upstream_grad(W, H, seed=3) * (W * H)
+    ref = oracle_forward(bg, g, cam, H, W)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, debug=True)
+    check_forward(C_, fout, ref, H, W, P)
+    gr = orc.backward(ref["state"], dl, 0.05)
+    bout = hip_backward(C_, fargs, fout, dl, 0.05, debug=True)
+    check_backward(bout, gr, ref["state"], 16)
+
+
 @pytest.mark.parametrize("kw", [
     dict(P=1, W=64, H=48, f=50.0, scale_mu=0.5, mod=1.0),
     dict(P=63, W=64, H=48, f=50.0, scale_mu=0.2, mod=1.0),
