@@ -57,15 +57,22 @@ void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
 
 // ---- bucketed depth sort ---------------------------------------------------------------------------------------
 // The generic device sort above is launch-latency bound at this size (block sort + 9 merge passes, ~125 us for
-// 500k keys).  The keys are view depths, so: (1) histogram over kDepthBuckets equal-width intervals of
-// [min depth, max depth] (the range comes from the preprocess kernel), exclusive scan by the last workgroup to
-// finish; (2) scatter (key, id) into the bucket regions; (3) one workgroup per bucket sorts its pairs in LDS as
-// 64-bit (key << 32 | id) words.  The bucket function is monotone in the key, so concatenating the sorted buckets
-// is the stable sort by depth bits the reference's 64-bit key sort implies.  A bucket larger than kBucketCap
-// (e.g. a fronto-parallel plane of splats) raises header.sort_overflow; the host sees it with the num_rendered
-// read-back and reruns the generic path.
-constexpr int kHistPerThread = 8;
-constexpr int kHistPerBlock = 256 * kHistPerThread;
+// 500k keys).  The keys are view depths, so:
+//   (1) every workgroup histograms its 4096 Gaussians over kDepthBuckets equal-width intervals of [min depth, max
+//       depth] (the range comes from the preprocess kernel) and stores its row -- no global atomics: device-scope
+//       atomics on the same few lines were the cost of the first version of this pass;
+//   (2) a column-wise scan of the rows (each workgroup's first slot inside each bucket) and the bucket totals;
+//       raises header.sort_overflow if a bucket exceeds kBucketCap;
+//   (3) (key, id) scatter into the bucket regions -- slot = bucket start (scan of the totals, redone per workgroup
+//       in LDS) + row base + LDS rank, again no global atomics;
+//   (4) one workgroup per bucket sorts its pairs in LDS as 64-bit (key << 32 | id) words and scans tiles_touched in
+//       that order on top of the bucket's base.
+// The bucket function is monotone in the key, so concatenating the sorted buckets is the stable sort by depth bits
+// the reference's 64-bit key sort implies.  On overflow (e.g. a fronto-parallel plane of splats) the host, which
+// sees the flag with the num_rendered read-back, reruns the generic path.
+constexpr int kHistPerThread = kHistPerBlock / 256;
+constexpr int kCountBits = 24;
+constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
 
 struct DepthRange {
     float zmin, scale;
@@ -90,110 +97,171 @@ __device__ inline int depth_bucket(uint32_t key, DepthRange r)
     return min(max(b, 0), kDepthBuckets - 1);
 }
 
-__global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key, GeomHeader* hdr,
-                                                         DepthSortScratch* ds)
+__global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
+                                                         const uint32_t* __restrict__ tiles, const GeomHeader* hdr,
+                                                         unsigned long long* __restrict__ rows)
 {
-    __shared__ uint32_t hist[kDepthBuckets + 1];
-    __shared__ uint32_t s_part[256];
-    __shared__ bool s_last;
+    __shared__ unsigned long long hist[kDepthBuckets + 1];
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
     const DepthRange rng = load_depth_range(hdr);
-    __syncthreads();
     const int base = blockIdx.x * kHistPerBlock;
-    for (int k = 0; k < kHistPerThread; k++) {
+    uint32_t kv[kHistPerThread], tv[kHistPerThread];
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++) {   // all loads in flight before the first LDS atomic
         const int i = base + k * 256 + threadIdx.x;
-        if (i < P) atomicAdd(&hist[depth_bucket(key[i], rng)], 1u);
+        kv[k] = i < P ? key[i] : 0xFFFFFFFFu;
+        tv[k] = i < P ? tiles[i] : 0u;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256)
-        if (hist[b]) atomicAdd(&ds->count[b], hist[b]);
-    __threadfence();
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++)
+        if (base + k * 256 + (int)threadIdx.x < P)
+            atomicAdd(&hist[depth_bucket(kv[k], rng)], ((unsigned long long)tv[k] << kCountBits) | 1ull);
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&ds->done, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    // last workgroup: exclusive scan of the 1025 counts (4-5 per thread, then a block scan) + overflow flag
-    __threadfence();
-    constexpr int kPer = (kDepthBuckets + 1 + 255) / 256;
-    uint32_t c[kPer], sum = 0, big = 0;
-    for (int k = 0; k < kPer; k++) {
-        const int b = threadIdx.x * kPer + k;
-        c[k] = b <= kDepthBuckets ? __hip_atomic_load(&ds->count[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (b < kDepthBuckets) big = max(big, c[k]);
-        sum += c[k];
-    }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (int k = 0; k < kPer; k++) {
-        const int b = threadIdx.x * kPer + k;
-        if (b <= kDepthBuckets) ds->start[b] = run;
-        run += c[k];
-    }
-    if (threadIdx.x == 255) ds->start[kDepthBuckets + 1] = s_part[255];
-    if (big > (uint32_t)kBucketCap) hdr->shard[0].sort_overflow = 1u;
+    unsigned long long* row = rows + (size_t)blockIdx.x * (kDepthBuckets + 1);
+    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) row[b] = hist[b];
 }
 
+// 64 columns per workgroup, a contiguous band of rows per wave: per column the exclusive prefix of the counts down
+// the rows (each histogram workgroup's first slot inside the bucket) and the column total.
+constexpr int kColWaves = 16;
+__global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_rows,
+                                                                       const unsigned long long* __restrict__ rows,
+                                                                       uint32_t* __restrict__ row_base,
+                                                                       DepthSortScratch* ds, GeomHeader* hdr)
+{
+    __shared__ unsigned long long s_part[kColWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c <= kDepthBuckets;
+    constexpr int kStride = kDepthBuckets + 1;
+    const int band = (n_rows + kColWaves - 1) / kColWaves;
+    const int r_lo = min(n_rows, w * band), r_hi = min(n_rows, r_lo + band);
+    unsigned long long mine = 0;
+    if (live) {
+#pragma unroll 8
+        for (int r = r_lo; r < r_hi; r++) mine += rows[(size_t)r * kStride + c];
+    }
+    s_part[w][lane] = mine;
+    __syncthreads();
+    if (!live) return;
+    unsigned long long acc = 0, total = 0;
+    for (int k = 0; k < kColWaves; k++) {
+        if (k < w) acc += s_part[k][lane];
+        total += s_part[k][lane];
+    }
+#pragma unroll 8
+    for (int r = r_lo; r < r_hi; r++) {
+        const unsigned long long v = rows[(size_t)r * kStride + c];
+        row_base[(size_t)r * kStride + c] = (uint32_t)(acc & kCountMask);
+        acc += v;
+    }
+    if (w == 0) {
+        ds->total[c] = total;
+        if (c < kDepthBuckets && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) hdr->shard[0].sort_overflow = 1u;
+    }
+}
+
+// Exclusive scan of the 1025 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
+// by a 256-thread workgroup into LDS.
+__device__ inline void scan_bucket_totals(const DepthSortScratch* ds, uint32_t* s_start, uint32_t* s_tile,
+                                          unsigned long long* s_tmp)
+{
+    constexpr int kPer = (kDepthBuckets + 1 + 255) / 256;
+    unsigned long long c[kPer], sum = 0;
+    for (int k = 0; k < kPer; k++) {
+        const int b = threadIdx.x * kPer + k;
+        c[k] = b <= kDepthBuckets ? ds->total[b] : 0ull;
+        sum += c[k];
+    }
+    s_tmp[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long add = (int)threadIdx.x >= off ? s_tmp[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_tmp[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = s_tmp[threadIdx.x] - sum;
+    for (int k = 0; k < kPer; k++) {
+        const int b = threadIdx.x * kPer + k;
+        if (b <= kDepthBuckets + 1) {
+            s_start[b] = (uint32_t)(run & kCountMask);
+            s_tile[b] = (uint32_t)(run >> kCountBits);
+        }
+        run += c[k];
+    }
+    __syncthreads();
+}
+
+// (key, id) into the bucket regions; the culled Gaussians go straight to their final place.
 __global__ __launch_bounds__(256) void depth_scatter_kernel(int P, const uint32_t* __restrict__ key,
                                                             const GeomHeader* hdr, DepthSortScratch* ds,
+                                                            const uint32_t* __restrict__ row_base,
                                                             uint32_t* __restrict__ out_key,
                                                             uint32_t* __restrict__ out_id,
-                                                            uint32_t* __restrict__ order)
+                                                            uint32_t* __restrict__ order,
+                                                            uint32_t* __restrict__ offsets)
 {
-    __shared__ uint32_t hist[kDepthBuckets + 1];   // count, then the workgroup's base slot inside the bucket
+    __shared__ uint32_t slot0[kDepthBuckets + 2];   // bucket starts, then this workgroup's first slot of each bucket
+    __shared__ uint32_t s_tile[kDepthBuckets + 2];
     __shared__ uint32_t rank[kDepthBuckets + 1];
+    __shared__ unsigned long long s_tmp[256];
+    scan_bucket_totals(ds, slot0, s_tile, s_tmp);
+    if (blockIdx.x == 0)   // published for the per-bucket sort kernel
+        for (int b = threadIdx.x; b <= kDepthBuckets + 1; b += 256) {
+            ds->start[b] = slot0[b];
+            ds->tile_base[b] = s_tile[b];
+        }
+    const uint32_t R = s_tile[kDepthBuckets];   // culled Gaussians add no tiles: their scan value is the total
+    __syncthreads();
+    const uint32_t* mybase = row_base + (size_t)blockIdx.x * (kDepthBuckets + 1);
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) {
-        hist[b] = 0;
+        slot0[b] += mybase[b];
         rank[b] = 0;
     }
     const DepthRange rng = load_depth_range(hdr);
-    __syncthreads();
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread];
-    int kb[kHistPerThread];
+#pragma unroll
     for (int k = 0; k < kHistPerThread; k++) {
         const int i = base + k * 256 + threadIdx.x;
-        kb[k] = -1;
-        if (i < P) {
-            kv[k] = key[i];
-            kb[k] = depth_bucket(kv[k], rng);
-            atomicAdd(&hist[kb[k]], 1u);
-        }
+        kv[k] = i < P ? key[i] : 0xFFFFFFFFu;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256)
-        if (hist[b]) hist[b] = ds->start[b] + atomicAdd(&ds->cursor[b], hist[b]);
-    __syncthreads();
-    for (int k = 0; k < kHistPerThread; k++)
-        if (kb[k] >= 0) {
-            const uint32_t slot = hist[kb[k]] + atomicAdd(&rank[kb[k]], 1u);   // any order: the bucket is sorted next
-            const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
-            if (kb[k] == kDepthBuckets) {
-                order[slot] = id;   // culled: zero tiles each, their order is immaterial -- final position already
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++) {
+        const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
+        if ((int)id < P) {
+            const int b = depth_bucket(kv[k], rng);
+            const uint32_t slot = slot0[b] + atomicAdd(&rank[b], 1u);   // any order: the bucket is sorted next
+            if (b == kDepthBuckets) {
+                order[slot] = id;
+                offsets[slot] = R;
             } else {
                 out_key[slot] = kv[k];
                 out_id[slot] = id;
             }
         }
+    }
 }
 
+// One workgroup per bucket: sort the (key << 32 | id) words in LDS, then the inclusive scan of tiles_touched in
+// that order on top of the bucket's base (rasterizer_impl.cu:441 InclusiveSum, fused).
 __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortScratch* __restrict__ ds,
                                                                 const uint32_t* __restrict__ in_key,
                                                                 const uint32_t* __restrict__ in_id,
-                                                                uint32_t* __restrict__ order)
+                                                                const uint32_t* __restrict__ tiles,
+                                                                uint32_t* __restrict__ order,
+                                                                uint32_t* __restrict__ offsets)
 {
     __shared__ unsigned long long s[kBucketCap];
+    __shared__ uint32_t s_sum[256];
     const int b = blockIdx.x;
     const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
     if (n == 0) return;
-    // A bucket that overflows the LDS (sort_overflow is set and the host reruns the generic sort) is passed through
-    // unsorted: `order` must hold valid ids either way, the scan that follows gathers through it.
+    // A bucket that overflows the LDS (sort_overflow is set and the host reruns the generic sort + scan) is passed
+    // through unsorted so that `order` holds valid ids.
     if (n > (uint32_t)kBucketCap) {
         for (uint32_t r = threadIdx.x; r < n; r += 256) order[start + r] = in_id[start + r];
         return;
@@ -216,23 +284,49 @@ __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortS
             }
             __syncthreads();
         }
-    for (uint32_t r = threadIdx.x; r < n; r += 256) order[start + r] = (uint32_t)s[r];
+    // scan: each thread owns `per` consecutive sorted entries
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t r0 = threadIdx.x * per;
+    uint32_t tl[kBucketCap / 256], mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t r = r0 + k;
+        tl[k] = r < n ? tiles[(uint32_t)s[r]] : 0u;
+        mine += tl[k];
+    }
+    s_sum[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = ds->tile_base[b] + s_sum[threadIdx.x] - mine;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t r = r0 + k;
+        if (r < n) {
+            run += tl[k];
+            order[start + r] = (uint32_t)s[r];
+            offsets[start + r] = run;
+        }
+    }
 }
 
 void run_depth_histogram(int P, GeomState& g, hipStream_t s)
 {
-    const int blocks = (P + kHistPerBlock - 1) / kHistPerBlock;
-    depth_hist_kernel<<<blocks, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort);
+    const int rows = (int)depth_hist_rows((size_t)P);
+    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.header, g.hist_rows);
+    depth_colscan_kernel<<<(kDepthBuckets + 1 + 63) / 64, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort,
+                                                                                     g.header);
 }
 
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)
 {
-    const int blocks = (P + kHistPerBlock - 1) / kHistPerBlock;
-    depth_scatter_kernel<<<blocks, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort, g.key_sorted, g.bucket_id, g.order);
-    depth_bucket_sort_kernel<<<kDepthBuckets, 256, 0, s>>>(g.dsort, g.key_sorted, g.bucket_id, g.order);
-    size_t bytes = g.temp_bytes;
-    auto it = rocprim::make_transform_iterator(g.order, GatherTiles{g.tiles});
-    R3_HIP(rocprim::inclusive_scan(g.temp, bytes, it, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
+    const int rows = (int)depth_hist_rows((size_t)P);
+    depth_scatter_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort, g.hist_base, g.key_sorted,
+                                              g.bucket_id, g.order, g.offsets);
+    depth_bucket_sort_kernel<<<kDepthBuckets, 256, 0, s>>>(g.dsort, g.key_sorted, g.bucket_id, g.tiles, g.order,
+                                                           g.offsets);
 }
 
 // rasterizer_impl.cu:43-58 getHigherMsb

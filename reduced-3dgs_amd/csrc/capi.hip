@@ -167,13 +167,12 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     ImageState img = ImageState::carve(iptr, (size_t)width * height, (size_t)gx * gy);
     if (!radii) radii = geom.radii_internal;
 
-    // header + depth-sort scratch are adjacent: one fill clears both
-    R3_HIP(hipMemsetAsync(geom.header, 0,
-                          (size_t)(reinterpret_cast<char*>(geom.dsort + 1) - reinterpret_cast<char*>(geom.header)), s));
-    static const bool generic_sort = [] {   // R3DGS_DEPTH_SORT=generic forces the rocPRIM path (A/B runs, tests)
+    R3_HIP(hipMemsetAsync(geom.header, 0, sizeof(GeomHeader), s));
+    static const bool generic_env = [] {   // R3DGS_DEPTH_SORT=generic forces the rocPRIM path (A/B runs, tests)
         const char* v = getenv("R3DGS_DEPTH_SORT");
         return v && std::string(v) == "generic";
     }();
+    const bool generic_sort = generic_env || P >= (1 << 24);   // the bucket histogram packs the count in 24 bits
 
     FwdInputs in;
     in.P = P;

@@ -47,12 +47,13 @@ static_assert(sizeof(GeomHeader) == 128 * kShards, "one 128-B line per shard");
 // depth, each sorted by one workgroup in LDS.  Zeroed together with the header at the start of every pass.
 constexpr int kDepthBuckets = 1024;
 constexpr int kBucketCap = 4096;   // (key, id) pairs one workgroup sorts in LDS (32 KB)
+constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
 struct DepthSortScratch {
-    uint32_t count[kDepthBuckets + 1];   // [kDepthBuckets] = the culled Gaussians
-    uint32_t cursor[kDepthBuckets + 1];
-    uint32_t start[kDepthBuckets + 2];   // exclusive scan of count, written by the histogram kernel's last block
-    uint32_t done;
+    unsigned long long total[kDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [kDepthBuckets] = culled
+    uint32_t start[kDepthBuckets + 2];       // exclusive scan of the bucket sizes
+    uint32_t tile_base[kDepthBuckets + 2];   // exclusive scan of the buckets' tiles_touched sums
 };
+inline size_t depth_hist_rows(size_t P) { return (P + kHistPerBlock - 1) / kHistPerBlock; }
 
 struct Carver {
     char* p;
@@ -72,7 +73,9 @@ struct Carver {
 
 struct GeomState {
     GeomHeader* header;
-    DepthSortScratch* dsort;  // directly behind the header: one memset clears both
+    DepthSortScratch* dsort;
+    unsigned long long* hist_rows;  // [rows][kDepthBuckets + 1]  per-workgroup (tile sum << 24 | count) histograms
+    uint32_t* hist_base;            // [rows][kDepthBuckets + 1]  first slot of each workgroup inside each bucket
     GRec* rec;            // [P]
     float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward)
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
@@ -91,6 +94,8 @@ struct GeomState {
         GeomState g;
         g.header = c.take<GeomHeader>(1);
         g.dsort = c.take<DepthSortScratch>(1);
+        g.hist_rows = c.take<unsigned long long>(depth_hist_rows(P) * (kDepthBuckets + 1));
+        g.hist_base = c.take<uint32_t>(depth_hist_rows(P) * (kDepthBuckets + 1));
         g.rec = c.take<GRec>(P);
         g.acc = c.take<float>(P * kAccStride);
         g.rect = c.take<ushort4>(P);
