@@ -14,7 +14,9 @@
 //   Stability of both sorts + ascending-id input order reproduces the reference's tie-break exactly.
 //
 // The sorts / scan use rocPRIM device primitives (onesweep radix sort, decoupled-lookback scan).
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include <rocprim/rocprim.hpp>
 
@@ -329,19 +331,15 @@ void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)
                                                            g.offsets);
 }
 
-// rasterizer_impl.cu:43-58 getHigherMsb
-static uint32_t higher_msb(uint32_t n)
+int tile_rank_bits(int P, size_t n_tiles)
 {
-    uint32_t msb = sizeof(n) * 4, step = msb;
-    while (step > 1) {
-        step /= 2;
-        if (n >> msb)
-            msb += step;
-        else
-            msb -= step;
-    }
-    if (n >> msb) msb++;
-    return msb;
+    static const bool force_pairs = [] {
+        const char* v = getenv("R3DGS_TILE_SORT");
+        return v && std::string(v) == "pairs";
+    }();
+    if (force_pairs) return 0;
+    const uint32_t tb = higher_msb((uint32_t)n_tiles), rb = higher_msb((uint32_t)P);
+    return tb + rb <= 32 ? (int)rb : 0;
 }
 
 // Pair emission, balanced over OUTPUT positions.  The reference loops one thread over all tiles of its
@@ -370,7 +368,8 @@ __device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restric
 __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, const uint32_t* __restrict__ order,
                                                          const uint32_t* __restrict__ offsets,
                                                          const ushort4* __restrict__ rect, int gx, GRec* rec,
-                                                         uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out)
+                                                         int rank_bits, uint32_t* __restrict__ tile_out,
+                                                         uint32_t* __restrict__ id_out)
 {
     __shared__ uint32_t s_end[kEmitSlice];
     __shared__ uint32_t s_id[kEmitSlice];
@@ -415,28 +414,55 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
             const ushort4 r = s_rect[lo];
             const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
             const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
-            tile_out[pos] = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
-            id_out[pos] = s_id[lo];
+            const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
+            if (rank_bits) {
+                tile_out[pos] = (tile << rank_bits) | (j_lo + lo);   // one word: tile | rank in depth order
+            } else {
+                tile_out[pos] = tile;
+                id_out[pos] = s_id[lo];
+            }
         }
     }
 }
 
-// rasterizer_impl.cu:124-146 identifyTileRanges on 32-bit tile keys
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_sorted, uint2* ranges)
+// rasterizer_impl.cu:124-146 identifyTileRanges on the sorted 32-bit keys; the packed sort's Gaussian ids
+// (point_list[i] = order[rank]) are materialised here too.
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_sorted,
+                                                          int rank_bits, const uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ point_list, uint2* ranges)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t cur = tile_sorted[i];
-    if (i == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = tile_sorted[i - 1];
-        if (cur != prev) {
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
+    if (i0 >= R) return;
+    uint32_t key[4];
+    const int n = min(4, R - i0);
+    if (n == 4) {
+        const uint4 k4 = *reinterpret_cast<const uint4*>(tile_sorted + i0);
+        key[0] = k4.x; key[1] = k4.y; key[2] = k4.z; key[3] = k4.w;
+    } else {
+        for (int k = 0; k < 4; k++) key[k] = k < n ? tile_sorted[i0 + k] : 0u;
+    }
+    uint32_t prev = i0 ? tile_sorted[i0 - 1] >> rank_bits : 0xFFFFFFFFu;
+    if (rank_bits) {
+        const uint32_t mask = (1u << rank_bits) - 1u;
+        uint32_t id[4];
+        for (int k = 0; k < 4; k++) id[k] = k < n ? order[key[k] & mask] : 0u;
+        if (n == 4)
+            *reinterpret_cast<uint4*>(point_list + i0) = make_uint4(id[0], id[1], id[2], id[3]);
+        else
+            for (int k = 0; k < n; k++) point_list[i0 + k] = id[k];
+    }
+    for (int k = 0; k < n; k++) {
+        const uint32_t cur = key[k] >> rank_bits;
+        const int i = i0 + k;
+        if (i == 0)
+            ranges[cur].x = 0;
+        else if (cur != prev) {
             ranges[prev].y = i;
             ranges[cur].x = i;
         }
+        if (i == R - 1) ranges[cur].y = R;
+        prev = cur;
     }
-    if (i == R - 1) ranges[cur].y = R;
 }
 
 void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s)
@@ -444,29 +470,37 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
     const size_t Tn = (size_t)gx * gy;
     R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
     if (R <= 0) return;
+    const int rank_bits = tile_rank_bits(P, Tn);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((R + kEmitPerBlock - 1) / kEmitPerBlock), dim3(256), 0, s, P, (uint32_t)R,
-                       g.order, g.offsets, g.rect, gx, g.rec, b.tile_in, b.gauss_in);
+                       g.order, g.offsets, g.rect, gx, g.rec, rank_bits, b.tile_in, b.gauss_in);
     const int bits = (int)higher_msb((uint32_t)Tn);
     size_t bytes = b.temp_bytes;
-    R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
-                                     bits, s));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, img.ranges);
+    if (rank_bits)
+        R3_HIP(rocprim::radix_sort_keys(b.temp, bytes, b.tile_in, b.tile_sorted, (size_t)R, rank_bits, rank_bits + bits, s));
+    else
+        R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
+                                         bits, s));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 1023) / 1024), dim3(256), 0, s, R, b.tile_sorted, rank_bits, g.order,
+                       b.point_list, img.ranges);
 }
 
 // debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list
-__global__ __launch_bounds__(256) void export_keys_kernel(int R, const uint32_t* __restrict__ tile_sorted,
+__global__ __launch_bounds__(256) void export_keys_kernel(int R, int rank_bits,
+                                                          const uint32_t* __restrict__ tile_sorted,
                                                           const uint32_t* __restrict__ point_list,
                                                           const uint32_t* __restrict__ depth_key, uint64_t* keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    keys[i] = ((uint64_t)tile_sorted[i] << 32) | (uint64_t)depth_key[point_list[i]];
+    keys[i] = ((uint64_t)(tile_sorted[i] >> rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
 }
 
-void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s)
+void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
+                        hipStream_t s)
 {
     if (R <= 0) return;
-    hipLaunchKernelGGL(export_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, b.tile_sorted, b.point_list,
+    hipLaunchKernelGGL(export_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_rank_bits(P, n_tiles),
+                       b.tile_sorted, b.point_list,
                        g.depth_key, keys_out);
 }
 

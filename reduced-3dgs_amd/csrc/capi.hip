@@ -168,6 +168,9 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     if (!radii) radii = geom.radii_internal;
 
     R3_HIP(hipMemsetAsync(geom.header, 0, sizeof(GeomHeader), s));
+    // (Clearing the tile ranges / pair flags on the side stream instead of the main one was tried: each cross-stream
+    // wait costs the main queue more than the ~5 us fill it saves -- step time went up by ~30 us.)
+    ReadbackCtx& rb = readback_ctx();
     static const bool generic_env = [] {   // R3DGS_DEPTH_SORT=generic forces the rocPRIM path (A/B runs, tests)
         const char* v = getenv("R3DGS_DEPTH_SORT");
         return v && std::string(v) == "generic";
@@ -205,7 +208,6 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     check_launch("preprocess", s, debug);
     StageTimer t1(kDepthSort, s);
     if (!generic_sort) run_depth_histogram(P, geom, s);   // also decides sort_overflow, which travels with the header
-    ReadbackCtx& rb = readback_ctx();
     R3_HIP(hipEventRecord(rb.after_pre, s));
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
     R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, sizeof(GeomHeader), hipMemcpyDeviceToHost, rb.side));
@@ -409,7 +411,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         if (R > 0) {
             R3_HIP(hipMemsetAsync(bin.pair_flag, 0, (size_t)R, s));
             launch_blend_backward(view, geom, bin, img, dL_dpix, s);
-            launch_pair_reduce(R, geom, bin, s);
+            launch_pair_reduce(P, R, (size_t)gx * gy, geom, bin, s);
         }
         t4.stop();
         check_launch("blend backward", s, debug);
@@ -503,7 +505,7 @@ int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer,
         ImageState img = ImageState::carve(image_buffer, N, Tn);
         if (R > 0) {
             BinState bin = BinState::carve(binning_buffer, (size_t)R, cached_tile_temp((size_t)R));
-            if (keys) launch_export_keys(R, bin, geom, keys, s);
+            if (keys) launch_export_keys(P, R, Tn, bin, geom, keys, s);
             if (point_list)
                 R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
         }

@@ -119,9 +119,9 @@ struct BinState {
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
     float* wave_part;      // [(R/64+1) * 2 * kPairGrad] leading / trailing partial run sums of each 64-pair group
     unsigned char* pair_flag;  // [R] 1 = the backward blend wrote this pair's row (only this is zeroed per pass)
-    uint32_t* tile_sorted; // [R] tile id of each entry
-    uint32_t* tile_in;     // [R]
-    uint32_t* gauss_in;    // [R]
+    uint32_t* tile_sorted; // [R] sorted keys: tile id (pair sort) or tile << rank_bits | depth rank (packed sort)
+    uint32_t* tile_in;     // [R] the same keys in emission (Gaussian-major) order
+    uint32_t* gauss_in;    // [R] Gaussian id per emitted pair (pair sort only)
     char* temp;
     size_t temp_bytes;
     char* end;
@@ -257,8 +257,28 @@ void launch_mark_visible(int P, const float* means3D, const float* view, bool* p
 void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);          // generic (rocPRIM) path
 void run_depth_histogram(int P, GeomState& g, hipStream_t s);              // bucketed path, step 1 (sets sort_overflow)
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s);   // bucketed path, steps 2-4
+// rasterizer_impl.cu:43-58 getHigherMsb
+inline uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb)
+            msb += step;
+        else
+            msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+// Packed tile sort: when (tile bits + depth-rank bits) fit 32 bits the pairs travel as ONE word
+// (tile << rank_bits | rank in depth order) through a key-only radix sort on the tile bits -- half the sort traffic;
+// the Gaussian id is order[rank].  Returns rank_bits, or 0 for the (key, value) pair sort.  Forward and backward
+// take the same decision from (P, #tiles) alone.  R3DGS_TILE_SORT=pairs forces the pair sort.
+int tile_rank_bits(int P, size_t n_tiles);
 void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s);
-void launch_export_keys(int R, const BinState& b, const GeomState& g, uint64_t* keys_out, hipStream_t s);
+void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
+                        hipStream_t s);
 
 void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
                           ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s);
@@ -280,7 +300,7 @@ void launch_colour_variance_accumulate(int P, const int* D, int M, int max_sh_de
                                        const float* cam_pos, const float* shs, const int* radii, const int* touched,
                                        const float* transmittance, float* wSum, float* wSumSq, float* mean,
                                        float* variance, float* accum, hipStream_t s);
-void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s);
+void launch_pair_reduce(int P, int R, size_t n_tiles, const GeomState& g, const BinState& b, hipStream_t s);
 void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
                                 const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
 

@@ -41,7 +41,8 @@ struct ShRowLdsRW {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const float* __restrict__ pair_grad,
                                                           const unsigned char* __restrict__ pair_flag,
-                                                          const uint32_t* __restrict__ pair_gid,
+                                                          const uint32_t* __restrict__ pair_gid, uint32_t rank_mask,
+                                                          const uint32_t* __restrict__ order,
                                                           const GRec* __restrict__ rec,
                                                           const uint32_t* __restrict__ tiles, float* __restrict__ acc,
                                                           float* __restrict__ wave_part)
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
 #pragma unroll
     for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
     if (valid) {
-        key = pair_gid[e];
+        // run key: the Gaussian id (pair sort) or its rank in depth order (packed sort: low bits of the pair word)
+        key = pair_gid[e] & rank_mask;
         if (pair_flag[e]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
             const float* src = pair_grad + (size_t)e * kPairGrad;
 #pragma unroll
@@ -73,9 +75,10 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
     }
     const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
     if (valid && (lane == 63 || knext != key)) {  // last lane of a run: holds the run's sum inside this group
-        const uint32_t gbase = e & ~63u, start = rec[key].pair_start, end = start + tiles[key];
+        const uint32_t gid = order ? order[key] : key;
+        const uint32_t gbase = e & ~63u, start = rec[gid].pair_start, end = start + tiles[gid];
         if (start >= gbase && end <= gbase + 64u) {
-            float* dst = acc + (size_t)key * kAccStride;
+            float* dst = acc + (size_t)gid * kAccStride;
 #pragma unroll
             for (int k = 0; k < kPairGrad; k++) dst[k] = v[k];
         } else {
@@ -92,12 +95,13 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
     }
 }
 
-void launch_pair_reduce(int R, const GeomState& g, const BinState& b, hipStream_t s)
+void launch_pair_reduce(int P, int R, size_t n_tiles, const GeomState& g, const BinState& b, hipStream_t s)
 {
     if (R <= 0) return;
+    const int rank_bits = tile_rank_bits(P, n_tiles);
     hipLaunchKernelGGL(pair_reduce_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.pair_grad, b.pair_flag,
-                       b.gauss_in,
-                       g.rec, g.tiles, g.acc, b.wave_part);
+                       rank_bits ? b.tile_in : b.gauss_in, rank_bits ? (1u << rank_bits) - 1u : 0xFFFFFFFFu,
+                       rank_bits ? g.order : nullptr, g.rec, g.tiles, g.acc, b.wave_part);
 }
 
 struct PreBwdArgs {

@@ -20,6 +20,7 @@ from oracle import oracle as orc
 from tests.golden_cases import CASES, case_inputs
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COLOR_ATOL = 1e-5
 GRAD_REL = 1e-4
@@ -382,3 +383,44 @@ def test_full_size_properties(C_, metric_scene):
         assert torch.equal(b1[k], b1_again[k]), k
     inv = radii == 0
     assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())
+
+
+def test_repeated_backward_and_pair_sort_path(C_):
+    """(1) Two backward passes over one forward state (retain_graph): the per-pair "row written" flags are cleared
+    by the forward and again by every backward, so the second pass must equal the first bit for bit.
+    (2) The (key, value) pair tile sort, used when tile bits + depth-rank bits exceed 32, gives the same integer
+    outputs as the packed key-only sort: forced here in a child process via R3DGS_TILE_SORT=pairs."""
+    import subprocess
+    import sys
+    W, H, P = 320, 240, 6000
+    cam = ss.make_camera(W, H, 250.0, 4)
+    g = ss.make_gaussians(P, cam, seed=8, degree_mode="mixed", scale_mu=0.03)
+    bg = np.array([0.0, 0.5, 1.0], np.float32)
+    dl = ss.upstream_grad(W, H, seed=9) * (W * H)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    b1 = hip_backward(C_, fargs, fout, dl, 0.1)
+    b2 = hip_backward(C_, fargs, fout, dl * 0.5, 0.1)
+    b3 = hip_backward(C_, fargs, fout, dl, 0.1)
+    for x, y in zip(b1, b3):
+        assert torch.equal(x, y)
+    assert not torch.equal(b1[3], b2[3])
+    ref = oracle_forward(bg, g, cam, H, W)
+    check_backward(b3, orc.backward(ref["state"], dl, 0.1), ref["state"], 16)
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import synth_scene as ss\n"
+        "from tests import test_gpu_parity as t\n"
+        "from diff_gaussian_rasterization import _C\n"
+        "cam = ss.make_camera(320, 240, 250.0, 4)\n"
+        "g = ss.make_gaussians(6000, cam, seed=8, degree_mode='mixed', scale_mu=0.03)\n"
+        "bg = np.array([0.0, 0.5, 1.0], np.float32)\n"
+        "dl = ss.upstream_grad(320, 240, seed=9) * (320 * 240)\n"
+        "ref = t.oracle_forward(bg, g, cam, 240, 320)\n"
+        "fargs, fout = t.hip_forward(_C, bg, g, cam, 240, 320)\n"
+        "t.check_forward(_C, fout, ref, 240, 320, 6000)\n"
+        "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), t.orc.backward(ref['state'], dl, 0.1), ref['state'], 16)\n"
+        "print('pairs-path-ok')\n") % (ROOT, os.path.join(ROOT, "reduced-3dgs_amd"))
+    env = dict(os.environ, R3DGS_TILE_SORT="pairs", R3DGS_DEPTH_SORT="generic")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert "pairs-path-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
