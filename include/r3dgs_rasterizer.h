@@ -117,10 +117,11 @@ int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg,
                                      float* mean, float* variance, float* colourDistancesAccum, void* stream);
 
 /* Optional per-stage timing (not in the reference; it times with torch.cuda.Event pairs from Python,
- * train.py:52-53, gaussian_renderer/__init__.py:95-98).  When enabled, every forward/backward records a
- * HIP event pair around each stage ON THE CALLER'S STREAM.  r3dgs_profile_read() waits for the recorded
- * events, writes per-stage total milliseconds and launch counts (arrays of r3dgs_profile_stage_count()
- * entries, host memory) and resets the counters. */
+ * train.py:52-53, gaussian_renderer/__init__.py:95-98).  When enabled, forward/backward record a HIP event pair
+ * around each selected stage ON THE CALLER'S STREAM.  on = 0: off; 1: every stage; otherwise bit (s + 1) selects
+ * stage s (each record is a stream packet: a dozen per pass cost a few percent of a 1 ms iteration).
+ * r3dgs_profile_read() waits for the recorded events, writes per-stage total milliseconds and launch counts
+ * (arrays of r3dgs_profile_stage_count() entries, host memory) and resets the counters. */
 int r3dgs_profile_enable(int on);
 int r3dgs_profile_stage_count(void);
 const char* r3dgs_profile_stage_name(int stage);

@@ -369,8 +369,12 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
                                                          const uint32_t* __restrict__ offsets,
                                                          const ushort4* __restrict__ rect, int gx, GRec* rec,
                                                          int rank_bits, uint32_t* __restrict__ tile_out,
-                                                         uint32_t* __restrict__ id_out)
+                                                         uint32_t* __restrict__ id_out, uint2* __restrict__ ranges,
+                                                         uint32_t n_tiles)
 {
+    // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
+    // by a fill of its own on the stream
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
     __shared__ uint32_t s_end[kEmitSlice];
     __shared__ uint32_t s_id[kEmitSlice];
     __shared__ ushort4 s_rect[kEmitSlice];
@@ -429,10 +433,16 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
 // (point_list[i] = order[rank]) are materialised here too.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_sorted,
                                                           int rank_bits, const uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ point_list, uint2* ranges)
+                                                          uint32_t* __restrict__ point_list, uint2* ranges,
+                                                          unsigned char* __restrict__ pair_flag)
 {
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
     if (i0 >= R) return;
+    // the backward's "row written" flags start out zero (it puts the ones it consumed back itself)
+    if (i0 + 4 <= R)
+        *reinterpret_cast<uint32_t*>(pair_flag + i0) = 0u;
+    else
+        for (int k = i0; k < R; k++) pair_flag[k] = 0;
     uint32_t key[4];
     const int n = min(4, R - i0);
     if (n == 4) {
@@ -468,11 +478,13 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t*
 void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s)
 {
     const size_t Tn = (size_t)gx * gy;
-    R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
-    if (R <= 0) return;
+    if (R <= 0) {
+        R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
+        return;
+    }
     const int rank_bits = tile_rank_bits(P, Tn);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((R + kEmitPerBlock - 1) / kEmitPerBlock), dim3(256), 0, s, P, (uint32_t)R,
-                       g.order, g.offsets, g.rect, gx, g.rec, rank_bits, b.tile_in, b.gauss_in);
+                       g.order, g.offsets, g.rect, gx, g.rec, rank_bits, b.tile_in, b.gauss_in, img.ranges, (uint32_t)Tn);
     const int bits = (int)higher_msb((uint32_t)Tn);
     size_t bytes = b.temp_bytes;
     if (rank_bits)
@@ -481,7 +493,7 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
         R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
                                          bits, s));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 1023) / 1024), dim3(256), 0, s, R, b.tile_sorted, rank_bits, g.order,
-                       b.point_list, img.ranges);
+                       b.point_list, img.ranges, b.pair_flag);
 }
 
 // debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list

@@ -60,7 +60,7 @@ size_t cached_tile_temp(size_t R)
 enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
 struct Profiler {
     std::mutex mu;
-    bool on = false;
+    unsigned mask = 0;   // bit (stage): record an event pair around that stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> used[kNumStages];
     std::vector<hipEvent_t> pool;
     hipEvent_t get()
@@ -82,7 +82,7 @@ struct StageTimer {
     hipEvent_t a = nullptr, b = nullptr;
     StageTimer(int stage_, hipStream_t s_) : stage(stage_), s(s_)
     {
-        if (!g_prof.on) return;
+        if (!((g_prof.mask >> stage_) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         a = g_prof.get();
         b = g_prof.get();
@@ -409,7 +409,8 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
 
         StageTimer t4(kBlendBwd, s);
         if (R > 0) {
-            R3_HIP(hipMemsetAsync(bin.pair_flag, 0, (size_t)R, s));
+            // bin.pair_flag is all zero here: the forward's tile_ranges kernel clears it and pair_reduce puts every
+            // flag it consumed back to zero, so neither pass pays for a fill of its own
             launch_blend_backward(view, geom, bin, img, dL_dpix, s);
             launch_pair_reduce(P, R, (size_t)gx * gy, geom, bin, s);
         }
@@ -455,8 +456,10 @@ int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg,
 
 int r3dgs_profile_enable(int on)
 {
+    // on == 0: off; on == 1: every stage; otherwise bit (s + 1) of `on` selects stage s alone -- each event record is
+    // a packet on the stream, and a dozen of them per pass cost a few percent of a 1 ms iteration
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.on = on != 0;
+    g_prof.mask = on == 0 ? 0u : (on == 1 ? ~0u : ((unsigned)on >> 1));
     return 0;
 }
 

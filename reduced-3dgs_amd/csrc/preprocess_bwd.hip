@@ -40,7 +40,7 @@ struct ShRowLdsRW {
 // over its own pairs instead cost 0.86 ms: the largest splats own 600+ pairs.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const float* __restrict__ pair_grad,
-                                                          const unsigned char* __restrict__ pair_flag,
+                                                          unsigned char* __restrict__ pair_flag,
                                                           const uint32_t* __restrict__ pair_gid, uint32_t rank_mask,
                                                           const uint32_t* __restrict__ order,
                                                           const GRec* __restrict__ rec,
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
         // run key: the Gaussian id (pair sort) or its rank in depth order (packed sort: low bits of the pair word)
         key = pair_gid[e] & rank_mask;
         if (pair_flag[e]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
+            pair_flag[e] = 0;  // consumed: all flags are zero again when this kernel ends (next backward pass)
             const float* src = pair_grad + (size_t)e * kPairGrad;
 #pragma unroll
             for (int k = 0; k < kPairGrad; k++) v[k] = src[k];

@@ -63,9 +63,18 @@ _lib.r3dgs_profile_read.argtypes = [_vp, _vp]
 LIBRARY_PATH = _LIB_PATH
 
 
-def profile_enable(on):
-    """Per-stage HIP-event timing inside the library (include/r3dgs_rasterizer.h r3dgs_profile_*)."""
-    _lib.r3dgs_profile_enable(int(bool(on)))
+def profile_enable(on, only=None):
+    """Per-stage HIP-event timing inside the library (include/r3dgs_rasterizer.h r3dgs_profile_*).
+    only: iterable of stage names to time alone (every event record is a packet on the stream)."""
+    if on and only:
+        n = _lib.r3dgs_profile_stage_count()
+        names = [_lib.r3dgs_profile_stage_name(k).decode() for k in range(n)]
+        code = 0
+        for name in only:
+            code |= 1 << (names.index(name) + 1)
+        _lib.r3dgs_profile_enable(code)
+    else:
+        _lib.r3dgs_profile_enable(int(bool(on)))
 
 
 def profile_read():

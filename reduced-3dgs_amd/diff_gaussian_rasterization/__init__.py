@@ -74,6 +74,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, degrees)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zeros_like(radii) fill per backward for the non-differentiable output
         return color, radii
 
     @staticmethod
@@ -81,6 +82,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
          degrees) = ctx.saved_tensors
+        if grad_out_color is None:  # the image did not take part in the loss
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=means3D.dtype,
+                                         device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, degrees, rs.campos,
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, ctx.lambda_sh_sparsity, rs.debug)
