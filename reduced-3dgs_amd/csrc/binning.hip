@@ -333,7 +333,7 @@ void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)
 
 int tile_rank_bits(int P, size_t n_tiles)
 {
-    static const bool force_pairs = [] {
+    static const bool force_pairs = [] {   // R3DGS_TILE_SORT=pairs | rocprim | (default: own radix on packed words)
         const char* v = getenv("R3DGS_TILE_SORT");
         return v && std::string(v) == "pairs";
     }();
@@ -370,8 +370,10 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
                                                          const ushort4* __restrict__ rect, int gx, GRec* rec,
                                                          int rank_bits, uint32_t* __restrict__ tile_out,
                                                          uint32_t* __restrict__ id_out, uint2* __restrict__ ranges,
-                                                         uint32_t n_tiles)
+                                                         uint32_t n_tiles, uint32_t* __restrict__ radix_rows)
 {
+    __shared__ uint32_t s_hist[kRadixBins];   // first radix digit of the packed tile sort, counted while emitting
+    if (radix_rows && threadIdx.x < kRadixBins) s_hist[threadIdx.x] = 0;
     // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
     // by a fill of its own on the stream
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
@@ -421,10 +423,136 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
             const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
             if (rank_bits) {
                 tile_out[pos] = (tile << rank_bits) | (j_lo + lo);   // one word: tile | rank in depth order
+                if (radix_rows) atomicAdd(&s_hist[tile & (kRadixBins - 1)], 1u);
             } else {
                 tile_out[pos] = tile;
                 id_out[pos] = s_id[lo];
             }
+        }
+    }
+    if (radix_rows) {
+        __syncthreads();
+        if (threadIdx.x < kRadixBins) radix_rows[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+    }
+}
+
+// ---- tile sort of the packed pair words: LSD radix, two 7-bit digits ------------------------------------------------
+// rocPRIM's onesweep spends more time around its two passes (per-pass fills of the look-back state, histogram and scan
+// kernels: ~65 us of launches and gaps for ~48 us of sorting at R = 3.6 M) than in them.  Here a pass is: per-workgroup
+// digit counts (for the first digit they come out of the emission kernel), one workgroup per digit scanning its row
+// of counts, and a scatter that ranks its 1024 keys stably -- wave-level match by seven ballots per round, running
+// per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the two passes give the tile-major order
+// with the emission (depth) order preserved inside a tile.
+__global__ __launch_bounds__(256) void radix_hist_kernel(uint32_t R, const uint32_t* __restrict__ in, int shift,
+                                                         uint32_t* __restrict__ rows)
+{
+    __shared__ uint32_t s_hist[kRadixBins];
+    if (threadIdx.x < kRadixBins) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kRadixBlock;
+#pragma unroll
+    for (int k = 0; k < kRadixBlock / 256; k++) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < R) atomicAdd(&s_hist[(in[i] >> shift) & (kRadixBins - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kRadixBins) rows[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of that digit's per-workgroup counts, and the digit total
+__global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, const uint32_t* __restrict__ rows,
+                                                               uint32_t* __restrict__ base, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t s_sum[256];
+    const uint32_t* row = rows + (size_t)blockIdx.x * nb;
+    uint32_t* out = base + (size_t)blockIdx.x * nb;
+    const uint32_t per = (nb + 255u) / 256u, e0 = threadIdx.x * per;
+    uint32_t mine = 0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < per; k++) mine += e0 + k < nb ? row[e0 + k] : 0u;
+    s_sum[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - mine;
+#pragma unroll 8
+    for (uint32_t k = 0; k < per; k++)
+        if (e0 + k < nb) {
+            const uint32_t v = row[e0 + k];
+            out[e0 + k] = run;
+            run += v;
+        }
+    if (threadIdx.x == 255) total[blockIdx.x] = s_sum[255];
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const uint32_t* __restrict__ in,
+                                                            uint32_t* __restrict__ out, int shift,
+                                                            const uint32_t* __restrict__ base,
+                                                            const uint32_t* __restrict__ total)
+{
+    constexpr int kWaves = 4, kRounds = kRadixBlock / 256;
+    __shared__ uint32_t s_wcount[kWaves][kRadixBins];   // running per-wave digit counts
+    __shared__ uint32_t s_start[kRadixBins];            // exclusive scan of the digit totals
+    __shared__ uint32_t s_off[kWaves][kRadixBins];      // digit start + workgroup base + waves below
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < kWaves * kRadixBins; t += 256) (&s_wcount[0][0])[t] = 0;
+    if (w == 0) {   // 128 totals, two per lane, scanned with shuffles
+        const uint32_t v0 = total[2 * lane], v1 = total[2 * lane + 1];
+        uint32_t incl = v0 + v1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += up;
+        }
+        const uint32_t excl = incl - (v0 + v1);
+        s_start[2 * lane] = excl;
+        s_start[2 * lane + 1] = excl + v0;
+    }
+    __syncthreads();
+    const uint32_t blk = blockIdx.x * (uint32_t)kRadixBlock + (uint32_t)w * (kRadixBlock / kWaves);
+    uint32_t key[kRounds], lrank[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const uint32_t i = blk + r * 64u + lane;
+        key[r] = i < R ? in[i] : 0u;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const bool valid = blk + r * 64u + lane < R;
+        const uint32_t d = (key[r] >> shift) & (kRadixBins - 1);
+        unsigned long long peers = __ballot(valid);   // lanes of this round holding the same digit
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t seen = s_wcount[w][d];          // same-digit keys of this wave in earlier rounds
+        lrank[r] = seen + (uint32_t)__popcll(peers & below);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & below) == 0ull) s_wcount[w][d] = seen + (uint32_t)__popcll(peers);   // group leader
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (threadIdx.x < kRadixBins) {
+        const int d = threadIdx.x;
+        uint32_t run = s_start[d] + base[(size_t)d * gridDim.x + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            s_off[k][d] = run;
+            run += s_wcount[k][d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        if (blk + r * 64u + lane < R) {
+            const uint32_t d = (key[r] >> shift) & (kRadixBins - 1);
+            out[s_off[w][d] + lrank[r]] = key[r];
         }
     }
 }
@@ -483,11 +611,30 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
         return;
     }
     const int rank_bits = tile_rank_bits(P, Tn);
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((R + kEmitPerBlock - 1) / kEmitPerBlock), dim3(256), 0, s, P, (uint32_t)R,
-                       g.order, g.offsets, g.rect, gx, g.rec, rank_bits, b.tile_in, b.gauss_in, img.ranges, (uint32_t)Tn);
     const int bits = (int)higher_msb((uint32_t)Tn);
+    const uint32_t nb = (uint32_t)((R + kEmitPerBlock - 1) / kEmitPerBlock);
+    static const bool rocprim_tiles = [] {   // R3DGS_TILE_SORT=rocprim: packed keys through rocPRIM's onesweep (A/B)
+        const char* v = getenv("R3DGS_TILE_SORT");
+        return v && std::string(v) == "rocprim";
+    }();
+    const bool own_radix = rank_bits && bits <= 2 * kRadixBits && !rocprim_tiles;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(nb), dim3(256), 0, s, P, (uint32_t)R, g.order, g.offsets, g.rect, gx, g.rec,
+                       rank_bits, b.tile_in, b.gauss_in, img.ranges, (uint32_t)Tn, own_radix ? b.radix_rows : nullptr);
     size_t bytes = b.temp_bytes;
-    if (rank_bits)
+    if (own_radix) {
+        // pass 1: low 7 tile bits (counts from the emission kernel), tile_in -> gauss_in (free in the packed sort)
+        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
+                           b.radix_total);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.tile_in, b.gauss_in, rank_bits,
+                           b.radix_base, b.radix_total);
+        // pass 2: the remaining tile bits, gauss_in -> tile_sorted
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, rank_bits + kRadixBits,
+                           b.radix_rows);
+        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
+                           b.radix_total + kRadixBins);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, b.tile_sorted,
+                           rank_bits + kRadixBits, b.radix_base, b.radix_total + kRadixBins);
+    } else if (rank_bits)
         R3_HIP(rocprim::radix_sort_keys(b.temp, bytes, b.tile_in, b.tile_sorted, (size_t)R, rank_bits, rank_bits + bits, s));
     else
         R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,

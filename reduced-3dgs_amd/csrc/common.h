@@ -114,6 +114,11 @@ struct GeomState {
     char* end;
 };
 
+// Tile sort of the packed pair words (binning.hip): LSD radix, 7-bit digits, 1024 keys per workgroup.
+constexpr int kRadixBits = 7;
+constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kRadixBlock = 1024;
+
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
@@ -121,7 +126,10 @@ struct BinState {
     unsigned char* pair_flag;  // [R] 1 = the backward blend wrote this pair's row (only this is zeroed per pass)
     uint32_t* tile_sorted; // [R] sorted keys: tile id (pair sort) or tile << rank_bits | depth rank (packed sort)
     uint32_t* tile_in;     // [R] the same keys in emission (Gaussian-major) order
-    uint32_t* gauss_in;    // [R] Gaussian id per emitted pair (pair sort only)
+    uint32_t* gauss_in;    // [R] Gaussian id per emitted pair (pair sort) / ping-pong buffer of the packed sort
+    uint32_t* radix_rows;  // [kRadixBins][R/kRadixBlock + 1] per-workgroup digit counts, digit-major
+    uint32_t* radix_base;  // same shape: first slot of each workgroup inside each digit
+    uint32_t* radix_total; // [2][kRadixBins] digit totals of the two passes
     char* temp;
     size_t temp_bytes;
     char* end;
@@ -136,6 +144,9 @@ struct BinState {
         b.tile_sorted = c.take<uint32_t>(R);
         b.tile_in = c.take<uint32_t>(R);
         b.gauss_in = c.take<uint32_t>(R);
+        b.radix_rows = c.take<uint32_t>((size_t)kRadixBins * (R / kRadixBlock + 1));
+        b.radix_base = c.take<uint32_t>((size_t)kRadixBins * (R / kRadixBlock + 1));
+        b.radix_total = c.take<uint32_t>(2 * kRadixBins);
         b.temp = c.take<char>(temp_bytes);
         b.temp_bytes = temp_bytes;
         b.end = c.p;
