@@ -79,18 +79,52 @@ constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
 struct DepthRange {
     float zmin, scale;
 };
-__device__ inline DepthRange load_depth_range(const GeomHeader* hdr)
+__device__ inline DepthRange make_depth_range(uint32_t mx, uint32_t mi)
 {
-    uint32_t mx = 0, mi = 0;
-    for (int k = 0; k < kShards; k++) {   // wave-uniform scalar loads
-        mx = max(mx, hdr->shard[k].depth_max);
-        mi = max(mi, hdr->shard[k].depth_inv_min);
-    }
     DepthRange r;
     const float zmax = __uint_as_float(mx), zmin = __uint_as_float(~mi);
     r.zmin = zmin;
     r.scale = zmax > zmin ? (float)kDepthBuckets / (zmax - zmin) : 0.f;   // no visible Gaussian: nothing is looked up
     return r;
+}
+__device__ inline DepthRange load_depth_range(const GeomHeader* hdr)
+{
+    return make_depth_range(hdr->depth_max, hdr->depth_inv_min);
+}
+// Sum / max of the preprocess workgroups' partials by one workgroup of 256 or 1024 threads (s_red: 4 x 16 words).
+__device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
+{
+    PrePartial acc = {0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(parts)[i];
+        acc.visible += v.x;
+        acc.num_rendered += v.y;
+        acc.depth_max = max(acc.depth_max, v.z);
+        acc.depth_inv_min = max(acc.depth_inv_min, v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.visible += (uint32_t)__shfl_xor((int)acc.visible, off);
+        acc.num_rendered += (uint32_t)__shfl_xor((int)acc.num_rendered, off);
+        acc.depth_max = max(acc.depth_max, (uint32_t)__shfl_xor((int)acc.depth_max, off));
+        acc.depth_inv_min = max(acc.depth_inv_min, (uint32_t)__shfl_xor((int)acc.depth_inv_min, off));
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[w][0] = acc.visible;
+        s_red[w][1] = acc.num_rendered;
+        s_red[w][2] = acc.depth_max;
+        s_red[w][3] = acc.depth_inv_min;
+    }
+    __syncthreads();
+    PrePartial out = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < nw; k++) {
+        out.visible += s_red[k][0];
+        out.num_rendered += s_red[k][1];
+        out.depth_max = max(out.depth_max, s_red[k][2]);
+        out.depth_inv_min = max(out.depth_inv_min, s_red[k][3]);
+    }
+    __syncthreads();
+    return out;
 }
 __device__ inline int depth_bucket(uint32_t key, DepthRange r)
 {
@@ -100,12 +134,15 @@ __device__ inline int depth_bucket(uint32_t key, DepthRange r)
 }
 
 __global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
-                                                         const uint32_t* __restrict__ tiles, const GeomHeader* hdr,
+                                                         const uint32_t* __restrict__ tiles,
+                                                         const PrePartial* __restrict__ parts, int n_parts,
                                                          unsigned long long* __restrict__ rows)
 {
     __shared__ unsigned long long hist[kDepthBuckets + 1];
+    __shared__ uint32_t s_red[16][4];
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
-    const DepthRange rng = load_depth_range(hdr);
+    const PrePartial all = reduce_partials(parts, n_parts, s_red);   // every workgroup derives the depth range itself
+    const DepthRange rng = make_depth_range(all.depth_max, all.depth_inv_min);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread], tv[kHistPerThread];
 #pragma unroll
@@ -130,9 +167,24 @@ constexpr int kColWaves = 16;
 __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_rows,
                                                                        const unsigned long long* __restrict__ rows,
                                                                        uint32_t* __restrict__ row_base,
-                                                                       DepthSortScratch* ds, GeomHeader* hdr)
+                                                                       DepthSortScratch* ds, GeomHeader* hdr,
+                                                                       const PrePartial* __restrict__ parts,
+                                                                       int n_parts)
 {
     __shared__ unsigned long long s_part[kColWaves][64];
+    __shared__ uint32_t s_red[16][4];
+    __shared__ uint32_t s_over;
+    if (threadIdx.x == 0) s_over = 0u;
+    if (blockIdx.x == 0) {   // the header the host reads back (and later kernels use): totals of the partials
+        const PrePartial all = reduce_partials(parts, n_parts, s_red);
+        if (threadIdx.x == 0) {
+            hdr->visible = all.visible;
+            hdr->num_rendered = all.num_rendered;
+            hdr->depth_max = all.depth_max;
+            hdr->depth_inv_min = all.depth_inv_min;
+        }
+        if (threadIdx.x >= gridDim.x && threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool live = c <= kDepthBuckets;
@@ -146,8 +198,8 @@ __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_row
     }
     s_part[w][lane] = mine;
     __syncthreads();
-    if (!live) return;
     unsigned long long acc = 0, total = 0;
+    if (live) {
     for (int k = 0; k < kColWaves; k++) {
         if (k < w) acc += s_part[k][lane];
         total += s_part[k][lane];
@@ -160,8 +212,25 @@ __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_row
     }
     if (w == 0) {
         ds->total[c] = total;
-        if (c < kDepthBuckets && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) hdr->shard[0].sort_overflow = 1u;
+        if (c < kDepthBuckets && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) s_over = 1u;
     }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->sort_overflow[blockIdx.x] = s_over;   // every slot the host reads is written
+}
+
+__global__ __launch_bounds__(1024) void header_reduce_kernel(const PrePartial* __restrict__ parts, int n_parts,
+                                                             GeomHeader* hdr)
+{
+    __shared__ uint32_t s_red[16][4];
+    const PrePartial all = reduce_partials(parts, n_parts, s_red);
+    if (threadIdx.x == 0) {
+        hdr->visible = all.visible;
+        hdr->num_rendered = all.num_rendered;
+        hdr->depth_max = all.depth_max;
+        hdr->depth_inv_min = all.depth_inv_min;
+    }
+    if (threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
 }
 
 // Exclusive scan of the 1025 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
@@ -314,12 +383,20 @@ __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortS
     }
 }
 
+constexpr int kColBlocks = (kDepthBuckets + 1 + 63) / 64;
+static_assert(kColBlocks <= kOverflowSlots, "one overflow slot per column-scan workgroup");
+
+void run_header_reduce(int P, GeomState& g, hipStream_t s)
+{
+    header_reduce_kernel<<<1, 1024, 0, s>>>(g.partials, (int)pre_partials((size_t)P), g.header);
+}
+
 void run_depth_histogram(int P, GeomState& g, hipStream_t s)
 {
-    const int rows = (int)depth_hist_rows((size_t)P);
-    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.header, g.hist_rows);
-    depth_colscan_kernel<<<(kDepthBuckets + 1 + 63) / 64, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort,
-                                                                                     g.header);
+    const int rows = (int)depth_hist_rows((size_t)P), np = (int)pre_partials((size_t)P);
+    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, g.hist_rows);
+    depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header,
+                                                                g.partials, np);
 }
 
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)

@@ -167,7 +167,6 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     ImageState img = ImageState::carve(iptr, (size_t)width * height, (size_t)gx * gy);
     if (!radii) radii = geom.radii_internal;
 
-    R3_HIP(hipMemsetAsync(geom.header, 0, sizeof(GeomHeader), s));
     // (Clearing the tile ranges / pair flags on the side stream instead of the main one was tried: each cross-stream
     // wait costs the main queue more than the ~5 us fill it saves -- step time went up by ~30 us.)
     ReadbackCtx& rb = readback_ctx();
@@ -207,7 +206,10 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     t0.stop();
     check_launch("preprocess", s, debug);
     StageTimer t1(kDepthSort, s);
-    if (!generic_sort) run_depth_histogram(P, geom, s);   // also decides sort_overflow, which travels with the header
+    if (!generic_sort)
+        run_depth_histogram(P, geom, s);   // also writes the header (totals, sort_overflow) the host reads back
+    else
+        run_header_reduce(P, geom, s);
     R3_HIP(hipEventRecord(rb.after_pre, s));
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
     R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, sizeof(GeomHeader), hipMemcpyDeviceToHost, rb.side));
@@ -230,11 +232,10 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) R3_HIP(q);
     }
-    uint64_t R64 = 0;
-    for (int k = 0; k < kShards; k++) R64 += rb.pinned->shard[k].num_rendered;
-    if (R64 > 0x7fffffffull) throw Error("num_rendered exceeds 2^31-1");
-    const uint32_t R = (uint32_t)R64;
-    if (!generic_sort && rb.pinned->shard[0].sort_overflow) {
+    const uint32_t R = rb.pinned->num_rendered;
+    bool overflow = false;
+    for (int k = 0; k < kOverflowSlots; k++) overflow |= rb.pinned->sort_overflow[k] != 0;
+    if (!generic_sort && overflow) {
         // a depth bucket did not fit one workgroup's LDS (many splats at one depth): redo with the generic sort
         StageTimer t1b(kDepthSort, s);
         run_depth_sort_and_scan(P, geom, s);

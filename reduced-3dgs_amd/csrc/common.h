@@ -27,24 +27,27 @@ constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the 
                               // dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb
 constexpr int kAccStride = 12;  // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
 
-// Per-view counters produced by the preprocess kernel.  One atomic per workgroup, spread over kShards
-// words that sit 128 B apart: the first GPU profile showed 7.8k same-address atomics (one per wave) costing
-// ~90 us -- more than the kernel's whole memory stream.  Consumers add the shards up.
-constexpr int kShards = 32;
-struct GeomHeader {
-    struct Shard {
-        uint32_t visible;       // #Gaussians with radii > 0 (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
-        uint32_t num_rendered;  // sum of tiles_touched
-        uint32_t depth_max;     // max depth bits over the visible Gaussians          } both by atomicMax, so the
-        uint32_t depth_inv_min; // max of ~(depth bits), i.e. ~min                    } zero-filled header is neutral
-        uint32_t sort_overflow; // shard 0 only: a depth bucket exceeds kBucketCap -> the host reruns the generic sort
-        uint32_t pad[27];
-    } shard[kShards];
+// Per-view counters.  Every preprocess workgroup stores one PrePartial (no atomics, nothing to pre-clear: the first
+// GPU profile showed 7.8k same-address atomics costing ~90 us, a sharded version still needed a fill of the header
+// in front of every pass); the depth-sort kernels reduce them, and one workgroup writes the header the host reads.
+constexpr int kPreBlockSize = 256;
+struct PrePartial {
+    uint32_t visible;        // #Gaussians with radii > 0 in the workgroup (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
+    uint32_t num_rendered;   // sum of tiles_touched
+    uint32_t depth_max;      // max depth bits over the visible Gaussians (0 if none)
+    uint32_t depth_inv_min;  // max of ~(depth bits), i.e. ~min (0 if none)
 };
-static_assert(sizeof(GeomHeader) == 128 * kShards, "one 128-B line per shard");
+constexpr int kOverflowSlots = 32;
+struct GeomHeader {
+    uint32_t visible, num_rendered, depth_max, depth_inv_min;
+    uint32_t sort_overflow[kOverflowSlots];  // one per column-scan workgroup: a depth bucket exceeds kBucketCap
+    uint32_t pad[28];
+};
+static_assert(sizeof(GeomHeader) == 256, "header = 256 B");
+inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBlockSize; }
 
 // Bucketed depth sort (binning.hip): kDepthBuckets equal-width depth intervals between the view's min and max
-// depth, each sorted by one workgroup in LDS.  Zeroed together with the header at the start of every pass.
+// depth, each sorted by one workgroup in LDS.
 constexpr int kDepthBuckets = 1024;
 constexpr int kBucketCap = 4096;   // (key, id) pairs one workgroup sorts in LDS (32 KB)
 constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
@@ -73,6 +76,7 @@ struct Carver {
 
 struct GeomState {
     GeomHeader* header;
+    PrePartial* partials;     // [ceil(P / 256)]
     DepthSortScratch* dsort;
     unsigned long long* hist_rows;  // [rows][kDepthBuckets + 1]  per-workgroup (tile sum << 24 | count) histograms
     uint32_t* hist_base;            // [rows][kDepthBuckets + 1]  first slot of each workgroup inside each bucket
@@ -93,6 +97,7 @@ struct GeomState {
         Carver c(base);
         GeomState g;
         g.header = c.take<GeomHeader>(1);
+        g.partials = c.take<PrePartial>(pre_partials(P));
         g.dsort = c.take<DepthSortScratch>(1);
         g.hist_rows = c.take<unsigned long long>(depth_hist_rows(P) * (kDepthBuckets + 1));
         g.hist_base = c.take<uint32_t>(depth_hist_rows(P) * (kDepthBuckets + 1));
@@ -265,6 +270,7 @@ void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomSt
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
 // depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])
+void run_header_reduce(int P, GeomState& g, hipStream_t s);                // generic path: partials -> header
 void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);          // generic (rocPRIM) path
 void run_depth_histogram(int P, GeomState& g, hipStream_t s);              // bucketed path, step 1 (sets sort_overflow)
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s);   // bucketed path, steps 2-4

@@ -16,7 +16,7 @@
 
 namespace r3 {
 
-constexpr int kPreBlock = 256;
+constexpr int kPreBlock = kPreBlockSize;
 constexpr int kMaxCoeff = 16;
 constexpr int kRowFloats = 3 * kMaxCoeff;                        // 48
 constexpr int kWaveShFloats = 64 * kRowFloats + (64 * kRowFloats) / 32;  // + bank skew
@@ -36,7 +36,7 @@ struct PreArgs {
     ushort4* rect;
     uint32_t* depth_key;
     uint32_t* tiles;
-    GeomHeader* header;
+    PrePartial* partials;
     int* radii;
 };
 
@@ -110,10 +110,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
         a.tiles[i] = o.tiles;
         a.depth_key[i] = dkey;
     }
-    // per-workgroup totals -> one atomic pair per workgroup on a sharded counter: visible count (SH-sparsity
-    // normaliser of the backward) and num_rendered.  R does not depend on the depth order, so the host can fetch it
-    // right after this kernel and size the binning blob while the GPU is busy with the depth sort (capi.hip).
-    // The depth range of the visible Gaussians rides along (bucketed depth sort, binning.hip).
+    // per-workgroup totals, stored (not accumulated): visible count (SH-sparsity normaliser of the backward),
+    // num_rendered, and the depth range of the visible Gaussians (bucketed depth sort, binning.hip).  R does not depend
+    // on the depth order, so the host can fetch it while the GPU is busy with the depth sort (capi.hip).
     const unsigned long long vmask = __ballot(o.radius > 0);
     uint32_t tsum = o.tiles;
     uint32_t dmax = o.radius > 0 ? __float_as_uint(o.depth) : 0u, dinv = o.radius > 0 ? ~__float_as_uint(o.depth) : 0u;
@@ -131,20 +130,14 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t v = 0, r = 0, mx = 0, mi = 0;
+        PrePartial pp = {0u, 0u, 0u, 0u};
         for (int k = 0; k < kPreBlock / 64; k++) {
-            v += s_cnt[k][0];
-            r += s_cnt[k][1];
-            mx = max(mx, s_cnt[k][2]);
-            mi = max(mi, s_cnt[k][3]);
+            pp.visible += s_cnt[k][0];
+            pp.num_rendered += s_cnt[k][1];
+            pp.depth_max = max(pp.depth_max, s_cnt[k][2]);
+            pp.depth_inv_min = max(pp.depth_inv_min, s_cnt[k][3]);
         }
-        if (v) {
-            GeomHeader::Shard* sh = a.header->shard + (blockIdx.x & (kShards - 1));
-            atomicAdd(&sh->visible, v);
-            atomicAdd(&sh->num_rendered, r);
-            atomicMax(&sh->depth_max, mx);
-            atomicMax(&sh->depth_inv_min, mi);
-        }
+        a.partials[blockIdx.x] = pp;
     }
 }
 
@@ -239,7 +232,7 @@ void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g
     a.rect = g.rect;
     a.depth_key = g.depth_key;
     a.tiles = g.tiles;
-    a.header = g.header;
+    a.partials = g.partials;
     a.radii = radii;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
     hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, a);
@@ -254,7 +247,7 @@ void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomSt
     a.rect = g.rect;
     a.depth_key = g.depth_key;
     a.tiles = g.tiles;
-    a.header = g.header;
+    a.partials = g.partials;
     a.radii = nullptr;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
     if (in.coeffs_num)

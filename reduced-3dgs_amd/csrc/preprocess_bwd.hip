@@ -192,8 +192,7 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
         if (has_sh) {
             float mult = 0.f;
             if (a.lambda_sh != 0.f) {
-                uint32_t V = 0;
-                for (int k = 0; k < kShards; k++) V += a.header->shard[k].visible;
+                const uint32_t V = a.header->visible;
                 mult = a.lambda_sh / (float)((int)V * 15 * 3);
             }
             const int deg = a.in.degrees[i];
