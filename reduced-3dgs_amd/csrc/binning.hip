@@ -57,6 +57,24 @@ void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
     R3_HIP(rocprim::inclusive_scan(g.temp, bytes, it, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
 }
 
+// Inclusive scan across a 256-thread workgroup: shuffles inside each wave, one LDS exchange of the four wave totals
+// (two barriers instead of the sixteen of a Hillis-Steele pass in LDS).  s_w: 4 words of LDS.
+template <class T>
+__device__ inline T block256_inclusive_scan(T v, T* s_w)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const T up = __shfl_up(v, off);
+        if (lane >= off) v += up;
+    }
+    __syncthreads();   // s_w may still be read from a previous use
+    if (lane == 63) s_w[w] = v;
+    __syncthreads();
+    T add = 0;
+    for (int k = 0; k < w; k++) add += s_w[k];
+    return v + add;
+}
+
 // ---- bucketed depth sort ---------------------------------------------------------------------------------------
 // The generic device sort above is launch-latency bound at this size (block sort + 9 merge passes, ~125 us for
 // 500k keys).  The keys are view depths, so:
@@ -245,15 +263,7 @@ __device__ inline void scan_bucket_totals(const DepthSortScratch* ds, uint32_t* 
         c[k] = b <= kDepthBuckets ? ds->total[b] : 0ull;
         sum += c[k];
     }
-    s_tmp[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned long long add = (int)threadIdx.x >= off ? s_tmp[threadIdx.x - off] : 0ull;
-        __syncthreads();
-        s_tmp[threadIdx.x] += add;
-        __syncthreads();
-    }
-    unsigned long long run = s_tmp[threadIdx.x] - sum;
+    unsigned long long run = block256_inclusive_scan(sum, s_tmp) - sum;
     for (int k = 0; k < kPer; k++) {
         const int b = threadIdx.x * kPer + k;
         if (b <= kDepthBuckets + 1) {
@@ -364,15 +374,7 @@ __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortS
         tl[k] = r < n ? tiles[(uint32_t)s[r]] : 0u;
         mine += tl[k];
     }
-    s_sum[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = (int)threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = ds->tile_base[b] + s_sum[threadIdx.x] - mine;
+    uint32_t run = ds->tile_base[b] + block256_inclusive_scan(mine, s_sum) - mine;
     for (uint32_t k = 0; k < per; k++) {
         const uint32_t r = r0 + k;
         if (r < n) {
@@ -547,15 +549,8 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, cons
     uint32_t mine = 0;
 #pragma unroll 8
     for (uint32_t k = 0; k < per; k++) mine += e0 + k < nb ? row[e0 + k] : 0u;
-    s_sum[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = (int)threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = s_sum[threadIdx.x] - mine;
+    const uint32_t incl = block256_inclusive_scan(mine, s_sum);
+    uint32_t run = incl - mine;
 #pragma unroll 8
     for (uint32_t k = 0; k < per; k++)
         if (e0 + k < nb) {
@@ -563,7 +558,7 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, cons
             out[e0 + k] = run;
             run += v;
         }
-    if (threadIdx.x == 255) total[blockIdx.x] = s_sum[255];
+    if (threadIdx.x == 255) total[blockIdx.x] = incl;
 }
 
 __global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const uint32_t* __restrict__ in,
