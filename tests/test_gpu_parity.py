@@ -93,18 +93,18 @@ def grads_close(name, ref, got, rel=GRAD_REL):
     assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} ({err / scale:.2e} rel)"
 
 
-def check_backward(bout, gr, st, M):
+def check_backward(bout, gr, st, M, rel=GRAD_REL):
     (dm2, dcol, dop, dm3, dcov, dsh, dsc, drot, dconic) = bout
-    grads_close("dL_dmeans2D", gr["dL_dmeans2D"], dm2)
-    grads_close("dL_dconic", gr["dL_dconic"][:, [0, 1, 3]], dconic.reshape(-1, 4)[:, [0, 1, 3]])
-    grads_close("dL_dcolors", gr["dL_dcolors"], dcol)
-    grads_close("dL_dopacity", gr["dL_dopacity"], dop)
-    grads_close("dL_dmeans3D", gr["dL_dmeans3D"], dm3)
-    grads_close("dL_dcov3D", gr["dL_dcov3D"], dcov)
+    grads_close("dL_dmeans2D", gr["dL_dmeans2D"], dm2, rel)
+    grads_close("dL_dconic", gr["dL_dconic"][:, [0, 1, 3]], dconic.reshape(-1, 4)[:, [0, 1, 3]], rel)
+    grads_close("dL_dcolors", gr["dL_dcolors"], dcol, rel)
+    grads_close("dL_dopacity", gr["dL_dopacity"], dop, rel)
+    grads_close("dL_dmeans3D", gr["dL_dmeans3D"], dm3, rel)
+    grads_close("dL_dcov3D", gr["dL_dcov3D"], dcov, rel)
     if M:
-        grads_close("dL_dsh", gr["dL_dsh"], dsh)
-    grads_close("dL_dscales", gr["dL_dscales"], dsc)
-    grads_close("dL_drotations", gr["dL_drotations"], drot)
+        grads_close("dL_dsh", gr["dL_dsh"], dsh, rel)
+    grads_close("dL_dscales", gr["dL_dscales"], dsc, rel)
+    grads_close("dL_drotations", gr["dL_drotations"], drot, rel)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
     for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):
@@ -199,7 +199,11 @@ def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     dict(P=65, W=130, H=70, f=80.0, scale_mu=0.2, mod=0.7),
     dict(P=2500, W=96, H=80, f=70.0, scale_mu=1.2, mod=1.0),   # every splat covers most tiles: lists of ~2000
     dict(P=4000, W=320, H=200, f=200.0, scale_mu=0.08, mod=1.6),
-], ids=["single", "p63", "p65_mod0.7", "dense_long_lists", "mod1.6"])
+    # 256 x 144 = 36864 tiles (16 tile bits): beyond the two 7-bit digits of the own radix sort -> rocPRIM key sort.
+    # 9.4 Mpix with few splats: the ~170 threshold-ambiguous pixels (excluded from the image checks) each move a
+    # gradient by one pixel's worth, which is 4e-4 of the largest gradient here -> looser gradient bar for this case.
+    dict(P=3000, W=4096, H=2304, f=3000.0, scale_mu=0.03, mod=1.0, grad_rel=2e-3),
+], ids=["single", "p63", "p65_mod0.7", "dense_long_lists", "mod1.6", "uhd_16_tile_bits"])
 def test_edge_sizes_long_lists_and_scale_modifier(C_, kw):
     W, H, P, mod = kw["W"], kw["H"], kw["P"], kw["mod"]
     cam = ss.make_camera(W, H, kw["f"], 9)
@@ -212,7 +216,7 @@ def test_edge_sizes_long_lists_and_scale_modifier(C_, kw):
     check_forward(C_, fout, ref, H, W, P)
     gr = orc.backward(ref["state"], dl, 0.02)
     bout = hip_backward(C_, fargs, fout, dl, 0.02)
-    check_backward(bout, gr, ref["state"], 16)
+    check_backward(bout, gr, ref["state"], 16, rel=kw.get("grad_rel", GRAD_REL))
     if kw["scale_mu"] > 1.0:
         rng_ = ref["state"]["ranges"].astype(np.int64)
         assert (rng_[:, 1] - rng_[:, 0]).max() > 1500  # really exercises multi-chunk lists
