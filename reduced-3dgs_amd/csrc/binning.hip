@@ -152,15 +152,12 @@ __device__ inline int depth_bucket(uint32_t key, DepthRange r)
 }
 
 __global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
-                                                         const uint32_t* __restrict__ tiles,
-                                                         const PrePartial* __restrict__ parts, int n_parts,
+                                                         const uint32_t* __restrict__ tiles, const GeomHeader* hdr,
                                                          unsigned long long* __restrict__ rows)
 {
     __shared__ unsigned long long hist[kDepthBuckets + 1];
-    __shared__ uint32_t s_red[16][4];
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
-    const PrePartial all = reduce_partials(parts, n_parts, s_red);   // every workgroup derives the depth range itself
-    const DepthRange rng = make_depth_range(all.depth_max, all.depth_inv_min);
+    const DepthRange rng = load_depth_range(hdr);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread], tv[kHistPerThread];
 #pragma unroll
@@ -185,24 +182,13 @@ constexpr int kColWaves = 16;
 __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_rows,
                                                                        const unsigned long long* __restrict__ rows,
                                                                        uint32_t* __restrict__ row_base,
-                                                                       DepthSortScratch* ds, GeomHeader* hdr,
-                                                                       const PrePartial* __restrict__ parts,
-                                                                       int n_parts)
+                                                                       DepthSortScratch* ds, GeomHeader* hdr)
 {
     __shared__ unsigned long long s_part[kColWaves][64];
-    __shared__ uint32_t s_red[16][4];
     __shared__ uint32_t s_over;
     if (threadIdx.x == 0) s_over = 0u;
-    if (blockIdx.x == 0) {   // the header the host reads back (and later kernels use): totals of the partials
-        const PrePartial all = reduce_partials(parts, n_parts, s_red);
-        if (threadIdx.x == 0) {
-            hdr->visible = all.visible;
-            hdr->num_rendered = all.num_rendered;
-            hdr->depth_max = all.depth_max;
-            hdr->depth_inv_min = all.depth_inv_min;
-        }
-        if (threadIdx.x >= gridDim.x && threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
-    }
+    // every overflow slot the host reads is written: this workgroup's own below, the unused ones here
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool live = c <= kDepthBuckets;
@@ -393,12 +379,11 @@ void run_header_reduce(int P, GeomState& g, hipStream_t s)
     header_reduce_kernel<<<1, 1024, 0, s>>>(g.partials, (int)pre_partials((size_t)P), g.header);
 }
 
-void run_depth_histogram(int P, GeomState& g, hipStream_t s)
+void run_depth_histogram(int P, GeomState& g, hipStream_t s)   // after run_header_reduce (depth range)
 {
-    const int rows = (int)depth_hist_rows((size_t)P), np = (int)pre_partials((size_t)P);
-    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, g.hist_rows);
-    depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header,
-                                                                g.partials, np);
+    const int rows = (int)depth_hist_rows((size_t)P);
+    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.header, g.hist_rows);
+    depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header);
 }
 
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)

@@ -14,6 +14,7 @@
 //   * `debug` makes every stage synchronise and surface its error (the reference's CHECK_CUDA).
 #include "../../include/r3dgs_rasterizer.h"
 
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -102,8 +103,8 @@ struct StageTimer {
 // pinned word, per (host thread, device).  The copy is ordered after the preprocess kernel by an event and
 // runs beside the depth sort, so the structural host round trip of the forward is hidden behind GPU work.
 struct ReadbackCtx {
-    hipStream_t side = nullptr;
-    hipEvent_t after_pre = nullptr, copied = nullptr, colored = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t after_pre = nullptr, copied = nullptr, colored = nullptr, after_hist = nullptr, copied2 = nullptr;
     r3::GeomHeader* pinned = nullptr;
 };
 ReadbackCtx& readback_ctx()
@@ -113,7 +114,15 @@ ReadbackCtx& readback_ctx()
     R3_HIP(hipGetDevice(&dev));
     ReadbackCtx& c = per_device[dev];
     if (!c.side) {
-        R3_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        // the SH -> RGB kernel on `side` is bandwidth-heavy filler under the latency-bound sort kernels of the
+        // caller's stream: lowest priority, so that their workgroups are dispatched first (at equal priority the
+        // depth scatter kernel took 46 us instead of 14 us next to it)
+        int prio_low = 0, prio_high = 0;
+        R3_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        R3_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio_low));
+        R3_HIP(hipStreamCreateWithPriority(&c.side2, hipStreamNonBlocking, prio_high));
+        R3_HIP(hipEventCreateWithFlags(&c.after_hist, hipEventDisableTiming));
+        R3_HIP(hipEventCreateWithFlags(&c.copied2, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.copied, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.colored, hipEventDisableTiming));
@@ -206,48 +215,62 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     t0.stop();
     check_launch("preprocess", s, debug);
     StageTimer t1(kDepthSort, s);
-    if (!generic_sort)
-        run_depth_histogram(P, geom, s);   // also writes the header (totals, sort_overflow) the host reads back
-    else
-        run_header_reduce(P, geom, s);
+    // One workgroup turns the preprocess partials into the header: num_rendered, visible count, depth range.  R
+    // does not depend on the depth order, so it starts its way to the host now -- the structural host round trip
+    // (size the binning blob, then enqueue the binning) overlaps the whole depth sort -- and the SH -> RGB kernel
+    // follows it on the side stream, underneath the (latency-bound) sort kernels of the main stream.
+    run_header_reduce(P, geom, s);
     R3_HIP(hipEventRecord(rb.after_pre, s));
     R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
-    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, sizeof(GeomHeader), hipMemcpyDeviceToHost, rb.side));
+    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, offsetof(GeomHeader, sort_overflow), hipMemcpyDeviceToHost, rb.side));
     R3_HIP(hipEventRecord(rb.copied, rb.side));
-    {   // SH -> RGB on the side stream, underneath the depth sort + binning of the main stream
+    {
         StageTimer tc(kColor, rb.side);
         launch_preprocess_color(in, view, geom, rb.side);
         tc.stop();
         R3_HIP(hipEventRecord(rb.colored, rb.side));
     }
-    if (generic_sort)
+    if (generic_sort) {
         run_depth_sort_and_scan(P, geom, s);
-    else
-        run_depth_bucket_sort_and_scan(P, geom, s);  // keeps the GPU busy during the host round trip below
+    } else {
+        run_depth_histogram(P, geom, s);
+        // the bucket-overflow flags follow on a second side stream (the first one is busy with the colours)
+        R3_HIP(hipEventRecord(rb.after_hist, s));
+        R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_hist, 0));
+        R3_HIP(hipMemcpyAsync(rb.pinned->sort_overflow, geom.header->sort_overflow, sizeof(uint32_t) * kOverflowSlots,
+                              hipMemcpyDeviceToHost, rb.side2));
+        R3_HIP(hipEventRecord(rb.copied2, rb.side2));
+        run_depth_bucket_sort_and_scan(P, geom, s);
+    }
     t1.stop();
     // spin on the event instead of hipEventSynchronize: a blocking wait parks the host thread, and on an otherwise
     // idle many-core host its wake-up (deep C-state exit) was observed to cost more than the whole forward
-    for (;;) {
-        const hipError_t q = hipEventQuery(rb.copied);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) R3_HIP(q);
-    }
+    auto spin = [](hipEvent_t ev) {
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) R3_HIP(q);
+        }
+    };
+    spin(rb.copied);
     const uint32_t R = rb.pinned->num_rendered;
-    bool overflow = false;
-    for (int k = 0; k < kOverflowSlots; k++) overflow |= rb.pinned->sort_overflow[k] != 0;
-    if (!generic_sort && overflow) {
-        // a depth bucket did not fit one workgroup's LDS (many splats at one depth): redo with the generic sort
-        StageTimer t1b(kDepthSort, s);
-        run_depth_sort_and_scan(P, geom, s);
-        t1b.stop();
-    }
-    check_launch("depth sort + scan", s, debug);
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
-
     const size_t tile_temp = cached_tile_temp(R);
-    char* bptr = binningBuffer(required_bytes<BinState>((size_t)R, tile_temp), binning_user);
+    char* bptr = binningBuffer(required_bytes<BinState>((size_t)R, tile_temp), binning_user);   // host work, overlapped
     if (!bptr) throw Error("binning allocator returned NULL");
     BinState bin = BinState::carve(bptr, (size_t)R, tile_temp);
+    if (!generic_sort) {
+        spin(rb.copied2);
+        bool overflow = false;
+        for (int k = 0; k < kOverflowSlots; k++) overflow |= rb.pinned->sort_overflow[k] != 0;
+        if (overflow) {
+            // a depth bucket did not fit one workgroup's LDS (many splats at one depth): redo with the generic sort
+            StageTimer t1b(kDepthSort, s);
+            run_depth_sort_and_scan(P, geom, s);
+            t1b.stop();
+        }
+    }
+    check_launch("depth sort + scan", s, debug);
 
     StageTimer t2(kBinning, s);
     run_tile_binning(P, (int)R, gx, gy, geom, bin, img, s);

@@ -12,6 +12,8 @@
 // lanes striding 192 B apart through global memory.  Output is one 48-byte record per visible Gaussian (GRec),
 // the tile rect, the depth sort key and tiles_touched.
 // Built with -ffp-contract=off: radii / rects / tiles_touched are bit-exact against the oracle.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace r3 {
@@ -145,15 +147,19 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
 // SH -> RGB (forward.cu:105-159, ragged variant :19-100) or copy of the precomputed colours into the
 // records of the visible Gaussians.  Streams the SH tensor (192 B per Gaussian at degree 3): the wave's 64 rows
 // are one contiguous span, staged through LDS with dwordx4 loads, evaluated per lane from LDS.
+// Launched as a SMALL persistent grid (launch_preprocess_color): the kernel is bandwidth-bound filler next to the
+// latency-bound depth-sort kernels of the main stream, and a full grid's LDS footprint (3 x 49 KB per CU) left their
+// workgroups no room -- the depth scatter kernel took 46 us instead of 14 us beside it.
 template <bool RAGGED>
-__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a)
+__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a, int n_blocks)
 {
     __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
-    const int i = blockIdx.x * kPreBlock + tid;
+  for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int i = blk * kPreBlock + tid;
     const bool valid = i < P;
-    const int wave_first = blockIdx.x * kPreBlock + wave * 64;
+    const int wave_first = blk * kPreBlock + wave * 64;
     const bool vis = valid && a.tiles[i] > 0;
     const bool need_sh = vis && (a.in.colors_precomp == nullptr);
 
@@ -187,14 +193,30 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a)
         const float* src = a.in.shs + span_first;
         float* dst = s_sh[wave];
         if (((span_first | span_len) & 3) == 0) {  // 16-B aligned span (always true for M = 16): dwordx4 loads
+            // Twelve loads per lane cover a full degree-3 span (64 rows x 192 B).  They are issued back to back before the
+            // first LDS store: with one load in flight per wave (load, wait, store, next load) the kernel ran at the
+            // 2 TB/s that 12 waves/CU x 1 KB per memory latency allow.
             const float4* src4 = reinterpret_cast<const float4*>(src);
-            for (int e4 = lane; e4 < (span_len >> 2); e4 += 64) {
-                const float4 v = src4[e4];
-                const int e = e4 << 2;
-                dst[skew(e)] = v.x;
-                dst[skew(e + 1)] = v.y;
-                dst[skew(e + 2)] = v.z;
-                dst[skew(e + 3)] = v.w;
+            const int n4 = span_len >> 2;
+            constexpr int kBatch = 12;
+            for (int base = 0; base < n4; base += 64 * kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const int e4 = base + k * 64 + lane;
+                    v[k] = e4 < n4 ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const int e4 = base + k * 64 + lane;
+                    if (e4 < n4) {
+                        const int e = e4 << 2;
+                        dst[skew(e)] = v[k].x;
+                        dst[skew(e + 1)] = v[k].y;
+                        dst[skew(e + 2)] = v[k].z;
+                        dst[skew(e + 3)] = v[k].w;
+                    }
+                }
             }
         } else {
             for (int e = lane; e < span_len; e += 64) dst[skew(e)] = src[e];
@@ -221,6 +243,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a)
         r->b = rgb[2];
         if (cbits) r->width_clamp |= cbits << 16;  // same lane wrote the width in the geometry kernel
     }
+    __syncthreads();   // the staging buffer is reused by the next round
+  }
 }
 
 void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s)
@@ -250,10 +274,15 @@ void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomSt
     a.partials = g.partials;
     a.radii = nullptr;
     const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
+    static const int max_grid = [] {   // R3DGS_COLOR_GRID: persistent-grid size (0 = one workgroup per 256 Gaussians)
+        const char* v = getenv("R3DGS_COLOR_GRID");
+        return v ? atoi(v) : 512;
+    }();
+    const int grid = max_grid > 0 && blocks > max_grid ? max_grid : blocks;
     if (in.coeffs_num)
-        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), 0, s, a, blocks);
     else
-        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(blocks), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), 0, s, a, blocks);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2
