@@ -105,6 +105,7 @@ struct StageTimer {
 struct ReadbackCtx {
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t after_pre = nullptr, copied = nullptr, colored = nullptr, after_hist = nullptr, copied2 = nullptr;
+    hipEvent_t geom_done = nullptr;
     r3::GeomHeader* pinned = nullptr;
 };
 ReadbackCtx& readback_ctx()
@@ -121,6 +122,7 @@ ReadbackCtx& readback_ctx()
         R3_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         R3_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio_low));
         R3_HIP(hipStreamCreateWithPriority(&c.side2, hipStreamNonBlocking, prio_high));
+        R3_HIP(hipEventCreateWithFlags(&c.geom_done, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.after_hist, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.copied2, hipEventDisableTiming));
         R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
@@ -214,27 +216,30 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     launch_preprocess(in, view, geom, radii, s);
     t0.stop();
     check_launch("preprocess", s, debug);
-    StageTimer t1(kDepthSort, s);
-    // One workgroup turns the preprocess partials into the header: num_rendered, visible count, depth range.  R
-    // does not depend on the depth order, so it starts its way to the host now -- the structural host round trip
-    // (size the binning blob, then enqueue the binning) overlaps the whole depth sort -- and the SH -> RGB kernel
-    // follows it on the side stream, underneath the (latency-bound) sort kernels of the main stream.
-    run_header_reduce(P, geom, s);
-    R3_HIP(hipEventRecord(rb.after_pre, s));
-    R3_HIP(hipStreamWaitEvent(rb.side, rb.after_pre, 0));
-    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, offsetof(GeomHeader, sort_overflow), hipMemcpyDeviceToHost, rb.side));
-    R3_HIP(hipEventRecord(rb.copied, rb.side));
+    // The SH -> RGB kernel needs only the geometry kernel's visibility: it starts now on the low-priority side stream,
+    // underneath the (latency-bound) header / depth-sort kernels of the main stream.
+    R3_HIP(hipEventRecord(rb.geom_done, s));
+    R3_HIP(hipStreamWaitEvent(rb.side, rb.geom_done, 0));
     {
         StageTimer tc(kColor, rb.side);
         launch_preprocess_color(in, view, geom, rb.side);
         tc.stop();
         R3_HIP(hipEventRecord(rb.colored, rb.side));
     }
+    StageTimer t1(kDepthSort, s);
+    // One workgroup turns the preprocess partials into the header: num_rendered, visible count, depth range.  R
+    // does not depend on the depth order, so it starts its way to the host now (second side stream): the structural
+    // host round trip -- size the binning blob, then enqueue the binning -- overlaps the whole depth sort.
+    run_header_reduce(P, geom, s);
+    R3_HIP(hipEventRecord(rb.after_pre, s));
+    R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_pre, 0));
+    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, offsetof(GeomHeader, sort_overflow), hipMemcpyDeviceToHost, rb.side2));
+    R3_HIP(hipEventRecord(rb.copied, rb.side2));
     if (generic_sort) {
         run_depth_sort_and_scan(P, geom, s);
     } else {
         run_depth_histogram(P, geom, s);
-        // the bucket-overflow flags follow on a second side stream (the first one is busy with the colours)
+        // the bucket-overflow flags follow on the same copy stream
         R3_HIP(hipEventRecord(rb.after_hist, s));
         R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_hist, 0));
         R3_HIP(hipMemcpyAsync(rb.pinned->sort_overflow, geom.header->sort_overflow, sizeof(uint32_t) * kOverflowSlots,
