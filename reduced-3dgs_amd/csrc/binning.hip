@@ -105,9 +105,9 @@ __device__ inline DepthRange make_depth_range(uint32_t mx, uint32_t mi)
     r.scale = zmax > zmin ? (float)kDepthBuckets / (zmax - zmin) : 0.f;   // no visible Gaussian: nothing is looked up
     return r;
 }
-__device__ inline DepthRange load_depth_range(const GeomHeader* hdr)
+__device__ inline DepthRange load_depth_range(const DepthSortScratch* ds)
 {
-    return make_depth_range(hdr->depth_max, hdr->depth_inv_min);
+    return make_depth_range(ds->depth_max, ds->depth_inv_min);
 }
 // Sum / max of the preprocess workgroups' partials by one workgroup of 256 or 1024 threads (s_red: 4 x 16 words).
 __device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
@@ -152,12 +152,21 @@ __device__ inline int depth_bucket(uint32_t key, DepthRange r)
 }
 
 __global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
-                                                         const uint32_t* __restrict__ tiles, const GeomHeader* hdr,
-                                                         unsigned long long* __restrict__ rows)
+                                                         const uint32_t* __restrict__ tiles,
+                                                         const PrePartial* __restrict__ parts, int n_parts,
+                                                         DepthSortScratch* ds, unsigned long long* __restrict__ rows)
 {
     __shared__ unsigned long long hist[kDepthBuckets + 1];
+    __shared__ uint32_t s_red[16][4];
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
-    const DepthRange rng = load_depth_range(hdr);
+    // every workgroup derives the depth range from the preprocess partials itself (the header is being produced on
+    // another stream at the same time); workgroup 0 leaves it for the scatter kernel
+    const PrePartial all = reduce_partials(parts, n_parts, s_red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ds->depth_max = all.depth_max;
+        ds->depth_inv_min = all.depth_inv_min;
+    }
+    const DepthRange rng = make_depth_range(all.depth_max, all.depth_inv_min);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread], tv[kHistPerThread];
 #pragma unroll
@@ -234,7 +243,6 @@ __global__ __launch_bounds__(1024) void header_reduce_kernel(const PrePartial* _
         hdr->depth_max = all.depth_max;
         hdr->depth_inv_min = all.depth_inv_min;
     }
-    if (threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
 }
 
 // Exclusive scan of the 1025 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256) void depth_scatter_kernel(int P, const uint32_
         slot0[b] += mybase[b];
         rank[b] = 0;
     }
-    const DepthRange rng = load_depth_range(hdr);
+    const DepthRange rng = load_depth_range(ds);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread];
 #pragma unroll
@@ -379,10 +387,10 @@ void run_header_reduce(int P, GeomState& g, hipStream_t s)
     header_reduce_kernel<<<1, 1024, 0, s>>>(g.partials, (int)pre_partials((size_t)P), g.header);
 }
 
-void run_depth_histogram(int P, GeomState& g, hipStream_t s)   // after run_header_reduce (depth range)
+void run_depth_histogram(int P, GeomState& g, hipStream_t s)
 {
-    const int rows = (int)depth_hist_rows((size_t)P);
-    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.header, g.hist_rows);
+    const int rows = (int)depth_hist_rows((size_t)P), np = (int)pre_partials((size_t)P);
+    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, g.dsort, g.hist_rows);
     depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header);
 }
 

@@ -226,15 +226,26 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
         tc.stop();
         R3_HIP(hipEventRecord(rb.colored, rb.side));
     }
-    StageTimer t1(kDepthSort, s);
-    // One workgroup turns the preprocess partials into the header: num_rendered, visible count, depth range.  R
-    // does not depend on the depth order, so it starts its way to the host now (second side stream): the structural
-    // host round trip -- size the binning blob, then enqueue the binning -- overlaps the whole depth sort.
-    run_header_reduce(P, geom, s);
-    R3_HIP(hipEventRecord(rb.after_pre, s));
-    R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_pre, 0));
+    // The header the host needs: one workgroup turns the preprocess partials into num_rendered / visible count and
+    // the 16 bytes start their way to the host on the copy stream.  R does not depend on the depth order, so the
+    // structural host round trip -- size the binning blob, then enqueue the binning -- overlaps the whole depth sort.
+    // (Running the reduction on the copy stream as well keeps 12 us off the main chain but delays R by the
+    // cross-queue latency: 991 vs 1010 it/s on the same box, R3DGS_HEADER_SIDE=1 selects it.)
+    static const bool header_on_main = [] {
+        const char* v = getenv("R3DGS_HEADER_SIDE");
+        return !(v && v[0] == '1');
+    }();
+    if (header_on_main) {
+        run_header_reduce(P, geom, s);
+        R3_HIP(hipEventRecord(rb.after_pre, s));
+        R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_pre, 0));
+    } else {
+        R3_HIP(hipStreamWaitEvent(rb.side2, rb.geom_done, 0));
+        run_header_reduce(P, geom, rb.side2);
+    }
     R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, offsetof(GeomHeader, sort_overflow), hipMemcpyDeviceToHost, rb.side2));
     R3_HIP(hipEventRecord(rb.copied, rb.side2));
+    StageTimer t1(kDepthSort, s);
     if (generic_sort) {
         run_depth_sort_and_scan(P, geom, s);
     } else {

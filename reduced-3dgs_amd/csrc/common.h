@@ -52,6 +52,7 @@ constexpr int kDepthBuckets = 1024;
 constexpr int kBucketCap = 4096;   // (key, id) pairs one workgroup sorts in LDS (32 KB)
 constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
 struct DepthSortScratch {
+    uint32_t depth_max, depth_inv_min, pad_[2];   // depth range of the visible Gaussians (histogram workgroup 0)
     unsigned long long total[kDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [kDepthBuckets] = culled
     uint32_t start[kDepthBuckets + 2];       // exclusive scan of the bucket sizes
     uint32_t tile_base[kDepthBuckets + 2];   // exclusive scan of the buckets' tiles_touched sums
