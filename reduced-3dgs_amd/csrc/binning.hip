@@ -154,14 +154,21 @@ __device__ inline int depth_bucket(uint32_t key, DepthRange r)
 __global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
                                                          const uint32_t* __restrict__ tiles,
                                                          const PrePartial* __restrict__ parts, int n_parts,
-                                                         DepthSortScratch* ds, unsigned long long* __restrict__ rows)
+                                                         const GeomHeader* hdr, DepthSortScratch* ds,
+                                                         unsigned long long* __restrict__ rows)
 {
     __shared__ unsigned long long hist[kDepthBuckets + 1];
     __shared__ uint32_t s_red[16][4];
     for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
-    // every workgroup derives the depth range from the preprocess partials itself (the header is being produced on
-    // another stream at the same time); workgroup 0 leaves it for the scatter kernel
-    const PrePartial all = reduce_partials(parts, n_parts, s_red);
+    // depth range: from the header if it is already there, else every workgroup derives it from the preprocess
+    // partials itself (header being produced on another stream); workgroup 0 leaves it for the scatter kernel
+    PrePartial all;
+    if (hdr) {   // the header was reduced on this stream before the launch
+        all.depth_max = hdr->depth_max;
+        all.depth_inv_min = hdr->depth_inv_min;
+    } else {
+        all = reduce_partials(parts, n_parts, s_red);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ds->depth_max = all.depth_max;
         ds->depth_inv_min = all.depth_inv_min;
@@ -387,10 +394,11 @@ void run_header_reduce(int P, GeomState& g, hipStream_t s)
     header_reduce_kernel<<<1, 1024, 0, s>>>(g.partials, (int)pre_partials((size_t)P), g.header);
 }
 
-void run_depth_histogram(int P, GeomState& g, hipStream_t s)
+void run_depth_histogram(int P, GeomState& g, bool header_ready, hipStream_t s)
 {
     const int rows = (int)depth_hist_rows((size_t)P), np = (int)pre_partials((size_t)P);
-    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, g.dsort, g.hist_rows);
+    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, header_ready ? g.header : nullptr,
+                                           g.dsort, g.hist_rows);
     depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header);
 }
 

@@ -249,7 +249,7 @@ int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc
     if (generic_sort) {
         run_depth_sort_and_scan(P, geom, s);
     } else {
-        run_depth_histogram(P, geom, s);
+        run_depth_histogram(P, geom, header_on_main, s);
         // the bucket-overflow flags follow on the same copy stream
         R3_HIP(hipEventRecord(rb.after_hist, s));
         R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_hist, 0));

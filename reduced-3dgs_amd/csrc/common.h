@@ -273,7 +273,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view, bool* p
 // depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])
 void run_header_reduce(int P, GeomState& g, hipStream_t s);                // generic path: partials -> header
 void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);          // generic (rocPRIM) path
-void run_depth_histogram(int P, GeomState& g, hipStream_t s);              // bucketed path, step 1 (sets sort_overflow)
+void run_depth_histogram(int P, GeomState& g, bool header_ready, hipStream_t s);  // bucketed path, step 1 (sets sort_overflow)
 void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s);   // bucketed path, steps 2-4
 // rasterizer_impl.cu:43-58 getHigherMsb
 inline uint32_t higher_msb(uint32_t n)
