@@ -176,6 +176,10 @@ def main():
                 for c in cams]
     exch = ViewParallelExchange({"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)},
                                 P, device) if world > 1 else None
+    if exch is not None and os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
+        _C.set_gradient_arena(exch.arena)   # parameter gradients are written straight into the exchange buffer
+
+    born_in_buffer = [None]
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
@@ -190,7 +194,12 @@ def main():
                                                settings[cam_index(step)], 0.0)
         color.backward(dl)
         if exch is not None:
-            exch.pack({k: v.grad for k, v in leaves.items()}, means2D.grad, radii)
+            grads = {k: v.grad for k, v in leaves.items()}
+            if step == 0:   # reported once: did autograd keep the arena views as .grad (zero-copy pack)?
+                born_in_buffer[0] = sum(exch.arena(k, tuple(g_.shape)) is not None and
+                                        g_.data_ptr() == exch.arena(k, tuple(g_.shape)).data_ptr()
+                                        for k, g_ in grads.items())
+            exch.pack(grads, means2D.grad, radii)
             exch.exchange()
         return radii
 
@@ -287,7 +296,8 @@ def main():
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                    "exchange": "RCCL reduce-scatter+all-gather of 59 fp32 grads + 2 stats / Gaussian, MAX radii"
-                   if world > 1 else None},
+                   if world > 1 else None,
+                   "grads_born_in_exchange_buffer": born_in_buffer[0]},
         "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
         "render_fps": round(args.steps / render_s, 1),
         "roofline": roofline,

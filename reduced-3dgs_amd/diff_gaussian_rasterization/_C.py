@@ -204,6 +204,18 @@ def rasterize_gaussians_variableSH_bands(background, means3D, colors, opacity, s
                            tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos, prefiltered, debug)
 
 
+_grad_arena = None
+
+
+def set_gradient_arena(fn):
+    """Extension for multi-GPU training (not in the reference): `fn(name, shape) -> float32 CUDA tensor or None`
+    supplies the storage of the backward's outputs (names: means2D, colors, opacity, means3D, cov3D, sh, scales,
+    rotations).  A view-parallel trainer hands out views of its flat all-reduce buffer, so the gradients are born
+    inside it and no packing copy is needed (multiview.ViewParallelExchange.arena).  None restores torch.empty."""
+    global _grad_arena
+    _grad_arena = fn
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
                                  degrees, campos, geomBuffer, R, binningBuffer, imageBuffer, lambda_sh_sparsity,
@@ -218,10 +230,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P == 0:
         z = lambda *s: torch.zeros(s, **opts)
         return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
-    e = lambda *s: torch.empty(s, **opts)  # every element is written by the library
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity = e(P, 3), e(P, 3), e(P, 3), e(P, 1)
-    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
-    dL_dconic = e(P, 2, 2) if _want_conic else None
+    def e(name, *s):  # every element is written by the library
+        if _grad_arena is not None:
+            t = _grad_arena(name, s)
+            if t is not None:
+                if tuple(t.shape) != s or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                    raise RuntimeError(f"gradient arena returned an unusable tensor for {name}")
+                return t
+        return torch.empty(s, **opts)
+    dL_dmeans3D, dL_dmeans2D = e("means3D", P, 3), e("means2D", P, 3)
+    dL_dcolors, dL_dopacity = e("colors", P, 3), e("opacity", P, 1)
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e("cov3D", P, 6), e("sh", P, M, 3), e("scales", P, 3), e("rotations", P, 4)
+    dL_dconic = torch.empty((P, 2, 2), **opts) if _want_conic else None
     bg, m3 = _dev_f32(background, dev), _dev_f32(means3D, dev)
     col, sc, rot, cov = (_dev_f32(t, dev) for t in (colors, scales, rotations, cov3D_precomp))
     vm, pm, cp = _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev), _dev_f32(campos, dev)

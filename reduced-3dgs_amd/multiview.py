@@ -43,10 +43,21 @@ class ViewParallelExchange:
         self.radii = torch.zeros(P, dtype=torch.int32, device=device)
         self.two_phase = two_phase and self.world > 1
 
+    def arena(self, name, shape):
+        """For diff_gaussian_rasterization._C.set_gradient_arena: the rasterizer's backward then writes the parameter
+        gradients straight into this exchange buffer and pack() has nothing to copy for them."""
+        hit = self.slices.get(name)
+        if hit is None or tuple(hit[2]) != tuple(shape):
+            return None
+        return self.flat[hit[0]:hit[1]].view(hit[2])
+
     def pack(self, grads, viewspace_grad, radii):
         """grads: dict name -> tensor (this rank's view). viewspace_grad: [P,3] grad of the means2D dummy."""
         for name, (a, b, _shape) in self.slices.items():
-            self.flat[a:b].copy_(grads[name].reshape(-1))
+            g = grads[name]
+            if g.data_ptr() == self.flat.data_ptr() + 4 * a and g.is_contiguous():
+                continue   # born in the buffer (arena)
+            self.flat[a:b].copy_(g.reshape(-1))
         vis = radii > 0
         P, o = self.P, self.stat_off
         self.flat[o:o + P].copy_(torch.norm(viewspace_grad[:, :2], dim=-1) * vis)

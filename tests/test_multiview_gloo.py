@@ -30,7 +30,7 @@ def _rank_inputs(rank):
     return grads, vgrad, radii
 
 
-def _worker(rank, world, port, two_phase, q):
+def _worker(rank, world, port, two_phase, q, arena=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,19 @@ def _worker(rank, world, port, two_phase, q):
     from multiview import ViewParallelExchange
     ex = ViewParallelExchange(SHAPES, P, torch.device("cpu"), two_phase=two_phase)
     grads, vgrad, radii = _rank_inputs(rank)
+    if arena:   # gradients "born" in the exchange buffer, as the rasterizer's backward does with set_gradient_arena
+        born = {}
+        for k, v in grads.items():
+            t = ex.arena(k, tuple(v.shape))
+            assert t is not None and t.data_ptr() == ex.flat.data_ptr() + 4 * ex.slices[k][0]
+            t.copy_(v)
+            born[k] = t
+        assert ex.arena("cov3D", (P, 6)) is None and ex.arena("sh", (P, 4, 3)) is None
+        grads = born
+        sentinel = ex.flat.clone()
     ex.pack(grads, vgrad, radii)
+    if arena:   # pack() had nothing to copy for the parameter gradients
+        assert torch.equal(ex.flat[:ex.stat_off], sentinel[:ex.stat_off])
     ex.exchange()
     out, gnorm, vis, rmax = ex.unpack()
     q.put((rank, {k: v.clone().numpy() for k, v in out.items()}, gnorm.clone().numpy(), vis.clone().numpy(),
@@ -48,12 +60,12 @@ def _worker(rank, world, port, two_phase, q):
     dist.destroy_process_group()
 
 
-def _run(two_phase):
+def _run(two_phase, arena=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, two_phase, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, two_phase, q, arena)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
@@ -76,3 +88,7 @@ def test_exchange_reduce_scatter_all_gather():
 
 def test_exchange_single_all_reduce():
     _run(two_phase=False)
+
+
+def test_exchange_with_gradient_arena():
+    _run(two_phase=True, arena=True)
