@@ -65,6 +65,14 @@ size_t r3dgs_knn_workspace_bytes(int P);
 int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, float* mean_dist3, char* workspace,
               void* stream);
 
+/* Per-view densification statistics of a view-parallel training step (no reference equivalent: the reference is
+ * single-GPU; this is what train.py:134 and scene/gaussian_model.py:693-695 accumulate per view), fused into one launch:
+ *   grad_norm[i] = radii[i] > 0 ? ||viewspace_grad[i, 0:2]|| : 0      visible[i] = radii[i] > 0 ? 1 : 0
+ *   radii_out[i] = radii[i]
+ * viewspace_grad: [P,3] (gradient of the means2D dummy).  Outputs may live in a flat exchange buffer. */
+int r3dgs_pack_view_stats(int P, const float* viewspace_grad, const int* radii, float* grad_norm, float* visible,
+                          int* radii_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

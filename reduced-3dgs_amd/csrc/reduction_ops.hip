@@ -142,6 +142,21 @@ __global__ __launch_bounds__(kBlock) void min_redundancy_kernel(long long total,
     atomicMin(&min_redundancy[neighbours[pair]], redundancy[pair / knn]);
 }
 
+// densification statistics of one view, for the view-parallel exchange (multiview.py)
+__global__ __launch_bounds__(kBlock) void pack_view_stats_kernel(int P, const float* __restrict__ vg,
+                                                                 const int* __restrict__ radii,
+                                                                 float* __restrict__ grad_norm,
+                                                                 float* __restrict__ visible, int* __restrict__ radii_out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    const float gx = vg[3 * i], gy = vg[3 * i + 1];
+    grad_norm[i] = r > 0 ? sqrtf(gx * gx + gy * gy) : 0.f;
+    visible[i] = r > 0 ? 1.f : 0.f;
+    radii_out[i] = r;
+}
+
 int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -203,6 +218,19 @@ int r3dgs_min_redundancy(int P, int knn, const int* redundancy, const int* neigh
             min_redundancy_kernel<<<grid_for((long long)P * knn), kBlock, 0, s>>>((long long)P * knn, knn, redundancy,
                                                                                     neighbours, mask, min_redundancy);
         r3::check_launch("min redundancy", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_pack_view_stats(int P, const float* viewspace_grad, const int* radii, float* grad_norm, float* visible,
+                          int* radii_out, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (P <= 0) return 0;
+        if (!viewspace_grad || !radii || !grad_norm || !visible || !radii_out) throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        pack_view_stats_kernel<<<grid_for(P), kBlock, 0, s>>>(P, viewspace_grad, radii, grad_norm, visible, radii_out);
+        r3::check_launch("pack view stats", s, false);
         return 0;
     });
 }

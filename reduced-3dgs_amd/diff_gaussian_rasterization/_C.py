@@ -55,6 +55,8 @@ _lib.r3dgs_kmeans_workspace_bytes.restype = C.c_size_t
 _lib.r3dgs_kmeans_workspace_bytes.argtypes = [_i, _i]
 _lib.r3dgs_kmeans.restype = _i
 _lib.r3dgs_kmeans.argtypes = [_i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]
+_lib.r3dgs_pack_view_stats.restype = _i
+_lib.r3dgs_pack_view_stats.argtypes = [_i] + [_vp] * 6
 _lib.r3dgs_profile_enable.argtypes = [_i]
 _lib.r3dgs_profile_stage_name.restype = C.c_char_p
 _lib.r3dgs_profile_stage_name.argtypes = [_i]
@@ -425,3 +427,20 @@ def kmeans_cuda(values, centers, tol, max_iterations, _want_iterations=False):
     if _want_iterations:
         return ids, new_centers, iters
     return ids, new_centers
+
+
+def pack_view_stats(viewspace_grad, radii, grad_norm_out, visible_out, radii_out):
+    """One launch for the per-view densification statistics of a view-parallel step (include/r3dgs_reduction.h
+    r3dgs_pack_view_stats): ||viewspace_grad[:, :2]|| where radii > 0, the visibility indicator and a copy of radii,
+    written into caller-provided (exchange-buffer) tensors."""
+    dev = _need_gpu(viewspace_grad, "pack_view_stats")
+    P = int(radii.numel())
+    if P == 0:
+        return
+    vg, rd = _dev_f32(viewspace_grad, dev), _dev_i32(radii, dev)
+    for t, dt in ((grad_norm_out, torch.float32), (visible_out, torch.float32), (radii_out, torch.int32)):
+        if t.device != dev or t.dtype != dt or t.numel() != P or not t.is_contiguous():
+            raise RuntimeError("pack_view_stats: outputs must be contiguous [P] tensors on the same GPU")
+    with torch.cuda.device(dev):
+        _check(_lib.r3dgs_pack_view_stats(P, _ptr(vg), _ptr(rd), _ptr(grad_norm_out), _ptr(visible_out), _ptr(radii_out),
+                                          _stream()), "pack_view_stats")

@@ -58,8 +58,12 @@ class ViewParallelExchange:
             if g.data_ptr() == self.flat.data_ptr() + 4 * a and g.is_contiguous():
                 continue   # born in the buffer (arena)
             self.flat[a:b].copy_(g.reshape(-1))
-        vis = radii > 0
         P, o = self.P, self.stat_off
+        if self.flat.is_cuda and viewspace_grad.is_contiguous() and radii.dtype == torch.int32:
+            from diff_gaussian_rasterization import _C   # one fused launch instead of ~8 small torch kernels
+            _C.pack_view_stats(viewspace_grad, radii, self.flat[o:o + P], self.flat[o + P:o + 2 * P], self.radii)
+            return
+        vis = radii > 0
         self.flat[o:o + P].copy_(torch.norm(viewspace_grad[:, :2], dim=-1) * vis)
         self.flat[o + P:o + 2 * P].copy_(vis.to(torch.float32))
         self.radii.copy_(radii)

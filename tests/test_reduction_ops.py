@@ -289,3 +289,30 @@ def test_gpu_dist_cuda2_and_scene_scale():
     assert np.array_equal(distCUDA2(_dev(pts[:5000])).cpu().numpy(), small)
     with pytest.raises(RuntimeError):
         distCUDA2(torch.zeros(10, 3))                 # no CPU path
+
+
+@pytest.mark.gpu
+def test_gpu_pack_view_stats_and_exchange_pack():
+    """The fused per-view statistics kernel against the torch expressions it replaces, directly and through
+    ViewParallelExchange.pack (world size 1)."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    from multiview import ViewParallelExchange
+    P = 10_007
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vg = torch.randn(P, 3, generator=g, device="cuda")
+    radii = torch.randint(0, 50, (P,), generator=g, device="cuda", dtype=torch.int32)
+    radii[torch.rand(P, generator=g, device="cuda") < 0.3] = 0
+    n, v, r = torch.empty(P, device="cuda"), torch.empty(P, device="cuda"), torch.empty(P, device="cuda", dtype=torch.int32)
+    _C.pack_view_stats(vg, radii, n, v, r)
+    vis = radii > 0
+    want = torch.sqrt(vg[:, 0] * vg[:, 0] + vg[:, 1] * vg[:, 1]) * vis
+    assert torch.allclose(n, want, rtol=1e-6, atol=0) and torch.equal(v, vis.float()) and torch.equal(r, radii)
+    shapes = {"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)}
+    ex = ViewParallelExchange(shapes, P, torch.device("cuda"))
+    grads = {k: torch.randn((P,) + s, generator=g, device="cuda") for k, s in shapes.items()}
+    ex.pack(grads, vg, radii)
+    out, gnorm, visible, rmax = ex.unpack()
+    for k in shapes:
+        assert torch.equal(out[k], grads[k])
+    assert torch.allclose(gnorm, want, rtol=1e-6, atol=0) and torch.equal(visible, vis.float()) and torch.equal(rmax, radii)
