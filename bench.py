@@ -51,14 +51,17 @@ def stage_bytes(P, R, N, Tn, Kbar):
     }
 
 
-# kernels that make up each stage (names as rocprofv3 reports them, without arguments)
+# kernels that make up each stage (names as rocprofv3 reports them, without arguments) and launches per stage
 STAGE_KERNELS = {
-    "preprocess_fwd": ["r3::preprocess_geom_kernel"],
-    "sh_color_overlapped": ["r3::preprocess_color_kernel<false>"],
-    "tile_binning": ["r3::emit_pairs_kernel", "r3::tile_ranges_kernel"],
-    "blend_fwd": ["r3::blend_fwd_kernel<2, false>"],
-    "blend_bwd": ["r3::blend_bwd_kernel<4>", "r3::pair_reduce_kernel"],
-    "preprocess_bwd": ["r3::preprocess_bwd_kernel"],
+    "preprocess_fwd": [("r3::preprocess_geom_kernel", 1)],
+    "sh_color_overlapped": [("r3::preprocess_color_kernel<false>", 1)],
+    "depth_sort_scan": [("r3::header_reduce_kernel", 1), ("r3::depth_hist_kernel", 1), ("r3::depth_colscan_kernel", 1),
+                        ("r3::depth_scatter_kernel", 1), ("r3::depth_bucket_sort_kernel", 1)],
+    "tile_binning": [("r3::emit_pairs_kernel", 1), ("r3::radix_digit_scan_kernel", 2), ("r3::radix_scatter_kernel", 2),
+                     ("r3::radix_hist_kernel", 1), ("r3::tile_ranges_kernel", 1)],
+    "blend_fwd": [("r3::blend_fwd_kernel<2, false>", 1)],
+    "blend_bwd": [("r3::blend_bwd_kernel<4>", 1), ("r3::pair_reduce_kernel", 1)],
+    "preprocess_bwd": [("r3::preprocess_bwd_kernel", 1)],
 }
 
 
@@ -72,10 +75,10 @@ def pmc_traffic(stage, workload):
         return None
     pmc = json.load(open(path))
     total = 0.0
-    for k in STAGE_KERNELS[stage]:
+    for k, launches in STAGE_KERNELS[stage]:
         if k not in pmc or "FETCH_SIZE" not in pmc[k] or "WRITE_SIZE" not in pmc[k]:
             return None
-        total += (2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0
+        total += launches * (2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0
     return int(total)
 
 
