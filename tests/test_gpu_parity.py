@@ -334,9 +334,11 @@ def test_empty_and_all_culled(C_):
 # -------------------------------------------------------------------------------------------------
 # BASELINE.json metric shape: size-independent properties (the oracle needs minutes here)
 # -------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def metric_scene():
-    w = ss.WORKLOADS["metric_500k_1600x1062"]
+@pytest.fixture(scope="module", params=["metric_500k_1600x1062", "garden_like_2M_1600x1062"])
+def metric_scene(request):
+    """The bench workload, and the 2 M-Gaussian one: 21 depth-rank bits + 13 tile bits > 32, i.e. the (tile, id) pair
+    sort, four times the depth-histogram rows, 14.5 M pairs."""
+    w = ss.WORKLOADS[request.param]
     cam = ss.make_camera(w["W"], w["H"], w["f"], None)
     g = ss.make_gaussians(w["P"], cam, seed=0, degree_mode=w["degree_mode"])
     return w, cam, g
@@ -362,6 +364,23 @@ def test_full_size_properties(C_, metric_scene):
     pl = ex["point_list"].to(torch.int64)
     assert bool((pl[1:][same] > pl[:-1][same]).all())
     assert bool(((radii > 0) == (ex["tiles_touched"] > 0)).all())
+    # every Gaussian occupies exactly the tiles of one rectangle, once each, tiles_touched of them (rasterizer_impl.cu:
+    # 106-117), checked from the sorted list alone
+    gx = (W + 15) // 16
+    tx, ty = tile_of % gx, tile_of // gx
+    big = torch.iinfo(torch.int64).max
+
+    def per_gaussian(values, reduce, init):
+        out = torch.full((P,), init, dtype=torch.int64, device=pl.device)
+        return out.scatter_reduce(0, pl, values, reduce=reduce, include_self=True)
+    x0, x1 = per_gaussian(tx, "amin", big), per_gaussian(tx, "amax", -1)
+    y0, y1 = per_gaussian(ty, "amin", big), per_gaussian(ty, "amax", -1)
+    count = torch.bincount(pl, minlength=P)
+    seen = count > 0
+    assert bool((seen == (radii > 0)).all())
+    assert bool((count == ex["tiles_touched"].to(torch.int64)).all())
+    assert bool((((x1 - x0 + 1) * (y1 - y0 + 1))[seen] == count[seen]).all())
+    assert int(torch.unique(keys >> 32 << 32 | pl).numel()) == R                   # no (tile, Gaussian) pair twice
     # idempotence / determinism of the forward
     _, fout2 = hip_forward(C_, black, g, cam, H, W)
     assert fout2[0] == R and torch.equal(fout2[1], color) and torch.equal(fout2[2], radii)
