@@ -9,6 +9,9 @@ Fixtures are data (inputs + expected outputs); no reference source travels.
                      + the scene/cameras.py:54-58 composition                      (reference Python)
  ref_loss_grad.npz : utils/loss_utils.py:17-66 l1_loss/ssim value and d(loss)/d(image) of
                      0.8*L1 + 0.2*(1-SSIM) (train.py:109-110) -- a realistic dL_dout_color
+ ref_cov3d.npz     : utils/general_utils.py:64-110 build_scaling_rotation / strip_symmetric composed as
+                     scene/gaussian_model.py:49-54 build_covariance_from_scaling_rotation -- the 6-float 3D covariance the
+                     render() path passes as cov3D_precomp when compute_cov3D_python is set            (reference Python)
  ref_pixel_size.npz: scene/__init__.py:103-141 find_minimum_projected_pixel_size_python -- the reference's own torch
                      version of the find_minimum_projected_pixel_size operator, run on CPU      (reference Python)
  oracle_case_*.npz : outputs of the repo's own CPU oracle on small seeded scenes (regression
@@ -143,11 +146,35 @@ def ref_pixel_size():
                         pixel_sizes=sizes.numpy())
 
 
+def ref_cov3d():
+    """The reference's Python covariance (it hard-codes device="cuda" in torch.zeros: wrapped to drop it)."""
+    import utils.general_utils as gu
+    rng = np.random.default_rng(17)
+    n = 513
+    scales = np.exp(rng.normal(-3.0, 1.0, (n, 3))).astype(np.float32)
+    rot = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    real_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        out = {}
+        for mod in (1.0, 0.6):
+            L = gu.build_scaling_rotation(mod * torch.tensor(scales), torch.tensor(rot))
+            out[f"cov_mod{mod}"] = gu.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    finally:
+        torch.zeros = real_zeros
+    np.savez_compressed(os.path.join(HERE, "ref_cov3d.npz"), scales=scales, rotations=rot, **out)
+
+
 if __name__ == "__main__":
+    if "--only-cov3d" in sys.argv:
+        ref_cov3d()
+        sys.exit(0)
     if "--only-pixel-size" in sys.argv:
         ref_pixel_size()
         sys.exit(0)
     ref_sh()
+    ref_cov3d()
     ref_pixel_size()
     ref_camera()
     ref_loss()

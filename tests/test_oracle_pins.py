@@ -84,3 +84,34 @@ def test_oracle_reproduces_committed_goldens(golden_dir, name):
     for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         scale = np.abs(z[k]).max() + 1e-30
         assert np.abs(gr[k] - z[k]).max() <= 1e-5 * scale, k
+
+
+@pytest.mark.parametrize("mod", [1.0, 0.6])
+def test_cov3d_matches_reference_python_covariance(golden_dir, mod):
+    """The oracle's scale/rotation -> 3D covariance (forward.cu:207-241 restated) against the reference's own Python
+    version (utils/general_utils.py:64-110 via scene/gaussian_model.py:49-54), fixture made by tests/golden/make_golden.py.
+    Also the precomputed-covariance input path: feeding that fixture as cov3D_precomp must give the same radii/image."""
+    import synth_scene as ss
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "ref_cov3d.npz"))
+    scales, rot, want = z["scales"], z["rotations"], z[f"cov_mod{mod}"]
+    n = scales.shape[0]
+    W, H = 96, 64
+    cam = ss.make_camera(W, H, 80.0, None)
+    rng = np.random.default_rng(1)
+    means = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.6, 0.6, n), rng.uniform(3, 6, n)], 1).astype(np.float32)
+    g = ss.make_gaussians(n, cam, seed=3, degree_mode="all0")
+    args = dict(bg=np.zeros(3, np.float32), means3D=means, colors_precomp=None, opacity=g["opacity"], scale_modifier=mod,
+                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, tan_fovx=cam.tanfovx,
+                tan_fovy=cam.tanfovy, H=H, W=W, sh=g["sh"], degrees=g["degrees"], campos=cam.camera_center)
+    a = orc.forward(scales=scales, rotations=rot, cov3D_precomp=None, **args)
+    vis = a["radii"] > 0
+    assert vis.sum() > 300
+    got = a["state"]["cov3D"]
+    # fp32 products in a different association order: error relative to the matrix's own scale (small off-diagonal
+    # entries are differences of larger terms)
+    scale = np.abs(want[vis]).max(1, keepdims=True)
+    assert (np.abs(got[vis] - want[vis]) <= 2e-6 * scale).all()
+    b = orc.forward(scales=None, rotations=None, cov3D_precomp=want, **args)
+    assert np.array_equal(a["radii"], b["radii"]) or (a["radii"] != b["radii"]).mean() < 0.01   # 1-ulp cov differences
+    assert np.abs(a["color"] - b["color"]).max() < 1e-4
