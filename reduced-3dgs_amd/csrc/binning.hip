@@ -432,21 +432,9 @@ int tile_rank_bits(int P, size_t n_tiles)
 constexpr int kEmitPerBlock = 1024;
 constexpr int kEmitSlice = kEmitPerBlock + 8;
 
-__device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restrict__ a, uint32_t n, uint32_t pos)
-{
-    uint32_t lo = 0, hi = n;  // smallest j in [0, n) with a[j] > pos (n if none)
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] > pos)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    return lo;
-}
-
-// The same search by a whole wave: 64 probes per step, four dependent loads for P = 500k instead of nineteen.
-// All 64 lanes must call it; the result is wave-uniform.
+// Smallest j in [0, n] with a[j] > pos (n if none), a non-decreasing, searched by a whole wave: 64 probes per step,
+// four dependent loads for P = 500k instead of the nineteen of a scalar binary search.  All 64 lanes must call it;
+// the result is wave-uniform.
 __device__ __forceinline__ uint32_t upper_bound_wave(const uint32_t* __restrict__ a, uint32_t n, uint32_t pos, int lane)
 {
     uint32_t lo = 0, hi = n;  // the answer (smallest j with a[j] > pos, n if none) lies in [lo, hi]
@@ -587,16 +575,12 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, cons
     if (threadIdx.x == 255) total[blockIdx.x] = incl;
 }
 
-// FINAL: the last pass also materialises the Gaussian ids of the sorted words (point_list[pos] = order[rank]) --
-// measured slower than doing it in tile_ranges_kernel (the dependent gather lengthens this kernel by 19 us and saves
-// 13 us there), so it is instantiated with FINAL = false only.
-template <bool FINAL>
+// (Materialising point_list[pos] = order[rank] here in the last pass was measured: the dependent gather lengthens this
+// kernel by 19 us and saves 13 us in tile_ranges_kernel, so it stays there.)
 __global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const uint32_t* __restrict__ in,
                                                             uint32_t* __restrict__ out, int shift,
                                                             const uint32_t* __restrict__ base,
-                                                            const uint32_t* __restrict__ total, uint32_t rank_mask,
-                                                            const uint32_t* __restrict__ order,
-                                                            uint32_t* __restrict__ point_list)
+                                                            const uint32_t* __restrict__ total)
 {
     constexpr int kWaves = 4, kRounds = kRadixBlock / 256;
     __shared__ uint32_t s_wcount[kWaves][kRadixBins];   // running per-wave digit counts
@@ -656,9 +640,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const ui
     for (int r = 0; r < kRounds; r++) {
         if (blk + r * 64u + lane < R) {
             const uint32_t d = (key[r] >> shift) & (kRadixBins - 1);
-            const uint32_t pos = s_off[w][d] + lrank[r];
-            out[pos] = key[r];
-            if (FINAL) point_list[pos] = order[key[r] & rank_mask];
+            out[s_off[w][d] + lrank[r]] = key[r];
         }
     }
 }
@@ -731,16 +713,15 @@ void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, I
         // pass 1: low 7 tile bits (counts from the emission kernel), tile_in -> gauss_in (free in the packed sort)
         hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
                            b.radix_total);
-        hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.tile_in, b.gauss_in,
-                           rank_bits, b.radix_base, b.radix_total, 0u, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.tile_in, b.gauss_in, rank_bits,
+                           b.radix_base, b.radix_total);
         // pass 2: the remaining tile bits, gauss_in -> tile_sorted
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, rank_bits + kRadixBits,
                            b.radix_rows);
         hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
                            b.radix_total + kRadixBins);
-        hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, b.tile_sorted,
-                           rank_bits + kRadixBits, b.radix_base, b.radix_total + kRadixBins, 0u, (const uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, b.tile_sorted,
+                           rank_bits + kRadixBits, b.radix_base, b.radix_total + kRadixBins);
     } else if (rank_bits)
         R3_HIP(rocprim::radix_sort_keys(b.temp, bytes, b.tile_in, b.tile_sorted, (size_t)R, rank_bits, rank_bits + bits, s));
     else
