@@ -22,8 +22,7 @@ def test_pmc_traffic_uses_the_committed_counters():
     pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
     for stage, kernels in bench.STAGE_KERNELS.items():
         for name, launches in kernels:
-            if name != "r3::header_reduce_kernel":      # added after the committed counter passes
-                assert name in pmc, name
+            assert name in pmc, name
     t = bench.pmc_traffic("blend_bwd", "metric_500k_1600x1062")
     want = sum((2 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024 for k in ("r3::blend_bwd_kernel<4>", "r3::pair_reduce_kernel"))
     assert t == int(want) and 3e8 < t < 7e8
