@@ -37,10 +37,15 @@ const char* r3dgs_version(void);
 const char* r3dgs_last_error(void);
 
 /* Sizes of the three opaque state blobs (the reference's required<GeometryState>(P) etc.,
- * rasterizer_impl.h:66-72).  Layouts are private to the library. */
+ * rasterizer_impl.h:66-72).  Layouts are private to the library.  The binning blob is sized by a pair capacity
+ * (`reserve`: num_rendered for an exact-size pass, the reservation for r3dgs_forward_reserved); its layout also
+ * depends on (P, width, height) -- 64-bit pair words once tile bits + log2(P) exceed 32.
+ * r3dgs_binning_capacity inverts r3dgs_binning_bytes: the largest capacity whose layout fits `bytes` (it
+ * reproduces the carve of the pass that sized the blob), 0 if none fits, negative on error. */
 size_t r3dgs_geometry_bytes(int P);
-size_t r3dgs_binning_bytes(int num_rendered);
+size_t r3dgs_binning_bytes(int P, int width, int height, int reserve);
 size_t r3dgs_image_bytes(int width, int height);
+int r3dgs_binning_capacity(int P, int width, int height, size_t bytes);
 
 /* Rasterizer::markVisible (rasterizer.h:25-30, rasterizer_impl.cu:149-161): present[i] = view-space z > 0.2.
  * `present` is a device array of P bytes (0/1).  Returns 0 or a negative status. */
@@ -48,8 +53,10 @@ int r3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, con
                        unsigned char* present, void* stream);
 
 /* Rasterizer::forward (rasterizer.h:31-56, rasterizer_impl.cu:359-504).
- * Returns num_rendered (>= 0) or a negative status.  Performs ONE host synchronisation on `stream`
- * (num_rendered sizes the binning blob, like the reference's cudaMemcpy at rasterizer_impl.cu:446).
+ * Returns num_rendered (>= 0) or a negative status.  Exact-size contract of the reference: the binning blob is
+ * requested through the callback once num_rendered is known, i.e. this entry point waits for that one number
+ * (the reference's cudaMemcpy at rasterizer_impl.cu:446) -- by polling host-mapped memory the pass writes, with a
+ * deadline (R3DGS_SYNC_TIMEOUT_MS).  Training loops should use r3dgs_forward_reserved, which never waits.
  *   D        : per-Gaussian SH degree [P] (int32)
  *   M        : SH coefficients per Gaussian in the dense `shs` tensor [P, M, 3] (<= 16)
  *   opacities: RAW (pre-sigmoid); scales: ACTIVATED; rotations: UNIT quaternions (r,x,y,z)
@@ -81,8 +88,50 @@ int r3dgs_inference_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, 
                             int prefiltered, float* out_color, int* out_touched_pixels, float* out_transmittance,
                             int* radii, int calculate_mean_transmittance, int debug, void* stream);
 
+/* ---- asynchronous forward (extension; the hot path) -------------------------------------------------------------
+ * The reference's forward blocks the host in the middle of every pass to size the binning buffer
+ * (rasterizer_impl.cu:441-450).  r3dgs_forward_reserved removes that: the caller passes the three blobs up front
+ * (r3dgs_geometry_bytes / r3dgs_binning_bytes(..., reserve) / r3dgs_image_bytes) and a pair reservation; everything
+ * is enqueued on `stream` -- as ONE hipGraph launch per pass once the shape has been seen -- and the call returns
+ * a pass ticket (> 0) without waiting.  num_rendered lives on the device; if it exceeds `reserve` the FARTHEST
+ * pairs are dropped for that pass (emission is in depth order), the pass is flagged R3DGS_PASS_TRUNCATED and
+ * r3dgs_reserve_hint grows.  Everything else (arguments, outputs, numerics) is r3dgs_forward's.
+ *   r3dgs_reserve_hint: reservation proposed from the num_rendered of earlier passes of this (device, W, H), scaled
+ *     to P, with slack (R3DGS_RESERVE_SLACK_PCT, default 150) and kept stable per P; 0 = nothing known yet (run
+ *     r3dgs_forward once) or R3DGS_RESERVE=off.
+ *   r3dgs_pass_query: num_rendered / visible / reserve (-1 for exact-size passes) / flags of a ticket; wait = 0
+ *     returns 0 if the pass has not produced them yet, wait = 1 blocks (host-memory poll with deadline).
+ *     Returns 1 when filled in, negative on error (e.g. the ticket is more than ~1000 passes old).
+ *   r3dgs_reserve_overflow_events: number of truncated passes seen so far (+ the last one's numbers). */
+#define R3DGS_PASS_TRUNCATED 1
+#define R3DGS_PASS_DEPTH_BUCKET_OVERFLOW 2
+int r3dgs_reserve_hint(int P, int width, int height);
+long long r3dgs_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, int P,
+                                 const int* D, int M, const float* background, int width, int height,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                 int prefiltered, float* out_color, int* out_touched_pixels, float* out_transmittance,
+                                 int* radii, int calculate_mean_transmittance, int debug, void* stream);
+long long r3dgs_inference_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve,
+                                           int P, const int* D, int bandsNum, const int* coeffsNum,
+                                           const int* perBandPrimitiveCount, const int* cumSumPrimitiveCount,
+                                           const float* background, int width, int height, const float* means3D,
+                                           const float* shs, const float* colors_precomp, const float* opacities,
+                                           const float* scales, float scale_modifier, const float* rotations,
+                                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                           float* out_color, int* out_touched_pixels, float* out_transmittance,
+                                           int* radii, int calculate_mean_transmittance, int debug, void* stream);
+int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible, int* reserve, int* flags);
+long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserve);
+
 /* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
- * No host synchronisation.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
+ * No host synchronisation; one hipGraph launch once the shape has been seen.  R is the pair capacity the forward
+ * sized the binning blob with: num_rendered as returned by r3dgs_forward, or the `reserve` passed to
+ * r3dgs_forward_reserved (r3dgs_binning_capacity recovers it from the blob's size); the pair count itself is read
+ * from the device.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
  * rasterize_points.cu:245; the multiplier lambda / (visible * 45) is formed on the device).
  * Every element of every output is written (zeros where the reference relies on zero-initialised
  * tensors), so outputs may be uninitialised.  dL_dconic ([P,2,2]) may be NULL.
@@ -100,8 +149,9 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
 /* Debug accessor for bit-exact checks of the integer stages (SURVEY.md 8b "provide a debug accessor"):
  * copies, out of the opaque blobs of a finished forward, the sorted list in the REFERENCE's format --
  * keys[i] = (tile << 32) | depth_bits (rasterizer_impl.cu:110-113), point_list, per-tile ranges,
- * n_contrib and final T.  Any output pointer may be NULL.  Device pointers. */
-int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+ * n_contrib and final T.  R = pair capacity of the binning blob (as for r3dgs_backward), count = entries of the
+ * list to export (<= num_rendered).  Any output pointer may be NULL.  Device pointers. */
+int r3dgs_export_binning(int P, int R, int count, int width, int height, char* geom_buffer, char* binning_buffer,
                          char* image_buffer, uint64_t* keys, uint32_t* point_list, uint32_t* ranges /*[Tn][2]*/,
                          uint32_t* n_contrib, float* final_T, uint32_t* tiles_touched, void* stream);
 
@@ -119,7 +169,8 @@ int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg,
 /* Optional per-stage timing (not in the reference; it times with torch.cuda.Event pairs from Python,
  * train.py:52-53, gaussian_renderer/__init__.py:95-98).  When enabled, forward/backward record a HIP event pair
  * around each selected stage ON THE CALLER'S STREAM.  on = 0: off; 1: every stage; otherwise bit (s + 1) selects
- * stage s (each record is a stream packet: a dozen per pass cost a few percent of a 1 ms iteration).
+ * stage s.  A pass with a timed stage is issued with direct launches instead of its graph (the events sit between
+ * its kernels), so time only what you need: bench.py times the dominant stage alone inside its timed region.
  * r3dgs_profile_read() waits for the recorded events, writes per-stage total milliseconds and launch counts
  * (arrays of r3dgs_profile_stage_count() entries, host memory) and resets the counters. */
 int r3dgs_profile_enable(int on);

@@ -7,15 +7,18 @@
 // traffic, which is what bounds this stage on MI355X:
 //
 //   reference: sort R (u64 key, u32 value) pairs on 32+log2(tiles) bits  -> ~6 passes x 24 B x R
-//   here:      1. stable sort the P Gaussians once by their 32 depth bits (4 passes x 16 B x P, P << R)
-//              2. inclusive scan of tiles_touched in that depth order
-//              3. emit the R (tile, id) pairs in depth order, load-balanced per wave
-//              4. stable sort the pairs on the log2(tiles) tile bits only (2 passes x 16 B x R)
+//   here:      1. stable sort the P Gaussians once by their 32 depth bits (P << R): one bucketing pass + an LDS sort
+//              2. inclusive scan of tiles_touched in that depth order (fused into 1.)
+//              3. emit the R pairs in depth order as packed words (tile | depth rank), balanced over OUTPUT slots
+//              4. stable LSD radix sort of the words on the log2(tiles) tile bits only (2 passes x 8 or 16 B x R)
 //   Stability of both sorts + ascending-id input order reproduces the reference's tie-break exactly.
 //
-// The sorts / scan use rocPRIM device primitives (onesweep radix sort, decoupled-lookback scan).
+// Every kernel takes a pointer into the pass's device argument block (common.h) and reads the pair count from the
+// device header: nothing here depends on a host copy of num_rendered, grids are sized by the pair reservation.
+// rocPRIM is used only by the generic depth sort (fallback for P >= 2^24 and R3DGS_DEPTH_SORT=generic).
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include <rocprim/rocprim.hpp>
@@ -39,15 +42,7 @@ size_t depth_sort_temp_bytes(size_t P)
     return (a > b ? a : b) + 256;
 }
 
-size_t tile_sort_temp_bytes(size_t R)
-{
-    size_t a = 0;
-    uint32_t* n = nullptr;
-    R3_HIP(rocprim::radix_sort_pairs(nullptr, a, n, n, n, n, R ? R : 1, 0, 32));
-    return a + 256;
-}
-
-void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s)
+void run_generic_depth_sort(int P, GeomState& g, hipStream_t s)
 {
     size_t bytes = g.temp_bytes;
     R3_HIP(rocprim::radix_sort_pairs(g.temp, bytes, g.depth_key, g.key_sorted, rocprim::counting_iterator<uint32_t>(0),
@@ -75,41 +70,8 @@ __device__ inline T block256_inclusive_scan(T v, T* s_w)
     return v + add;
 }
 
-// ---- bucketed depth sort ---------------------------------------------------------------------------------------
-// The generic device sort above is launch-latency bound at this size (block sort + 9 merge passes, ~125 us for
-// 500k keys).  The keys are view depths, so:
-//   (1) every workgroup histograms its 4096 Gaussians over kDepthBuckets equal-width intervals of [min depth, max
-//       depth] (the range comes from the preprocess kernel) and stores its row -- no global atomics: device-scope
-//       atomics on the same few lines were the cost of the first version of this pass;
-//   (2) a column-wise scan of the rows (each workgroup's first slot inside each bucket) and the bucket totals;
-//       raises header.sort_overflow if a bucket exceeds kBucketCap;
-//   (3) (key, id) scatter into the bucket regions -- slot = bucket start (scan of the totals, redone per workgroup
-//       in LDS) + row base + LDS rank, again no global atomics;
-//   (4) one workgroup per bucket sorts its pairs in LDS as 64-bit (key << 32 | id) words and scans tiles_touched in
-//       that order on top of the bucket's base.
-// The bucket function is monotone in the key, so concatenating the sorted buckets is the stable sort by depth bits
-// the reference's 64-bit key sort implies.  On overflow (e.g. a fronto-parallel plane of splats) the host, which
-// sees the flag with the num_rendered read-back, reruns the generic path.
-constexpr int kHistPerThread = kHistPerBlock / 256;
-constexpr int kCountBits = 24;
-constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
-
-struct DepthRange {
-    float zmin, scale;
-};
-__device__ inline DepthRange make_depth_range(uint32_t mx, uint32_t mi)
-{
-    DepthRange r;
-    const float zmax = __uint_as_float(mx), zmin = __uint_as_float(~mi);
-    r.zmin = zmin;
-    r.scale = zmax > zmin ? (float)kDepthBuckets / (zmax - zmin) : 0.f;   // no visible Gaussian: nothing is looked up
-    return r;
-}
-__device__ inline DepthRange load_depth_range(const DepthSortScratch* ds)
-{
-    return make_depth_range(ds->depth_max, ds->depth_inv_min);
-}
-// Sum / max of the preprocess workgroups' partials by one workgroup of 256 or 1024 threads (s_red: 4 x 16 words).
+// ---- per-view header ----------------------------------------------------------------------------------------------
+// Sum / max of the preprocess workgroups' partials by one workgroup of 1024 threads (s_red: 16 x 4 words).
 __device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
 {
     PrePartial acc = {0u, 0u, 0u, 0u};
@@ -144,43 +106,99 @@ __device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ part
     __syncthreads();
     return out;
 }
-__device__ inline int depth_bucket(uint32_t key, DepthRange r)
+
+// One workgroup turns the preprocess partials into the device header every later kernel reads (visible count,
+// num_rendered, the pair count clamped to the reservation, depth range) and publishes num_rendered / visible in the
+// pass's host-mapped PassInfo slot: the host never has to wait for it, and when it wants it (exact-size path, lazy
+// statistics) it polls plain memory.
+__global__ __launch_bounds__(1024) void header_reduce_kernel(const HeaderArgs* __restrict__ ap)
 {
-    if (key == 0xFFFFFFFFu) return kDepthBuckets;   // culled
-    const int b = (int)((__uint_as_float(key) - r.zmin) * r.scale);
-    return min(max(b, 0), kDepthBuckets - 1);
+    __shared__ uint32_t s_red[16][4];
+    const HeaderArgs& a = *ap;
+    const PrePartial all = reduce_partials(a.parts, a.n_parts, s_red);
+    if (threadIdx.x == 0) {
+        GeomHeader* hdr = a.hdr;
+        hdr->visible = all.visible;
+        hdr->num_rendered = all.num_rendered;
+        hdr->depth_max = all.depth_max;
+        hdr->depth_inv_min = all.depth_inv_min;
+        hdr->num_pairs = min(all.num_rendered, a.reserve);
+        hdr->reserve = a.reserve;
+        hdr->sort_overflow = 0u;
+        volatile PassInfo* info = a.info;
+        if (info) {
+            info->num_rendered = all.num_rendered;
+            info->visible = all.visible;
+            info->reserve = a.reserve;
+            info->sort_overflow = 0u;
+            __threadfence_system();
+            info->seq = a.ticket;
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* __restrict__ key,
-                                                         const uint32_t* __restrict__ tiles,
-                                                         const PrePartial* __restrict__ parts, int n_parts,
-                                                         const GeomHeader* hdr, DepthSortScratch* ds,
-                                                         unsigned long long* __restrict__ rows)
+void issue_header_reduce(const HeaderArgs* a, hipStream_t s)
 {
-    __shared__ unsigned long long hist[kDepthBuckets + 1];
-    __shared__ uint32_t s_red[16][4];
-    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) hist[b] = 0;
-    // depth range: from the header if it is already there, else every workgroup derives it from the preprocess
-    // partials itself (header being produced on another stream); workgroup 0 leaves it for the scatter kernel
-    PrePartial all;
-    if (hdr) {   // the header was reduced on this stream before the launch
-        all.depth_max = hdr->depth_max;
-        all.depth_inv_min = hdr->depth_inv_min;
-    } else {
-        all = reduce_partials(parts, n_parts, s_red);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ds->depth_max = all.depth_max;
-        ds->depth_inv_min = all.depth_inv_min;
-    }
-    const DepthRange rng = make_depth_range(all.depth_max, all.depth_inv_min);
+    hipLaunchKernelGGL(header_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+// ---- bucketed depth sort ---------------------------------------------------------------------------------------
+// A generic device sort is launch-latency bound at this size (rocPRIM: block sort + 9 merge passes, ~125 us for 500k
+// keys).  The keys are view depths whose range the preprocess kernel already knows, so:
+//   (1) every workgroup histograms its 4096 Gaussians over nb monotone buckets of [min depth, max depth] and stores its
+//       row -- no global atomics: device-scope atomics on the same few lines were the cost of the first version;
+//   (2) a column-wise scan of the rows (each workgroup's first slot inside each bucket) and the bucket totals;
+//   (3) (key, id) scatter into the bucket regions -- slot = bucket start (scan of the totals, redone per workgroup
+//       in LDS) + row base + LDS rank, again no global atomics;
+//   (4) one workgroup per bucket sorts its pairs in LDS as 64-bit (key << 32 | id) words and scans tiles_touched in
+//       that order on top of the bucket's base.
+// The bucket function is monotone in the key, so concatenating the sorted buckets is the stable sort by depth bits
+// the reference's 64-bit key sort implies.  Buckets are equal-width in the key's BIT PATTERN (positive floats order
+// like their bits), i.e. roughly logarithmic in depth: an unbounded scene with its content at 2..8 units and a
+// background out to 100 puts ~a quarter of the buckets under the content instead of 6% of them.  nb grows with P
+// (mean load <= 512).  A bucket that still exceeds the LDS capacity (a fronto-parallel plane of splats) is sorted by
+// its workgroup with a radix sort in global memory -- correct, slow, and flagged in the header / PassInfo so that
+// the host can route later passes of such a view through the generic sort.
+constexpr int kHistPerThread = kHistPerBlock / 256;
+constexpr int kCountBits = 24;
+constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
+constexpr int kMaxBucketsPerThread = (kMaxDepthBuckets + 1 + 255) / 256;
+
+struct DepthRange {
+    uint32_t kmin;
+    double scale;
+    int nb;
+};
+__device__ inline DepthRange make_depth_range(uint32_t mx, uint32_t mi, int nb)
+{
+    DepthRange r;
+    const uint32_t kmax = mx, kmin = ~mi;
+    r.kmin = kmin;
+    r.nb = nb;
+    r.scale = kmax >= kmin ? (double)nb / ((double)(kmax - kmin) + 1.0) : 0.0;   // no visible Gaussian: nothing is looked up
+    return r;
+}
+__device__ inline int depth_bucket(uint32_t key, const DepthRange& r)
+{
+    if (key == 0xFFFFFFFFu) return r.nb;   // culled
+    const int b = (int)((double)(key - r.kmin) * r.scale);   // monotone in key
+    return min(max(b, 0), r.nb - 1);
+}
+
+__global__ __launch_bounds__(256) void depth_hist_kernel(const DepthArgs* __restrict__ ap)
+{
+    extern __shared__ unsigned long long hist[];   // [nb + 1]
+    const DepthArgs& a = *ap;
+    const int P = a.P, nb = a.nb;
+    for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;
+    const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread], tv[kHistPerThread];
 #pragma unroll
     for (int k = 0; k < kHistPerThread; k++) {   // all loads in flight before the first LDS atomic
         const int i = base + k * 256 + threadIdx.x;
-        kv[k] = i < P ? key[i] : 0xFFFFFFFFu;
-        tv[k] = i < P ? tiles[i] : 0u;
+        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
+        tv[k] = i < P ? a.tiles[i] : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -188,27 +206,26 @@ __global__ __launch_bounds__(256) void depth_hist_kernel(int P, const uint32_t* 
         if (base + k * 256 + (int)threadIdx.x < P)
             atomicAdd(&hist[depth_bucket(kv[k], rng)], ((unsigned long long)tv[k] << kCountBits) | 1ull);
     __syncthreads();
-    unsigned long long* row = rows + (size_t)blockIdx.x * (kDepthBuckets + 1);
-    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) row[b] = hist[b];
+    unsigned long long* row = a.hist_rows + (size_t)blockIdx.x * (nb + 1);
+    for (int b = threadIdx.x; b <= nb; b += 256) row[b] = hist[b];
 }
 
 // 64 columns per workgroup, a contiguous band of rows per wave: per column the exclusive prefix of the counts down
 // the rows (each histogram workgroup's first slot inside the bucket) and the column total.
 constexpr int kColWaves = 16;
-__global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_rows,
-                                                                       const unsigned long long* __restrict__ rows,
-                                                                       uint32_t* __restrict__ row_base,
-                                                                       DepthSortScratch* ds, GeomHeader* hdr)
+__global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(const DepthArgs* __restrict__ ap)
 {
     __shared__ unsigned long long s_part[kColWaves][64];
     __shared__ uint32_t s_over;
+    const DepthArgs& a = *ap;
+    const int n_rows = a.rows, nb = a.nb;
+    const unsigned long long* __restrict__ rows = a.hist_rows;
+    uint32_t* __restrict__ row_base = a.hist_base;
     if (threadIdx.x == 0) s_over = 0u;
-    // every overflow slot the host reads is written: this workgroup's own below, the unused ones here
-    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < kOverflowSlots) hdr->sort_overflow[threadIdx.x] = 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const bool live = c <= kDepthBuckets;
-    constexpr int kStride = kDepthBuckets + 1;
+    const bool live = c <= nb;
+    const int kStride = nb + 1;
     const int band = (n_rows + kColWaves - 1) / kColWaves;
     const int r_lo = min(n_rows, w * band), r_hi = min(n_rows, r_lo + band);
     unsigned long long mine = 0;
@@ -220,54 +237,46 @@ __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(int n_row
     __syncthreads();
     unsigned long long acc = 0, total = 0;
     if (live) {
-    for (int k = 0; k < kColWaves; k++) {
-        if (k < w) acc += s_part[k][lane];
-        total += s_part[k][lane];
-    }
+        for (int k = 0; k < kColWaves; k++) {
+            if (k < w) acc += s_part[k][lane];
+            total += s_part[k][lane];
+        }
 #pragma unroll 8
-    for (int r = r_lo; r < r_hi; r++) {
-        const unsigned long long v = rows[(size_t)r * kStride + c];
-        row_base[(size_t)r * kStride + c] = (uint32_t)(acc & kCountMask);
-        acc += v;
-    }
-    if (w == 0) {
-        ds->total[c] = total;
-        if (c < kDepthBuckets && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) s_over = 1u;
-    }
+        for (int r = r_lo; r < r_hi; r++) {
+            const unsigned long long v = rows[(size_t)r * kStride + c];
+            row_base[(size_t)r * kStride + c] = (uint32_t)(acc & kCountMask);
+            acc += v;
+        }
+        if (w == 0) {
+            a.ds->total[c] = total;
+            if (c < nb && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) s_over = 1u;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) hdr->sort_overflow[blockIdx.x] = s_over;   // every slot the host reads is written
-}
-
-__global__ __launch_bounds__(1024) void header_reduce_kernel(const PrePartial* __restrict__ parts, int n_parts,
-                                                             GeomHeader* hdr)
-{
-    __shared__ uint32_t s_red[16][4];
-    const PrePartial all = reduce_partials(parts, n_parts, s_red);
-    if (threadIdx.x == 0) {
-        hdr->visible = all.visible;
-        hdr->num_rendered = all.num_rendered;
-        hdr->depth_max = all.depth_max;
-        hdr->depth_inv_min = all.depth_inv_min;
+    if (threadIdx.x == 0 && s_over) {   // both were zeroed by header_reduce_kernel earlier in this pass
+        a.hdr->sort_overflow = 1u;
+        if (a.info) a.info->sort_overflow = 1u;
     }
 }
 
-// Exclusive scan of the 1025 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
+// Exclusive scan of the nb + 1 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
 // by a 256-thread workgroup into LDS.
-__device__ inline void scan_bucket_totals(const DepthSortScratch* ds, uint32_t* s_start, uint32_t* s_tile,
+__device__ inline void scan_bucket_totals(const DepthSortScratch* ds, int nb, uint32_t* s_start, uint32_t* s_tile,
                                           unsigned long long* s_tmp)
 {
-    constexpr int kPer = (kDepthBuckets + 1 + 255) / 256;
-    unsigned long long c[kPer], sum = 0;
-    for (int k = 0; k < kPer; k++) {
-        const int b = threadIdx.x * kPer + k;
-        c[k] = b <= kDepthBuckets ? ds->total[b] : 0ull;
+    const int per = (nb + 1 + 255) / 256;
+    unsigned long long c[kMaxBucketsPerThread], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBucketsPerThread; k++) {
+        const int b = threadIdx.x * per + k;
+        c[k] = (k < per && b <= nb) ? ds->total[b] : 0ull;
         sum += c[k];
     }
     unsigned long long run = block256_inclusive_scan(sum, s_tmp) - sum;
-    for (int k = 0; k < kPer; k++) {
-        const int b = threadIdx.x * kPer + k;
-        if (b <= kDepthBuckets + 1) {
+#pragma unroll
+    for (int k = 0; k < kMaxBucketsPerThread; k++) {
+        const int b = threadIdx.x * per + k;
+        if (k < per && b <= nb + 1) {
             s_start[b] = (uint32_t)(run & kCountMask);
             s_tile[b] = (uint32_t)(run >> kCountBits);
         }
@@ -277,38 +286,36 @@ __device__ inline void scan_bucket_totals(const DepthSortScratch* ds, uint32_t* 
 }
 
 // (key, id) into the bucket regions; the culled Gaussians go straight to their final place.
-__global__ __launch_bounds__(256) void depth_scatter_kernel(int P, const uint32_t* __restrict__ key,
-                                                            const GeomHeader* hdr, DepthSortScratch* ds,
-                                                            const uint32_t* __restrict__ row_base,
-                                                            uint32_t* __restrict__ out_key,
-                                                            uint32_t* __restrict__ out_id,
-                                                            uint32_t* __restrict__ order,
-                                                            uint32_t* __restrict__ offsets)
+__global__ __launch_bounds__(256) void depth_scatter_kernel(const DepthArgs* __restrict__ ap)
 {
-    __shared__ uint32_t slot0[kDepthBuckets + 2];   // bucket starts, then this workgroup's first slot of each bucket
-    __shared__ uint32_t s_tile[kDepthBuckets + 2];
-    __shared__ uint32_t rank[kDepthBuckets + 1];
+    extern __shared__ uint32_t s_dyn[];   // slot0[nb + 2] | s_tile[nb + 2] | rank[nb + 2]
     __shared__ unsigned long long s_tmp[256];
-    scan_bucket_totals(ds, slot0, s_tile, s_tmp);
+    const DepthArgs& a = *ap;
+    const int P = a.P, nb = a.nb;
+    uint32_t* slot0 = s_dyn;   // bucket starts, then this workgroup's first slot of each bucket
+    uint32_t* s_tile = s_dyn + (nb + 2);
+    uint32_t* rank = s_dyn + 2 * (nb + 2);
+    DepthSortScratch* ds = a.ds;
+    scan_bucket_totals(ds, nb, slot0, s_tile, s_tmp);
     if (blockIdx.x == 0)   // published for the per-bucket sort kernel
-        for (int b = threadIdx.x; b <= kDepthBuckets + 1; b += 256) {
+        for (int b = threadIdx.x; b <= nb + 1; b += 256) {
             ds->start[b] = slot0[b];
             ds->tile_base[b] = s_tile[b];
         }
-    const uint32_t R = s_tile[kDepthBuckets];   // culled Gaussians add no tiles: their scan value is the total
+    const uint32_t R = s_tile[nb];   // culled Gaussians add no tiles: their scan value is the total
     __syncthreads();
-    const uint32_t* mybase = row_base + (size_t)blockIdx.x * (kDepthBuckets + 1);
-    for (int b = threadIdx.x; b <= kDepthBuckets; b += 256) {
+    const uint32_t* mybase = a.hist_base + (size_t)blockIdx.x * (nb + 1);
+    for (int b = threadIdx.x; b <= nb; b += 256) {
         slot0[b] += mybase[b];
         rank[b] = 0;
     }
-    const DepthRange rng = load_depth_range(ds);
+    const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
     const int base = blockIdx.x * kHistPerBlock;
     uint32_t kv[kHistPerThread];
 #pragma unroll
     for (int k = 0; k < kHistPerThread; k++) {
         const int i = base + k * 256 + threadIdx.x;
-        kv[k] = i < P ? key[i] : 0xFFFFFFFFu;
+        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
     }
     __syncthreads();
 #pragma unroll
@@ -317,37 +324,128 @@ __global__ __launch_bounds__(256) void depth_scatter_kernel(int P, const uint32_
         if ((int)id < P) {
             const int b = depth_bucket(kv[k], rng);
             const uint32_t slot = slot0[b] + atomicAdd(&rank[b], 1u);   // any order: the bucket is sorted next
-            if (b == kDepthBuckets) {
-                order[slot] = id;
-                offsets[slot] = R;
+            if (b == nb) {
+                a.order[slot] = id;
+                a.offsets[slot] = R;
             } else {
-                out_key[slot] = kv[k];
-                out_id[slot] = id;
+                a.key_sorted[slot] = kv[k];
+                a.bucket_id[slot] = id;
             }
         }
     }
 }
 
+// Stable partition of one wave's 64 digits: lanes holding the same digit as this lane (including itself).
+template <int BITS>
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+// Slow path of the bucket sort: n (key, id) pairs in global memory, sorted by (key, id) by ONE 256-thread workgroup
+// with a stable LSD radix sort (8-bit digits; digits on which all pairs agree are skipped -- a bucket's keys share
+// their high bits).  Ping-pongs between (k0, v0) and (k1, v1); returns 0 / 1 = which pair of arrays holds the result.
+__device__ int block_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n)
+{
+    __shared__ uint32_t s_hist[256], s_base[256], s_wc[4][256];
+    __shared__ uint32_t s_skip;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int cur = 0;
+    for (int pass = 0; pass < 7; pass++) {   // id bytes 0..2 (P < 2^24), then key bytes 0..3
+        const uint32_t* kin = cur ? k1 : k0;
+        const uint32_t* vin = cur ? v1 : v0;
+        uint32_t* kout = cur ? k0 : k1;
+        uint32_t* vout = cur ? v0 : v1;
+        const bool on_id = pass < 3;
+        const int shift = on_id ? 8 * pass : 8 * (pass - 3);
+        s_hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_skip = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            atomicAdd(&s_hist[((on_id ? vin[i] : kin[i]) >> shift) & 255u], 1u);
+        __syncthreads();
+        const uint32_t cnt = s_hist[threadIdx.x];
+        if (cnt == n) s_skip = 1;   // every pair has this digit: the pass would not move anything
+        const uint32_t incl = block256_inclusive_scan(cnt, s_base);   // s_base doubles as the scan's 4-word scratch
+        __syncthreads();
+        const bool skip = s_skip != 0;
+        __syncthreads();
+        s_base[threadIdx.x] = incl - cnt;
+        __syncthreads();
+        if (skip) continue;
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {   // chunks in order: stability
+            const uint32_t i = c0 + threadIdx.x;
+            const bool valid = i < n;
+            const uint32_t kk = valid ? kin[i] : 0u, vv = valid ? vin[i] : 0u;
+            const uint32_t d = ((on_id ? vv : kk) >> shift) & 255u;
+            for (int t = threadIdx.x; t < 4 * 256; t += 256) (&s_wc[0][0])[t] = 0;
+            __syncthreads();
+            const unsigned long long peers = match_digit<8>(d, valid);
+            if (valid && (peers & below) == 0ull) s_wc[w][d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = s_base[d] + (uint32_t)__popcll(peers & below);
+                for (int k = 0; k < w; k++) pos += s_wc[k][d];
+                kout[pos] = kk;
+                vout[pos] = vv;
+            }
+            __syncthreads();
+            s_base[threadIdx.x] += s_wc[0][threadIdx.x] + s_wc[1][threadIdx.x] + s_wc[2][threadIdx.x] + s_wc[3][threadIdx.x];
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        cur ^= 1;
+    }
+    return cur;
+}
+
 // One workgroup per bucket: sort the (key << 32 | id) words in LDS, then the inclusive scan of tiles_touched in
 // that order on top of the bucket's base (rasterizer_impl.cu:441 InclusiveSum, fused).
-__global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortScratch* __restrict__ ds,
-                                                                const uint32_t* __restrict__ in_key,
-                                                                const uint32_t* __restrict__ in_id,
-                                                                const uint32_t* __restrict__ tiles,
-                                                                uint32_t* __restrict__ order,
-                                                                uint32_t* __restrict__ offsets)
+__global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthArgs* __restrict__ ap)
 {
     __shared__ unsigned long long s[kBucketCap];
     __shared__ uint32_t s_sum[256];
+    const DepthArgs& a = *ap;
+    const DepthSortScratch* __restrict__ ds = a.ds;
+    const uint32_t* __restrict__ tiles = a.tiles;
+    uint32_t* __restrict__ order = a.order;
+    uint32_t* __restrict__ offsets = a.offsets;
     const int b = blockIdx.x;
     const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
     if (n == 0) return;
-    // A bucket that overflows the LDS (sort_overflow is set and the host reruns the generic sort + scan) is passed
-    // through unsorted so that `order` holds valid ids.
     if (n > (uint32_t)kBucketCap) {
-        for (uint32_t r = threadIdx.x; r < n; r += 256) order[start + r] = in_id[start + r];
+        // the bucket does not fit the LDS sort: radix sort in global memory, then the scan in strides of 256
+        const int cur = block_radix_sort_pairs(a.key_sorted + start, a.bucket_id + start, a.ovf_key + start,
+                                               a.ovf_id + start, n);
+        const uint32_t* ids = (cur ? a.ovf_id : a.bucket_id) + start;
+        uint32_t run = ds->tile_base[b];
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+            const uint32_t r = c0 + threadIdx.x;
+            const uint32_t id = r < n ? ids[r] : 0u;
+            const uint32_t t = r < n ? tiles[id] : 0u;
+            const uint32_t incl = block256_inclusive_scan(t, s_sum);
+            if (r < n) {
+                order[start + r] = id;
+                offsets[start + r] = run + incl;
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) s_sum[4] = incl;
+            __syncthreads();
+            run += s_sum[4];
+        }
         return;
     }
+    const uint32_t* __restrict__ in_key = a.key_sorted;
+    const uint32_t* __restrict__ in_id = a.bucket_id;
     uint32_t N = 2;
     while (N < n) N <<= 1;
     for (uint32_t r = threadIdx.x; r < N; r += 256)
@@ -357,11 +455,11 @@ __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortS
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
                 const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;   // lo has bit j clear
-                const unsigned long long a = s[lo], c = s[hi];
+                const unsigned long long x = s[lo], y = s[hi];
                 const bool up = (lo & k) == 0;
-                if ((a > c) == up) {
-                    s[lo] = c;
-                    s[hi] = a;
+                if ((x > y) == up) {
+                    s[lo] = y;
+                    s[hi] = x;
                 }
             }
             __syncthreads();
@@ -386,50 +484,69 @@ __global__ __launch_bounds__(256) void depth_bucket_sort_kernel(const DepthSortS
     }
 }
 
-constexpr int kColBlocks = (kDepthBuckets + 1 + 63) / 64;
-static_assert(kColBlocks <= kOverflowSlots, "one overflow slot per column-scan workgroup");
+static size_t depth_hist_lds(int nb) { return (size_t)(nb + 1) * sizeof(unsigned long long); }
+static size_t depth_scatter_lds(int nb) { return (size_t)3 * (nb + 2) * sizeof(uint32_t); }
 
-void run_header_reduce(int P, GeomState& g, hipStream_t s)
+void prepare_depth_bucket_sort(int nb)
 {
-    header_reduce_kernel<<<1, 1024, 0, s>>>(g.partials, (int)pre_partials((size_t)P), g.header);
+    static std::mutex mu;
+    static int prepared_nb = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (nb <= prepared_nb) return;
+    if (depth_hist_lds(nb) > 48 * 1024)
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depth_hist_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)depth_hist_lds(nb)));
+    if (depth_scatter_lds(nb) > 48 * 1024)
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depth_scatter_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)depth_scatter_lds(nb)));
+    prepared_nb = nb;
 }
 
-void run_depth_histogram(int P, GeomState& g, bool header_ready, hipStream_t s)
+void issue_depth_bucket_sort(const FwdPlan& p, const DepthArgs* a, hipStream_t s)
 {
-    const int rows = (int)depth_hist_rows((size_t)P), np = (int)pre_partials((size_t)P);
-    depth_hist_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.tiles, g.partials, np, header_ready ? g.header : nullptr,
-                                           g.dsort, g.hist_rows);
-    depth_colscan_kernel<<<kColBlocks, 64 * kColWaves, 0, s>>>(rows, g.hist_rows, g.hist_base, g.dsort, g.header);
+    const int rows = (int)depth_hist_rows((size_t)p.P), nb = p.nb;
+    const size_t hist_lds = depth_hist_lds(nb), scat_lds = depth_scatter_lds(nb);
+    hipLaunchKernelGGL(depth_hist_kernel, dim3(rows), dim3(256), hist_lds, s, a);
+    hipLaunchKernelGGL(depth_colscan_kernel, dim3((nb + 1 + 63) / 64), dim3(64 * kColWaves), 0, s, a);
+    hipLaunchKernelGGL(depth_scatter_kernel, dim3(rows), dim3(256), scat_lds, s, a);
+    hipLaunchKernelGGL(depth_bucket_sort_kernel, dim3(nb), dim3(256), 0, s, a);
 }
 
-void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s)
+// ---- packed pair words -------------------------------------------------------------------------------------------
+PairLayout pair_layout(int P, size_t n_tiles)
 {
-    const int rows = (int)depth_hist_rows((size_t)P);
-    depth_scatter_kernel<<<rows, 256, 0, s>>>(P, g.depth_key, g.header, g.dsort, g.hist_base, g.key_sorted,
-                                              g.bucket_id, g.order, g.offsets);
-    depth_bucket_sort_kernel<<<kDepthBuckets, 256, 0, s>>>(g.dsort, g.key_sorted, g.bucket_id, g.tiles, g.order,
-                                                           g.offsets);
-}
-
-int tile_rank_bits(int P, size_t n_tiles)
-{
-    static const bool force_pairs = [] {   // R3DGS_TILE_SORT=pairs | rocprim | (default: own radix on packed words)
+    static const bool force_wide = [] {   // R3DGS_TILE_SORT=wide: 64-bit words for every shape (A/B runs, tests)
         const char* v = getenv("R3DGS_TILE_SORT");
-        return v && std::string(v) == "pairs";
+        return v && std::string(v) == "wide";
     }();
-    if (force_pairs) return 0;
-    const uint32_t tb = higher_msb((uint32_t)n_tiles), rb = higher_msb((uint32_t)P);
-    return tb + rb <= 32 ? (int)rb : 0;
+    PairLayout l;
+    l.tile_bits = (int)higher_msb((uint32_t)n_tiles);
+    const int rb = (int)higher_msb((uint32_t)P);
+    l.wide = (force_wide || l.tile_bits + rb > 32) ? 1 : 0;
+    l.rank_bits = l.wide ? 32 : rb;
+    l.digit_bits = l.tile_bits <= 14 ? 7 : 8;
+    l.passes = (l.tile_bits + l.digit_bits - 1) / l.digit_bits;
+    if (l.passes < 2) l.passes = 2;   // the first digit's counts come out of the emission kernel; keep one shape
+    if (l.passes > kMaxRadixPasses) throw Error("more than 2^24 tiles are not supported");
+    return l;
+}
+
+template <class Word>
+__device__ __forceinline__ uint32_t word_tile(Word w, int rank_bits)
+{
+    return (uint32_t)(w >> rank_bits);
 }
 
 // Pair emission, balanced over OUTPUT positions.  The reference loops one thread over all tiles of its
 // Gaussian (rasterizer_impl.cu:106-117); in depth order the nearest -- largest -- splats sit next to each
 // other, so any per-Gaussian (or per-64-Gaussian) work split has a tail: the first GPU version of this
 // kernel spent 234 us waiting for its first few waves.  Here every workgroup owns kEmitPerBlock
-// consecutive output slots: two lanes locate the slot range's first/last source Gaussian by binary
+// consecutive output slots: two waves locate the slot range's first/last source Gaussian by a 64-ary
 // search in the inclusive scan, the block stages that <= kEmitPerBlock+1 long slice (end offset, id,
 // tile rect) in LDS, and every lane resolves its slots with an LDS binary search.  Stores are coalesced.
-constexpr int kEmitPerBlock = 1024;
+// With num_rendered above the pass's reservation the slots stop at the reservation: emission is in depth order, so
+// what is dropped are the FARTHEST pairs.
+constexpr int kEmitPerBlock = kRadixBlock;
 constexpr int kEmitSlice = kEmitPerBlock + 8;
 
 // Smallest j in [0, n] with a[j] > pos (n if none), a non-decreasing, searched by a whole wave: 64 probes per step,
@@ -455,28 +572,29 @@ __device__ __forceinline__ uint32_t upper_bound_wave(const uint32_t* __restrict_
     return m ? lo + (uint32_t)__builtin_ctzll(m) : hi;
 }
 
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, const uint32_t* __restrict__ order,
-                                                         const uint32_t* __restrict__ offsets,
-                                                         const ushort4* __restrict__ rect, int gx, GRec* rec,
-                                                         int rank_bits, uint32_t* __restrict__ tile_out,
-                                                         uint32_t* __restrict__ id_out, uint2* __restrict__ ranges,
-                                                         uint32_t n_tiles, uint32_t* __restrict__ radix_rows)
+template <class Word>
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restrict__ ap)
 {
-    __shared__ uint32_t s_hist[kRadixBins];   // first radix digit of the packed tile sort, counted while emitting
-    if (radix_rows && threadIdx.x < kRadixBins) s_hist[threadIdx.x] = 0;
-    // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
-    // by a fill of its own on the stream
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+    __shared__ uint32_t s_hist[kMaxRadixBins];   // first radix digit of the tile sort, counted while emitting
     __shared__ uint32_t s_end[kEmitSlice];
     __shared__ uint32_t s_id[kEmitSlice];
     __shared__ ushort4 s_rect[kEmitSlice];
     __shared__ uint32_t s_j[2];
     __shared__ uint32_t s_start0;
+    const EmitArgs& a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    const int bins = 1 << a.digit_bits;
+    // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
+    // by a fill of its own on the stream
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.n_tiles; t += gridDim.x * 256u) a.ranges[t] = make_uint2(0u, 0u);
     const uint32_t pos0 = blockIdx.x * (uint32_t)kEmitPerBlock;
+    if (pos0 >= R) return;   // the grid covers the reservation
+    if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
+    const uint32_t* __restrict__ offsets = a.offsets;
     const uint32_t pos1 = min(R, pos0 + (uint32_t)kEmitPerBlock);  // exclusive
     if (threadIdx.x < 128) {   // wave 0 locates the first slot's Gaussian, wave 1 the last slot's
         const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const uint32_t j = upper_bound_wave(offsets, (uint32_t)P, w == 0 ? pos0 : pos1 - 1, lane);
+        const uint32_t j = upper_bound_wave(offsets, (uint32_t)a.P, w == 0 ? pos0 : pos1 - 1, lane);
         if (lane == 0) {
             s_j[w] = j;
             if (w == 0) s_start0 = j == 0 ? 0u : offsets[j - 1];
@@ -487,15 +605,17 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
     // every Gaussian inside the slice owns >= 1 slot (culled ones sort to the very end), so n <= slots + 1
     const uint32_t n = min(j_hi - j_lo + 1u, (uint32_t)kEmitSlice);
     for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t id = order[j_lo + k];
+        const uint32_t id = a.order[j_lo + k];
         s_end[k] = offsets[j_lo + k];
         s_id[k] = id;
-        s_rect[k] = rect[id];
+        s_rect[k] = a.rect[id];
     }
     __syncthreads();
     const uint32_t start0 = s_start0;
     // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value)
-    for (uint32_t k = threadIdx.x; k < n; k += 256) rec[s_id[k]].pair_start = k == 0 ? start0 : s_end[k - 1];
+    for (uint32_t k = threadIdx.x; k < n; k += 256) a.rec[s_id[k]].pair_start = k == 0 ? start0 : s_end[k - 1];
+    Word* __restrict__ out = reinterpret_cast<Word*>(a.words_out);
+    const int rank_bits = a.rank_bits;
 #pragma unroll
     for (int e = 0; e < kEmitPerBlock / 256; e++) {
         const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
@@ -513,52 +633,52 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, uint32_t R, cons
             const ushort4 r = s_rect[lo];
             const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
             const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
-            const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx;
-            if (rank_bits) {
-                tile_out[pos] = (tile << rank_bits) | (j_lo + lo);   // one word: tile | rank in depth order
-                if (radix_rows) atomicAdd(&s_hist[tile & (kRadixBins - 1)], 1u);
-            } else {
-                tile_out[pos] = tile;
-                id_out[pos] = s_id[lo];
-            }
+            const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)a.gx + (uint32_t)r.x + tx;
+            out[pos] = ((Word)tile << rank_bits) | (Word)(j_lo + lo);   // one word: tile | rank in depth order
+            if (sizeof(Word) == 8) a.pair_rank[pos] = j_lo + lo;
+            atomicAdd(&s_hist[tile & (uint32_t)(bins - 1)], 1u);
         }
     }
-    if (radix_rows) {
-        __syncthreads();
-        if (threadIdx.x < kRadixBins) radix_rows[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
-    }
+    __syncthreads();
+    if ((int)threadIdx.x < bins) a.radix_rows[(size_t)threadIdx.x * a.row_stride + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// ---- tile sort of the packed pair words: LSD radix, two 7-bit digits ------------------------------------------------
+// ---- tile sort of the packed pair words: LSD radix -------------------------------------------------------------------
 // rocPRIM's onesweep spends more time around its two passes (per-pass fills of the look-back state, histogram and scan
 // kernels: ~65 us of launches and gaps for ~48 us of sorting at R = 3.6 M) than in them.  Here a pass is: per-workgroup
 // digit counts (for the first digit they come out of the emission kernel), one workgroup per digit scanning its row
-// of counts, and a scatter that ranks its 1024 keys stably -- wave-level match by seven ballots per round, running
-// per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the two passes give the tile-major order
-// with the emission (depth) order preserved inside a tile.
-__global__ __launch_bounds__(256) void radix_hist_kernel(uint32_t R, const uint32_t* __restrict__ in, int shift,
-                                                         uint32_t* __restrict__ rows)
+// of counts, and a scatter that ranks its 1024 keys stably -- wave-level match by one ballot per digit bit per round,
+// running per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the passes give the tile-major
+// order with the emission (depth) order preserved inside a tile.
+template <class Word>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const RadixArgs* __restrict__ ap)
 {
-    __shared__ uint32_t s_hist[kRadixBins];
-    if (threadIdx.x < kRadixBins) s_hist[threadIdx.x] = 0;
-    __syncthreads();
+    __shared__ uint32_t s_hist[kMaxRadixBins];
+    const RadixArgs& a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
     const uint32_t base = blockIdx.x * (uint32_t)kRadixBlock;
+    if (base >= R) return;
+    const int bins = 1 << a.digit_bits;
+    if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const Word* __restrict__ in = reinterpret_cast<const Word*>(a.in);
 #pragma unroll
     for (int k = 0; k < kRadixBlock / 256; k++) {
         const uint32_t i = base + k * 256u + threadIdx.x;
-        if (i < R) atomicAdd(&s_hist[(in[i] >> shift) & (kRadixBins - 1)], 1u);
+        if (i < R) atomicAdd(&s_hist[(uint32_t)(in[i] >> a.shift) & (uint32_t)(bins - 1)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kRadixBins) rows[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+    if ((int)threadIdx.x < bins) a.rows[(size_t)threadIdx.x * a.row_stride + blockIdx.x] = s_hist[threadIdx.x];
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-workgroup counts, and the digit total
-__global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, const uint32_t* __restrict__ rows,
-                                                               uint32_t* __restrict__ base, uint32_t* __restrict__ total)
+__global__ __launch_bounds__(256) void radix_digit_scan_kernel(const RadixArgs* __restrict__ ap)
 {
     __shared__ uint32_t s_sum[256];
-    const uint32_t* row = rows + (size_t)blockIdx.x * nb;
-    uint32_t* out = base + (size_t)blockIdx.x * nb;
+    const RadixArgs& a = *ap;
+    const uint32_t nb = (a.hdr->num_pairs + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // live workgroups
+    const uint32_t* row = a.rows + (size_t)blockIdx.x * a.row_stride;
+    uint32_t* out = a.base + (size_t)blockIdx.x * a.row_stride;
     const uint32_t per = (nb + 255u) / 256u, e0 = threadIdx.x * per;
     uint32_t mine = 0;
 #pragma unroll 8
@@ -572,53 +692,61 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(uint32_t nb, cons
             out[e0 + k] = run;
             run += v;
         }
-    if (threadIdx.x == 255) total[blockIdx.x] = incl;
+    if (threadIdx.x == 255) a.total[blockIdx.x] = incl;
 }
 
 // (Materialising point_list[pos] = order[rank] here in the last pass was measured: the dependent gather lengthens this
 // kernel by 19 us and saves 13 us in tile_ranges_kernel, so it stays there.)
-__global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const uint32_t* __restrict__ in,
-                                                            uint32_t* __restrict__ out, int shift,
-                                                            const uint32_t* __restrict__ base,
-                                                            const uint32_t* __restrict__ total)
+template <class Word, int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __restrict__ ap)
 {
-    constexpr int kWaves = 4, kRounds = kRadixBlock / 256;
-    __shared__ uint32_t s_wcount[kWaves][kRadixBins];   // running per-wave digit counts
-    __shared__ uint32_t s_start[kRadixBins];            // exclusive scan of the digit totals
-    __shared__ uint32_t s_off[kWaves][kRadixBins];      // digit start + workgroup base + waves below
+    constexpr int kWaves = 4, kRounds = kRadixBlock / 256, kBins = 1 << BITS;
+    __shared__ uint32_t s_wcount[kWaves][kBins];   // running per-wave digit counts
+    __shared__ uint32_t s_start[kBins];            // exclusive scan of the digit totals
+    __shared__ uint32_t s_off[kWaves][kBins];      // digit start + workgroup base + waves below
+    const RadixArgs& a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    if (blockIdx.x * (uint32_t)kRadixBlock >= R) return;
+    const Word* __restrict__ in = reinterpret_cast<const Word*>(a.in);
+    Word* __restrict__ out = reinterpret_cast<Word*>(a.out);
+    const int shift = a.shift;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int t = threadIdx.x; t < kWaves * kRadixBins; t += 256) (&s_wcount[0][0])[t] = 0;
-    if (w == 0) {   // 128 totals, two per lane, scanned with shuffles
-        const uint32_t v0 = total[2 * lane], v1 = total[2 * lane + 1];
-        uint32_t incl = v0 + v1;
+    for (int t = threadIdx.x; t < kWaves * kBins; t += 256) (&s_wcount[0][0])[t] = 0;
+    if (w == 0) {   // kBins totals, kBins/64 per lane, scanned with shuffles
+        constexpr int kPer = kBins / 64;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            v[k] = a.total[kPer * lane + k];
+            sum += v[k];
+        }
+        uint32_t incl = sum;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
             if (lane >= off) incl += up;
         }
-        const uint32_t excl = incl - (v0 + v1);
-        s_start[2 * lane] = excl;
-        s_start[2 * lane + 1] = excl + v0;
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            s_start[kPer * lane + k] = run;
+            run += v[k];
+        }
     }
     __syncthreads();
     const uint32_t blk = blockIdx.x * (uint32_t)kRadixBlock + (uint32_t)w * (kRadixBlock / kWaves);
-    uint32_t key[kRounds], lrank[kRounds];
+    Word key[kRounds];
+    uint32_t lrank[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
         const uint32_t i = blk + r * 64u + lane;
-        key[r] = i < R ? in[i] : 0u;
+        key[r] = i < R ? in[i] : (Word)0;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
         const bool valid = blk + r * 64u + lane < R;
-        const uint32_t d = (key[r] >> shift) & (kRadixBins - 1);
-        unsigned long long peers = __ballot(valid);   // lanes of this round holding the same digit
-#pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(kBins - 1);
+        const unsigned long long peers = match_digit<BITS>(d, valid);   // lanes of this round holding the same digit
         const uint32_t seen = s_wcount[w][d];          // same-digit keys of this wave in earlier rounds
         lrank[r] = seen + (uint32_t)__popcll(peers & below);
         __builtin_amdgcn_wave_barrier();
@@ -626,9 +754,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const ui
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    if (threadIdx.x < kRadixBins) {
-        const int d = threadIdx.x;
-        uint32_t run = s_start[d] + base[(size_t)d * gridDim.x + blockIdx.x];
+    for (int d = threadIdx.x; d < kBins; d += 256) {
+        uint32_t run = s_start[d] + a.base[(size_t)d * a.row_stride + blockIdx.x];
 #pragma unroll
         for (int k = 0; k < kWaves; k++) {
             s_off[k][d] = run;
@@ -639,46 +766,46 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(uint32_t R, const ui
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
         if (blk + r * 64u + lane < R) {
-            const uint32_t d = (key[r] >> shift) & (kRadixBins - 1);
+            const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(kBins - 1);
             out[s_off[w][d] + lrank[r]] = key[r];
         }
     }
 }
 
-// rasterizer_impl.cu:124-146 identifyTileRanges on the sorted 32-bit keys; the packed sort's Gaussian ids
-// (point_list[i] = order[rank]) are materialised here too.
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_sorted,
-                                                          int rank_bits, const uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ point_list, uint2* ranges,
-                                                          unsigned char* __restrict__ pair_flag)
+// rasterizer_impl.cu:124-146 identifyTileRanges on the sorted words; the Gaussian ids (point_list[i] = order[rank])
+// are materialised here too.
+template <class Word>
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __restrict__ ap)
 {
+    const RangesArgs& a = *ap;
+    const int R = (int)a.hdr->num_pairs;
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
     if (i0 >= R) return;
+    const Word* __restrict__ sorted = reinterpret_cast<const Word*>(a.sorted);
+    unsigned char* __restrict__ pair_flag = a.pair_flag;
+    uint32_t* __restrict__ point_list = a.point_list;
+    uint2* ranges = a.ranges;
+    const int rank_bits = a.rank_bits;
     // the backward's "row written" flags start out zero (it puts the ones it consumed back itself)
     if (i0 + 4 <= R)
         *reinterpret_cast<uint32_t*>(pair_flag + i0) = 0u;
     else
         for (int k = i0; k < R; k++) pair_flag[k] = 0;
-    uint32_t key[4];
+    Word key[4];
     const int n = min(4, R - i0);
-    if (n == 4) {
-        const uint4 k4 = *reinterpret_cast<const uint4*>(tile_sorted + i0);
-        key[0] = k4.x; key[1] = k4.y; key[2] = k4.z; key[3] = k4.w;
-    } else {
-        for (int k = 0; k < 4; k++) key[k] = k < n ? tile_sorted[i0 + k] : 0u;
-    }
-    uint32_t prev = i0 ? tile_sorted[i0 - 1] >> rank_bits : 0xFFFFFFFFu;
-    if (rank_bits && order) {
-        const uint32_t mask = (1u << rank_bits) - 1u;
+    for (int k = 0; k < 4; k++) key[k] = k < n ? sorted[i0 + k] : (Word)0;
+    uint32_t prev = i0 ? word_tile(sorted[i0 - 1], rank_bits) : 0xFFFFFFFFu;
+    {
+        const Word mask = (((Word)1) << rank_bits) - 1;
         uint32_t id[4];
-        for (int k = 0; k < 4; k++) id[k] = k < n ? order[key[k] & mask] : 0u;
+        for (int k = 0; k < 4; k++) id[k] = k < n ? a.order[(uint32_t)(key[k] & mask)] : 0u;
         if (n == 4)
             *reinterpret_cast<uint4*>(point_list + i0) = make_uint4(id[0], id[1], id[2], id[3]);
         else
             for (int k = 0; k < n; k++) point_list[i0 + k] = id[k];
     }
     for (int k = 0; k < n; k++) {
-        const uint32_t cur = key[k] >> rank_bits;
+        const uint32_t cur = word_tile(key[k], rank_bits);
         const int i = i0 + k;
         if (i == 0)
             ranges[cur].x = 0;
@@ -691,65 +818,63 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t*
     }
 }
 
-void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s)
+template <class Word>
+static void issue_tile_binning_t(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
 {
-    const size_t Tn = (size_t)gx * gy;
-    if (R <= 0) {
-        R3_HIP(hipMemsetAsync(img.ranges, 0, Tn * sizeof(uint2), s));  // rasterizer_impl.cu:475
-        return;
+    const PairLayout& l = p.layout;
+    const uint32_t nbk = (p.reserve + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // == row_stride
+    const int bins = 1 << l.digit_bits;
+    hipLaunchKernelGGL(emit_pairs_kernel<Word>, dim3(nbk), dim3(256), 0, s, &a->emit);
+    for (int k = 0; k < l.passes; k++) {
+        const RadixArgs* ra = &a->radix[k];
+        if (k > 0) hipLaunchKernelGGL(radix_hist_kernel<Word>, dim3(nbk), dim3(256), 0, s, ra);
+        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(bins), dim3(256), 0, s, ra);
+        if (l.digit_bits == 7)
+            hipLaunchKernelGGL((radix_scatter_kernel<Word, 7>), dim3(nbk), dim3(256), 0, s, ra);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<Word, 8>), dim3(nbk), dim3(256), 0, s, ra);
     }
-    const int rank_bits = tile_rank_bits(P, Tn);
-    const int bits = (int)higher_msb((uint32_t)Tn);
-    const uint32_t nb = (uint32_t)((R + kEmitPerBlock - 1) / kEmitPerBlock);
-    static const bool rocprim_tiles = [] {   // R3DGS_TILE_SORT=rocprim: packed keys through rocPRIM's onesweep (A/B)
-        const char* v = getenv("R3DGS_TILE_SORT");
-        return v && std::string(v) == "rocprim";
-    }();
-    const bool own_radix = rank_bits && bits <= 2 * kRadixBits && !rocprim_tiles;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(nb), dim3(256), 0, s, P, (uint32_t)R, g.order, g.offsets, g.rect, gx, g.rec,
-                       rank_bits, b.tile_in, b.gauss_in, img.ranges, (uint32_t)Tn, own_radix ? b.radix_rows : nullptr);
-    size_t bytes = b.temp_bytes;
-    if (own_radix) {
-        // pass 1: low 7 tile bits (counts from the emission kernel), tile_in -> gauss_in (free in the packed sort)
-        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
-                           b.radix_total);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.tile_in, b.gauss_in, rank_bits,
-                           b.radix_base, b.radix_total);
-        // pass 2: the remaining tile bits, gauss_in -> tile_sorted
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, rank_bits + kRadixBits,
-                           b.radix_rows);
-        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(kRadixBins), dim3(256), 0, s, nb, b.radix_rows, b.radix_base,
-                           b.radix_total + kRadixBins);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, (uint32_t)R, b.gauss_in, b.tile_sorted,
-                           rank_bits + kRadixBits, b.radix_base, b.radix_total + kRadixBins);
-    } else if (rank_bits)
-        R3_HIP(rocprim::radix_sort_keys(b.temp, bytes, b.tile_in, b.tile_sorted, (size_t)R, rank_bits, rank_bits + bits, s));
+    hipLaunchKernelGGL(tile_ranges_kernel<Word>, dim3((p.reserve + 1023u) / 1024u), dim3(256), 0, s, &a->ranges);
+}
+
+void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
+{
+    if (p.layout.wide)
+        issue_tile_binning_t<unsigned long long>(p, a, s);
     else
-        R3_HIP(rocprim::radix_sort_pairs(b.temp, bytes, b.tile_in, b.tile_sorted, b.gauss_in, b.point_list, (size_t)R, 0,
-                                         bits, s));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 1023) / 1024), dim3(256), 0, s, R, b.tile_sorted, rank_bits,
-                       (const uint32_t*)g.order,
-                       b.point_list, img.ranges, b.pair_flag);
+        issue_tile_binning_t<uint32_t>(p, a, s);
 }
 
 // debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list
-__global__ __launch_bounds__(256) void export_keys_kernel(int R, int rank_bits,
-                                                          const uint32_t* __restrict__ tile_sorted,
+template <class Word>
+__global__ __launch_bounds__(256) void export_keys_kernel(int R, int rank_bits, const Word* __restrict__ sorted,
                                                           const uint32_t* __restrict__ point_list,
                                                           const uint32_t* __restrict__ depth_key, uint64_t* keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    keys[i] = ((uint64_t)(tile_sorted[i] >> rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
+    keys[i] = ((uint64_t)word_tile(sorted[i], rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
+}
+
+// which buffer of the blob holds the sorted words after the passes (see fill of RadixArgs in capi.hip)
+const char* sorted_words(const BinState& b, const PairLayout& l)
+{
+    if (l.wide) return (l.passes & 1) ? b.words_b : b.words_a;   // a -> b -> a (-> b)
+    return (l.passes & 1) ? b.words_b : b.words_c;                // a -> b -> c (-> b)
 }
 
 void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
                         hipStream_t s)
 {
     if (R <= 0) return;
-    hipLaunchKernelGGL(export_keys_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_rank_bits(P, n_tiles),
-                       b.tile_sorted, b.point_list,
-                       g.depth_key, keys_out);
+    const PairLayout l = pair_layout(P, n_tiles);
+    const char* sorted = sorted_words(b, l);
+    if (l.wide)
+        hipLaunchKernelGGL(export_keys_kernel<unsigned long long>, dim3((R + 255) / 256), dim3(256), 0, s, R, l.rank_bits,
+                           reinterpret_cast<const unsigned long long*>(sorted), b.point_list, g.depth_key, keys_out);
+    else
+        hipLaunchKernelGGL(export_keys_kernel<uint32_t>, dim3((R + 255) / 256), dim3(256), 0, s, R, l.rank_bits,
+                           reinterpret_cast<const uint32_t*>(sorted), b.point_list, g.depth_key, keys_out);
 }
 
 }  // namespace r3

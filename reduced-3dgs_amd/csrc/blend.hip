@@ -146,34 +146,11 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
-// Tuning knobs for profiling runs (results are identical for every value):
-//   R3DGS_FWD_PPL / R3DGS_BWD_PPL : pixels per lane, 4 (one wave per tile), 2 or 1 (four waves per tile)
-static int env_int(const char* env, int dflt, int lo, int hi)
-{
-    const char* v = getenv(env);
-    if (!v) return dflt;
-    const int p = atoi(v);
-    return (p >= lo && p <= hi) ? p : dflt;
-}
-
-struct BlendFwdArgs {
-    const uint2* ranges;
-    const uint32_t* point_list;
-    const GRec* rec;
-    int W, H, gx;
-    uint32_t nblocks;
-    const float* bg;
-    float* out_color;
-    float* final_T;
-    uint32_t* n_contrib;
-    int* touched;
-    float* transmittance;
-};
-
 template <int PPL, bool COUNTERS>
-__global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
+__global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __restrict__ ap)
 {
     __shared__ LdsRec s_rec[kChunk];
+    const BlendFwdArgs& a = *ap;   // pass block in device memory (scalar loads)
     __shared__ uint32_t s_id[kChunk];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -289,65 +266,36 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(BlendFwdArgs a)
 }
 
 template <int PPL>
-static void launch_fwd_ppl(const BlendFwdArgs& a, bool counters, hipStream_t s)
+static void launch_fwd_ppl(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 {
-    if (counters)
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(a.nblocks), dim3(64), 0, s, a);
+    const uint32_t nblocks = (uint32_t)(p.gx * p.gy * (4 / PPL));   // == a->nblocks
+    if (p.counters)
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, true>), dim3(nblocks), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(a.nblocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((blend_fwd_kernel<PPL, false>), dim3(nblocks), dim3(64), 0, s, a);
 }
 
-void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b, ImageState& img,
-                          float* out_color, int* touched, float* transmittance, hipStream_t s)
+void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 {
-    static const int PPL0 = env_int("R3DGS_FWD_PPL", 2, 1, 4);
-    static const int PPL = PPL0 == 3 ? 2 : PPL0;
-    BlendFwdArgs a;
-    a.ranges = img.ranges;
-    a.point_list = b.point_list;
-    a.rec = g.rec;
-    a.W = view.W;
-    a.H = view.H;
-    a.gx = (view.W + kTile - 1) / kTile;
-    a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
-    a.bg = view.bg;
-    a.out_color = out_color;
-    a.final_T = img.final_T;
-    a.n_contrib = img.n_contrib;
-    a.touched = touched;
-    a.transmittance = transmittance;
-    if (PPL == 4)
-        launch_fwd_ppl<4>(a, touched != nullptr, s);
-    else if (PPL == 2)
-        launch_fwd_ppl<2>(a, touched != nullptr, s);
+    if (p.fwd_ppl == 4)
+        launch_fwd_ppl<4>(p, a, s);
+    else if (p.fwd_ppl == 2)
+        launch_fwd_ppl<2>(p, a, s);
     else
-        launch_fwd_ppl<1>(a, touched != nullptr, s);
+        launch_fwd_ppl<1>(p, a, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-struct BlendBwdArgs {
-    const uint2* ranges;
-    const uint32_t* point_list;
-    const GRec* rec;
-    const float* final_T;
-    const uint32_t* n_contrib;
-    const float* dL_dpix;
-    int W, H, gx;
-    uint32_t nblocks;
-    const float* bg;
-    float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
-    unsigned char* pair_flag;  // [R] set for rows written in this pass
-};
-
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
 // 5 waves per SIMD for the 4-pixel-per-lane variant: 100 -> 96 VGPRs, no spills
 template <int PPL>
-__global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBwdArgs a)
+__global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
 {
     __shared__ LdsRec s_rec[kChunk];
+    const BlendBwdArgs& a = *ap;
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -468,37 +416,16 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(BlendBw
     }
 }
 
-template <int PPL>
-static void launch_bwd_ppl(const BlendBwdArgs& a, hipStream_t s)
+void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s)
 {
-    hipLaunchKernelGGL((blend_bwd_kernel<PPL>), dim3(a.nblocks), dim3(64), 0, s, a);
-}
-
-void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState& b, const ImageState& img,
-                           const float* dL_dpix, hipStream_t s)
-{
-    static const int PPL0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
-    static const int PPL = PPL0 == 3 ? 4 : PPL0;
-    BlendBwdArgs a;
-    a.ranges = img.ranges;
-    a.point_list = b.point_list;
-    a.rec = g.rec;
-    a.final_T = img.final_T;
-    a.n_contrib = img.n_contrib;
-    a.dL_dpix = dL_dpix;
-    a.W = view.W;
-    a.H = view.H;
-    a.gx = (view.W + kTile - 1) / kTile;
-    a.nblocks = (uint32_t)(a.gx * ((view.H + kTile - 1) / kTile) * (4 / PPL));
-    a.bg = view.bg;
-    a.pair_grad = b.pair_grad;
-    a.pair_flag = b.pair_flag;
-    if (PPL == 4)
-        launch_bwd_ppl<4>(a, s);
-    else if (PPL == 2)
-        launch_bwd_ppl<2>(a, s);
+    if (!p.has_pairs) return;
+    const uint32_t nblocks = (uint32_t)(p.gx * p.gy * (4 / p.bwd_ppl));   // == a->nblocks
+    if (p.bwd_ppl == 4)
+        hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, a);
+    else if (p.bwd_ppl == 2)
+        hipLaunchKernelGGL((blend_bwd_kernel<2>), dim3(nblocks), dim3(64), 0, s, a);
     else
-        launch_bwd_ppl<1>(a, s);
+        hipLaunchKernelGGL((blend_bwd_kernel<1>), dim3(nblocks), dim3(64), 0, s, a);
 }
 
 }  // namespace r3

@@ -3,28 +3,61 @@
 // Orchestration of one forward / backward pass; replaces CudaRasterizer::Rasterizer::{forward,
 // inferenceForward, backward, markVisible} (cuda_rasterizer/rasterizer_impl.cu:149-161, :206-355,
 // :359-504, :508-630 of /root/reference/submodules/diff-gaussian-rasterization).
-// Differences in how the work is issued (results are the same):
-//   * everything runs on the caller's HIP stream; the only host synchronisation is the read-back of
-//     num_rendered, which sizes the caller-owned binning blob (same structural sync as the reference, but
-//     R is produced by the first kernel and fetched on a side stream while the depth sort runs, so the GPU
-//     does not idle during the host round trip);
-//   * the SH -> RGB kernel (the forward's HBM-heavy stream) runs on that side stream too, underneath the
-//     launch-latency-bound sorts;
+// How the work is issued (results are the same as the reference's):
+//   * The reference sizes its binning buffer from a blocking read-back of num_rendered in the middle of every forward
+//     (rasterizer_impl.cu:441-450).  Here the hot path (r3dgs_forward_reserved) takes a pair RESERVATION instead:
+//     the caller allocates the binning blob for `reserve` pairs up front, every kernel reads the actual count from
+//     the device header, and the host never waits.  r3dgs_reserve_hint() proposes the reservation from the
+//     num_rendered of earlier passes (published by the passes themselves in host-mapped memory, harvested lazily).
+//     r3dgs_forward keeps the reference's exact-size contract (allocator callbacks, returns num_rendered): it waits
+//     for that one number by polling host memory -- no HIP call, bounded by a deadline.
+//   * All kernels of a pass read their arguments from one device-resident block (common.h), so the launch chain of
+//     a shape never changes: it is captured once into a hipGraph and replayed with ONE hipGraphLaunch per pass
+//     (+ one hipGraphExecKernelNodeSetParams that carries the new block).  Measured on the MI355X box
+//     (tools/launch_bench*.hip): 20 direct launches cost 54 us of host time idle and 0.3-2.3 ms on a loaded /
+//     CPU-throttled host, one graph launch 6-10 us either way; a graph with a side-stream branch costs as much as
+//     direct launches, so the chain is linear.
 //   * no per-call hipMalloc/hipFree: all scratch lives in the three caller blobs;
-//   * `debug` makes every stage synchronise and surface its error (the reference's CHECK_CUDA).
+//   * `debug` and the per-stage timers issue the same chain with direct launches and synchronise / record events
+//     between stages (the reference's CHECK_CUDA).
 #include "../../include/r3dgs_rasterizer.h"
 
+#include <time.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
 
 #include "common.h"
 
+namespace r3 {
+int env_int(const char* env, int dflt, int lo, int hi)
+{
+    const char* v = getenv(env);
+    if (!v) return dflt;
+    const int p = atoi(v);
+    return (p >= lo && p <= hi) ? p : dflt;
+}
+}  // namespace r3
+
 namespace {
 
+using namespace r3;
+
 thread_local std::string g_last_error;
+
+bool env_is(const char* name, const char* value)
+{
+    const char* v = getenv(name);
+    return v && std::string(v) == value;
+}
 
 size_t cached_depth_temp(size_t P)
 {
@@ -33,35 +66,32 @@ size_t cached_depth_temp(size_t P)
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(P);
     if (it != cache.end()) return it->second;
-    size_t b = r3::depth_sort_temp_bytes(P);
+    size_t b = depth_sort_temp_bytes(P);
     cache[P] = b;
     return b;
 }
 
-// tile-sort temp grows with R; query on a rounded-up size so the cache stays small
-size_t round_up_R(size_t R)
+// ---- the argument-block writers ------------------------------------------------------------------------------------
+// The block travels as the kernel's by-value argument (so a replayed graph gets the new block with one
+// hipGraphExecKernelNodeSetParams and nothing the host writes later can race with a queued launch) and is copied
+// word-wise straight out of the kernarg segment: taking the parameter's address would first spill it to scratch.
+template <class Block>
+__global__ __launch_bounds__(256) void write_args_kernel(Block* dst, Block v)
 {
-    size_t g = 1 << 16;
-    return ((R + g - 1) / g) * g;
-}
-size_t cached_tile_temp(size_t R)
-{
-    static std::mutex mu;
-    static std::unordered_map<size_t, size_t> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    const size_t key = round_up_R(R ? R : 1);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    size_t b = r3::tile_sort_temp_bytes(key);
-    cache[key] = b;
-    return b;
+    static_assert(alignof(Block) == 8 && sizeof(Block) % 4 == 0, "kernarg layout: [dst (8 B)][block]");
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4))) * KernargWords;
+    KernargWords s = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(Block*) / 4;
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t k = threadIdx.x; k < sizeof(Block) / 4; k += 256) d[k] = s[k];
+#endif
+    (void)v;
 }
 
 // ---- optional per-stage timing with HIP events on the caller's stream (r3dgs_profile_*) ----------
-enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
 struct Profiler {
     std::mutex mu;
-    unsigned mask = 0;   // bit (stage): record an event pair around that stage
+    std::atomic<unsigned> mask{0};   // bit (stage): record an event pair around that stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> used[kNumStages];
     std::vector<hipEvent_t> pool;
     hipEvent_t get()
@@ -76,61 +106,627 @@ struct Profiler {
         return e;
     }
 } g_prof;
+constexpr unsigned kFwdStages = (1u << kPre) | (1u << kDepthSort) | (1u << kBinning) | (1u << kBlendFwd) | (1u << kColor);
+constexpr unsigned kBwdStages = (1u << kBlendBwd) | (1u << kPreBwd);
 
-struct StageTimer {
-    int stage;
-    hipStream_t s;
-    hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(int stage_, hipStream_t s_) : stage(stage_), s(s_)
+struct StageRun {   // direct-issue mode: events and / or debug synchronisation around each stage
+    bool debug;
+    hipEvent_t a[kNumStages] = {};
+    void begin(int stage, hipStream_t s)
     {
-        if (!((g_prof.mask >> stage_) & 1u)) return;
+        if (!((g_prof.mask.load() >> stage) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        a = g_prof.get();
-        b = g_prof.get();
-        R3_HIP(hipEventRecord(a, s));
+        a[stage] = g_prof.get();
+        R3_HIP(hipEventRecord(a[stage], s));
     }
-    void stop()
+    void end(int stage, const char* what, hipStream_t s)
     {
-        if (!a) return;
-        R3_HIP(hipEventRecord(b, s));
-        std::lock_guard<std::mutex> lk(g_prof.mu);
-        g_prof.used[stage].push_back({a, b});
-        a = nullptr;
+        if (a[stage]) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            hipEvent_t b = g_prof.get();
+            R3_HIP(hipEventRecord(b, s));
+            g_prof.used[stage].push_back({a[stage], b});
+            a[stage] = nullptr;
+        }
+        check_launch(what, s, debug);
     }
 };
 
-// Host-side resources for the num_rendered read-back: a non-blocking side stream, two events and one
-// pinned word, per (host thread, device).  The copy is ordered after the preprocess kernel by an event and
-// runs beside the depth sort, so the structural host round trip of the forward is hidden behind GPU work.
-struct ReadbackCtx {
-    hipStream_t side = nullptr, side2 = nullptr;
-    hipEvent_t after_pre = nullptr, copied = nullptr, colored = nullptr, after_hist = nullptr, copied2 = nullptr;
-    hipEvent_t geom_done = nullptr;
-    r3::GeomHeader* pinned = nullptr;
+// ---- pass tickets and the host-mapped PassInfo ring ---------------------------------------------------------------
+constexpr uint32_t kInfoRing = 1024;
+struct InfoRing {
+    PassInfo* host = nullptr;
+    PassInfo* dev = nullptr;
 };
-ReadbackCtx& readback_ctx()
+std::mutex g_ring_mu;
+std::unordered_map<int, InfoRing> g_rings;
+std::atomic<uint64_t> g_next_ticket{1};
+
+InfoRing& info_ring(int dev)
 {
-    thread_local std::unordered_map<int, ReadbackCtx> per_device;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    InfoRing& r = g_rings[dev];
+    if (!r.host) {
+        R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.host), sizeof(PassInfo) * kInfoRing,
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        memset(r.host, 0, sizeof(PassInfo) * kInfoRing);
+        R3_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.dev), r.host, 0));
+    }
+    return r;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Wait until the pass has published its header (num_rendered, visible).  Plain loads of host memory: a short spin,
+// then sleeps -- a spinning thread burns CPU quota that a containerised trainer may not have -- and a deadline
+// (R3DGS_SYNC_TIMEOUT_MS, default 30 s) that turns a hung GPU into an error instead of a hung host.
+const volatile PassInfo* wait_info(int dev, uint64_t ticket)
+{
+    static const int timeout_ms = env_int("R3DGS_SYNC_TIMEOUT_MS", 30000, 1, 3600000);
+    const volatile PassInfo* info = info_ring(dev).host + ticket % kInfoRing;
+    const uint32_t seq = (uint32_t)ticket;
+    const double t0 = now_ms();
+    for (int spins = 0;; spins++) {
+        if (info->seq == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return info;
+        }
+        if (spins < 2000) continue;
+        const double waited = now_ms() - t0;
+        if (waited > timeout_ms)
+            throw Error("timed out after " + std::to_string(timeout_ms) + " ms waiting for num_rendered of pass " +
+                        std::to_string(ticket) + " (GPU hung or stream never ran?)");
+        timespec ts = {0, waited < 2.0 ? 5000 : 50000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
+// ---- reservation advice from the passes seen so far ----------------------------------------------------------------
+struct Pending {
+    uint64_t ticket;
+    int dev, P, W, H;
+    uint32_t reserve;   // 0xFFFFFFFF for exact-size passes
+};
+struct ViewStats {
+    std::deque<std::pair<int, uint32_t>> recent;   // (P, num_rendered) of the last passes of this (device, W, H)
+    std::map<int, uint32_t> sticky;                // P -> reservation handed out (kept stable: it keys the graph cache)
+    int prefer_generic = 0;                        // passes left to route through the generic depth sort
+};
+struct Advisor {
+    std::mutex mu;
+    std::deque<Pending> pending;
+    std::map<std::tuple<int, int, int>, ViewStats> views;
+    uint64_t overflow_events = 0;
+    uint32_t last_overflow_rendered = 0, last_overflow_reserve = 0;
+} g_adv;
+constexpr size_t kRecentWindow = 1024;
+
+void observe_locked(const Pending& p, uint32_t rendered, uint32_t sort_overflow)
+{
+    ViewStats& v = g_adv.views[{p.dev, p.W, p.H}];
+    v.recent.push_back({p.P, rendered});
+    if (v.recent.size() > kRecentWindow) v.recent.pop_front();
+    if (sort_overflow) v.prefer_generic = 64;
+    if (p.reserve != 0xFFFFFFFFu && rendered > p.reserve) {
+        g_adv.overflow_events++;
+        g_adv.last_overflow_rendered = rendered;
+        g_adv.last_overflow_reserve = p.reserve;
+    }
+}
+
+// passes that have published their header since the last call
+void harvest_locked()
+{
+    const uint64_t newest = g_next_ticket.load();
+    while (!g_adv.pending.empty()) {
+        const Pending p = g_adv.pending.front();
+        if (newest - p.ticket >= kInfoRing - 8) {   // its slot is about to be / was reused: forget it
+            g_adv.pending.pop_front();
+            continue;
+        }
+        const volatile PassInfo* info = info_ring(p.dev).host + p.ticket % kInfoRing;
+        if (info->seq != (uint32_t)p.ticket) break;   // not there yet (tickets of one stream complete in order)
+        std::atomic_thread_fence(std::memory_order_acquire);
+        observe_locked(p, info->num_rendered, info->sort_overflow);
+        g_adv.pending.pop_front();
+    }
+    if (g_adv.pending.size() > 4 * kInfoRing) g_adv.pending.clear();
+}
+
+uint32_t reserve_hint(int dev, int P, int W, int H)
+{
+    static const bool off = env_is("R3DGS_RESERVE", "off");
+    static const double slack = 0.01 * env_int("R3DGS_RESERVE_SLACK_PCT", 150, 100, 1600);
+    if (off || P <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    harvest_locked();
+    auto it = g_adv.views.find({dev, W, H});
+    if (it == g_adv.views.end() || it->second.recent.empty()) return 0;
+    ViewStats& v = it->second;
+    double mx = 0.0;
+    for (auto& e : v.recent) {   // scaled to the current Gaussian count (densification / pruning between passes)
+        const double r = e.first > 0 ? (double)e.second * ((double)P / (double)e.first) : (double)e.second;
+        mx = r > mx ? r : mx;
+    }
+    const double want = mx * slack + 65536.0;
+    auto st = v.sticky.find(P);
+    if (st != v.sticky.end() && (double)st->second >= mx * (1.0 + 0.4 * (slack - 1.0)) && (double)st->second <= 4.0 * want)
+        return st->second;
+    if (want >= 2147000000.0) return 0;   // beyond a 31-bit pair count: exact path decides
+    const uint32_t r = (uint32_t)(((uint64_t)want + 65535u) / 65536u * 65536u);
+    if (v.sticky.size() > 64) v.sticky.clear();
+    v.sticky[P] = r;
+    return r;
+}
+
+// ---- launch contexts: device argument blocks and captured graphs ---------------------------------------------------
+struct CtxKey {
+    int dev, kind;   // kind 0: forward, 1: backward
+    hipStream_t stream;
+    int P, M, W, H;
+    uint32_t reserve, flags;
+    bool operator<(const CtxKey& o) const
+    {
+        return std::tie(dev, kind, stream, P, M, W, H, reserve, flags) <
+               std::tie(o.dev, o.kind, o.stream, o.P, o.M, o.W, o.H, o.reserve, o.flags);
+    }
+};
+struct GraphCtx {
+    void* d_args = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t node0 = nullptr;
+    uint64_t last_use = 0;
+};
+std::mutex g_ctx_mu;
+std::map<CtxKey, GraphCtx> g_graphs;
+std::map<std::tuple<int, int, hipStream_t>, void*> g_direct_blocks;   // (device, kind, stream) -> device block
+std::unordered_map<int, hipStream_t> g_capture_streams;
+uint64_t g_use_clock = 0;
+constexpr size_t kMaxGraphs = 48;
+
+void* direct_block(int dev, int kind, hipStream_t s, size_t bytes)
+{
+    void*& p = g_direct_blocks[{dev, kind, s}];
+    if (!p) R3_HIP(hipMalloc(&p, bytes));
+    return p;
+}
+
+hipStream_t capture_stream(int dev)
+{
+    hipStream_t& s = g_capture_streams[dev];
+    if (!s) R3_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+
+void evict_graphs_locked()
+{
+    while (g_graphs.size() > kMaxGraphs) {
+        auto victim = g_graphs.begin();
+        for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        // the exec may still be queued on its stream: wait for that stream before tearing it down (rare path)
+        (void)hipStreamSynchronize(victim->first.stream);
+        if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+        if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+        if (victim->second.d_args) (void)hipFree(victim->second.d_args);
+        g_graphs.erase(victim);
+    }
+}
+
+bool graphs_enabled()
+{
+    static const bool on = !env_is("R3DGS_GRAPH", "0");
+    return on;
+}
+
+// ---- the launch chains -----------------------------------------------------------------------------------------------
+struct NoHooks {
+    void begin(int, hipStream_t) {}
+    void end(int, const char*, hipStream_t) {}
+};
+
+// phases: 1 = geometry + header (everything num_rendered depends on), 2 = the rest
+template <class Hooks>
+void issue_forward(const FwdPlan& p, const FwdPassArgs* d, hipStream_t s, int phases, Hooks& h, GeomState* g_host)
+{
+    if (phases & 1) {
+        h.begin(kPre, s);
+        issue_preprocess_geom(p, &d->pre, s);
+        h.end(kPre, "preprocess", s);
+        issue_header_reduce(&d->header, s);
+    }
+    if (phases & 2) {
+        h.begin(kDepthSort, s);
+        if (p.generic_depth_sort)
+            run_generic_depth_sort(p.P, *g_host, s);
+        else
+            issue_depth_bucket_sort(p, &d->depth, s);
+        h.end(kDepthSort, "depth sort + scan", s);
+        h.begin(kColor, s);
+        issue_preprocess_color(p, &d->pre, s);
+        h.end(kColor, "SH colours", s);
+        h.begin(kBinning, s);
+        issue_tile_binning(p, d, s);
+        h.end(kBinning, "tile binning", s);
+        h.begin(kBlendFwd, s);
+        issue_blend_forward(p, &d->blend, s);
+        h.end(kBlendFwd, "blend forward", s);
+    }
+}
+
+template <class Hooks>
+void issue_backward(const BwdPlan& p, const BwdPassArgs* d, hipStream_t s, Hooks& h)
+{
+    h.begin(kBlendBwd, s);
+    // the pair flags are all zero here: the forward's tile_ranges kernel clears them and pair_reduce puts every
+    // flag it consumed back to zero, so neither pass pays for a fill of its own
+    issue_blend_backward(p, &d->blend, s);
+    issue_pair_reduce(p, &d->reduce, s);
+    h.end(kBlendBwd, "blend backward", s);
+    h.begin(kPreBwd, s);
+    issue_preprocess_backward(p, &d->pre, s);
+    h.end(kPreBwd, "preprocess backward", s);
+}
+
+template <class Block>
+void launch_write_args(Block* dst, const Block& v, hipStream_t s)
+{
+    hipLaunchKernelGGL(write_args_kernel<Block>, dim3(1), dim3(256), 0, s, dst, v);
+}
+
+// Replays (capturing it first if this shape is new) the launch chain of a pass as one graph launch on `s`.
+template <class Block, class Plan, class IssueFn>
+void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStream_t s, IssueFn&& issue)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    GraphCtx& c = g_graphs[key];
+    if (!c.exec) {
+        try {
+            R3_HIP(hipMalloc(&c.d_args, sizeof(Block)));
+            hipStream_t cap = capture_stream(key.dev);
+            R3_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+            try {
+                launch_write_args(static_cast<Block*>(c.d_args), args, cap);
+                issue(plan, static_cast<const Block*>(c.d_args), cap);
+            } catch (...) {
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(cap, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                throw;
+            }
+            R3_HIP(hipStreamEndCapture(cap, &c.graph));
+            size_t n_root = 0;
+            R3_HIP(hipGraphGetRootNodes(c.graph, nullptr, &n_root));
+            if (n_root != 1) throw Error("captured pass graph is not a linear chain");
+            R3_HIP(hipGraphGetRootNodes(c.graph, &c.node0, &n_root));
+            R3_HIP(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+        } catch (...) {
+            if (c.graph) (void)hipGraphDestroy(c.graph);
+            if (c.d_args) (void)hipFree(c.d_args);
+            g_graphs.erase(key);
+            throw;
+        }
+        evict_graphs_locked();
+    }
+    GraphCtx& ctx = g_graphs[key];
+    ctx.last_use = ++g_use_clock;
+    Block* dst = static_cast<Block*>(ctx.d_args);
+    Block copy = args;
+    void* params[2] = {&dst, &copy};
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.func = reinterpret_cast<void*>(write_args_kernel<Block>);
+    kp.gridDim = dim3(1);
+    kp.blockDim = dim3(256);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = params;
+    kp.extra = nullptr;
+    R3_HIP(hipGraphExecKernelNodeSetParams(ctx.exec, ctx.node0, &kp));   // by-value block: copied at this call
+    R3_HIP(hipGraphLaunch(ctx.exec, s));
+}
+
+// ---- argument blocks -------------------------------------------------------------------------------------------------
+struct FwdCall {
+    int P;
+    const int* D;
+    int M;
+    const int *coeffsNum, *perBand, *cumSum;
+    const float* background;
+    int width, height;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales;
+    float scale_modifier;
+    const float *rotations, *cov3D_precomp, *viewmatrix, *projmatrix, *cam_pos;
+    float tan_fovx, tan_fovy;
+    float* out_color;
+    int* out_touched_pixels;
+    float* out_transmittance;
+    int* radii;
+    int calculate_mean_transmittance, debug;
+    hipStream_t stream;
+};
+
+void validate_forward(const FwdCall& c)
+{
+    if (!c.means3D || !c.opacities || !c.viewmatrix || !c.projmatrix || !c.cam_pos || !c.background || !c.out_color)
+        throw Error("a required pointer is NULL");
+    if (!c.colors_precomp && !c.shs) throw Error("provide SHs or precomputed colours");
+    if (!c.cov3D_precomp && (!c.scales || !c.rotations)) throw Error("provide scale/rotation or a precomputed 3D covariance");
+    if (!c.colors_precomp && !c.coeffsNum && (c.M < 1 || c.M > 16)) throw Error("SH coefficient count M must be in [1,16]");
+    if (!c.colors_precomp && !c.coeffsNum && !c.D) throw Error("per-Gaussian degrees must be provided with SHs");
+    if (c.width <= 0 || c.height <= 0) throw Error("image size must be positive");
+    if (c.calculate_mean_transmittance && (!c.out_touched_pixels || !c.out_transmittance))
+        throw Error("counter mode needs out_touched_pixels and out_transmittance");
+}
+
+FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
+{
+    static const int ppl0 = env_int("R3DGS_FWD_PPL", 2, 1, 4);
+    static const int color_grid = env_int("R3DGS_COLOR_GRID", 512, 0, 1 << 20);
+    static const bool generic_env = env_is("R3DGS_DEPTH_SORT", "generic");   // forces the rocPRIM path (A/B runs, tests)
+    FwdPlan p;
+    p.P = c.P;
+    p.M = c.M;
+    p.W = c.width;
+    p.H = c.height;
+    p.gx = (c.width + kTile - 1) / kTile;
+    p.gy = (c.height + kTile - 1) / kTile;
+    p.reserve = reserve;
+    p.layout = pair_layout(c.P, (size_t)p.gx * p.gy);
+    p.nb = depth_bucket_count((size_t)c.P);
+    p.ragged = (c.coeffsNum != nullptr && !c.colors_precomp) ? 1 : 0;
+    p.counters = c.calculate_mean_transmittance ? 1 : 0;
+    p.fwd_ppl = ppl0 == 3 ? 2 : ppl0;
+    p.color_grid = color_grid;
+    p.generic_depth_sort = (generic_env || c.P >= (1 << 24)) ? 1 : 0;   // the bucket histogram packs the count in 24 bits
+    return p;
+}
+
+void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const GeomState& g, const BinState* b,
+                   const ImageState& img, PassInfo* info_dev, uint64_t ticket)
+{
+    memset(&a, 0, sizeof(a));
+    int* radii = c.radii ? c.radii : g.radii_internal;
+    FwdInputs& in = a.pre.in;
+    in.P = c.P;
+    in.M = c.M;
+    in.degrees = c.D;
+    in.means3D = c.means3D;
+    in.scales = c.scales;
+    in.rotations = c.rotations;
+    in.opacities = c.opacities;
+    in.shs = c.shs;
+    in.cov3D_precomp = c.cov3D_precomp;
+    in.colors_precomp = c.colors_precomp;
+    in.coeffs_num = p.ragged ? c.coeffsNum : nullptr;
+    in.per_band_count = p.ragged ? c.perBand : nullptr;
+    in.cumsum_count = p.ragged ? c.cumSum : nullptr;
+    ViewParams& v = a.pre.view;
+    v.view = c.viewmatrix;
+    v.proj = c.projmatrix;
+    v.campos = c.cam_pos;
+    v.bg = c.background;
+    v.tan_fovx = c.tan_fovx;
+    v.tan_fovy = c.tan_fovy;
+    v.W = c.width;
+    v.H = c.height;
+    v.scale_modifier = c.scale_modifier;
+    a.pre.rec = g.rec;
+    a.pre.rect = g.rect;
+    a.pre.depth_key = g.depth_key;
+    a.pre.tiles = g.tiles;
+    a.pre.partials = g.partials;
+    a.pre.radii = radii;
+    a.pre.color_blocks = (c.P + kPreBlockSize - 1) / kPreBlockSize;
+
+    a.header.parts = g.partials;
+    a.header.n_parts = (int)pre_partials((size_t)c.P);
+    a.header.hdr = g.header;
+    a.header.info = info_dev;
+    a.header.ticket = (uint32_t)ticket;
+    a.header.reserve = p.reserve;
+
+    DepthArgs& d = a.depth;
+    d.P = c.P;
+    d.nb = p.nb;
+    d.rows = (int)depth_hist_rows((size_t)c.P);
+    d.key = g.depth_key;
+    d.tiles = g.tiles;
+    d.hdr = g.header;
+    d.info = info_dev;
+    d.ds = g.dsort;
+    d.hist_rows = g.hist_rows;
+    d.hist_base = g.hist_base;
+    d.key_sorted = g.key_sorted;
+    d.bucket_id = g.bucket_id;
+    d.ovf_key = g.ovf_key;
+    d.ovf_id = g.ovf_id;
+    d.order = g.order;
+    d.offsets = g.offsets;
+
+    const PairLayout& l = p.layout;
+    const size_t Tn = (size_t)p.gx * p.gy;
+    if (b) {
+        const uint32_t stride = (p.reserve + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;
+        EmitArgs& e = a.emit;
+        e.P = c.P;
+        e.gx = p.gx;
+        e.hdr = g.header;
+        e.order = g.order;
+        e.offsets = g.offsets;
+        e.rect = g.rect;
+        e.rec = g.rec;
+        e.rank_bits = l.rank_bits;
+        e.digit_bits = l.digit_bits;
+        e.words_out = b->words_a;
+        e.pair_rank = l.wide ? b->pair_rank : nullptr;
+        e.ranges = img.ranges;
+        e.n_tiles = (uint32_t)Tn;
+        e.radix_rows = b->radix_rows;
+        e.row_stride = stride;
+        // buffer chain of the passes: narrow a -> b -> c (-> b), wide a -> b -> a (-> b); words_a of the narrow layout
+        // survives for the backward (pair_rank aliases it)
+        const char* src = b->words_a;
+        for (int k = 0; k < l.passes; k++) {
+            char* dst = l.wide ? ((k & 1) ? b->words_a : b->words_b) : ((k & 1) ? b->words_c : b->words_b);
+            RadixArgs& r = a.radix[k];
+            r.hdr = g.header;
+            r.in = src;
+            r.out = dst;
+            r.shift = l.rank_bits + k * l.digit_bits;
+            r.digit_bits = l.digit_bits;
+            r.rows = b->radix_rows;
+            r.base = b->radix_base;
+            r.total = b->radix_total + k * kMaxRadixBins;
+            r.row_stride = stride;
+            src = dst;
+        }
+        if (src != sorted_words(*b, l)) throw Error("internal: sorted-word buffer mismatch");
+        RangesArgs& t = a.ranges;
+        t.hdr = g.header;
+        t.sorted = src;
+        t.rank_bits = l.rank_bits;
+        t.order = g.order;
+        t.point_list = b->point_list;
+        t.ranges = img.ranges;
+        t.pair_flag = b->pair_flag;
+    }
+    BlendFwdArgs& f = a.blend;
+    f.ranges = img.ranges;
+    f.point_list = b ? b->point_list : nullptr;
+    f.rec = g.rec;
+    f.W = c.width;
+    f.H = c.height;
+    f.gx = p.gx;
+    f.nblocks = (uint32_t)(p.gx * p.gy * (4 / p.fwd_ppl));
+    f.bg = c.background;
+    f.out_color = c.out_color;
+    f.final_T = img.final_T;
+    f.n_contrib = img.n_contrib;
+    f.touched = p.counters ? c.out_touched_pixels : nullptr;
+    f.transmittance = p.counters ? c.out_transmittance : nullptr;
+}
+
+uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
+{
+    return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
+           ((uint32_t)p.layout.wide << 5) | ((uint32_t)(c.colors_precomp != nullptr) << 6);
+}
+
+int current_device()
+{
     int dev = 0;
     R3_HIP(hipGetDevice(&dev));
-    ReadbackCtx& c = per_device[dev];
-    if (!c.side) {
-        // the SH -> RGB kernel on `side` is bandwidth-heavy filler under the latency-bound sort kernels of the
-        // caller's stream: lowest priority, so that their workgroups are dispatched first (at equal priority the
-        // depth scatter kernel took 46 us instead of 14 us next to it)
-        int prio_low = 0, prio_high = 0;
-        R3_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        R3_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio_low));
-        R3_HIP(hipStreamCreateWithPriority(&c.side2, hipStreamNonBlocking, prio_high));
-        R3_HIP(hipEventCreateWithFlags(&c.geom_done, hipEventDisableTiming));
-        R3_HIP(hipEventCreateWithFlags(&c.after_hist, hipEventDisableTiming));
-        R3_HIP(hipEventCreateWithFlags(&c.copied2, hipEventDisableTiming));
-        R3_HIP(hipEventCreateWithFlags(&c.after_pre, hipEventDisableTiming));
-        R3_HIP(hipEventCreateWithFlags(&c.copied, hipEventDisableTiming));
-        R3_HIP(hipEventCreateWithFlags(&c.colored, hipEventDisableTiming));
-        R3_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(r3::GeomHeader), hipHostMallocDefault));
+    return dev;
+}
+
+uint64_t new_ticket(int dev, const FwdCall& c, uint32_t reserve, PassInfo** info_dev)
+{
+    const uint64_t ticket = g_next_ticket.fetch_add(1);
+    InfoRing& ring = info_ring(dev);
+    *info_dev = ring.dev + ticket % kInfoRing;
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    g_adv.pending.push_back({ticket, dev, c.P, c.width, c.height, reserve});
+    return ticket;
+}
+
+bool take_prefer_generic(int dev, const FwdCall& c)
+{
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    auto it = g_adv.views.find({dev, c.width, c.height});
+    if (it == g_adv.views.end() || it->second.prefer_generic <= 0) return false;
+    it->second.prefer_generic--;
+    return true;
+}
+
+// Exact-size forward (the reference's contract): allocator callbacks, returns num_rendered.
+int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer, void* binning_user,
+                  r3dgs_alloc_fn imageBuffer, void* image_user, const FwdCall& c)
+{
+    if (c.P <= 0) return 0;
+    if (!geometryBuffer || !binningBuffer || !imageBuffer) throw Error("allocator callbacks must not be NULL");
+    validate_forward(c);
+    hipStream_t s = c.stream;
+    const int dev = current_device();
+    FwdPlan plan = make_fwd_plan(c, 0xFFFFFFFFu);
+    if (!plan.generic_depth_sort && take_prefer_generic(dev, c)) plan.generic_depth_sort = 1;
+    prepare_depth_bucket_sort(plan.nb);
+    const size_t depth_temp = cached_depth_temp((size_t)c.P);
+    char* gptr = geometryBuffer(required_bytes<GeomState>((size_t)c.P, depth_temp), geometry_user);
+    if (!gptr) throw Error("geometry allocator returned NULL");
+    GeomState geom = GeomState::carve(gptr, (size_t)c.P, depth_temp);
+    const size_t N = (size_t)c.width * c.height, Tn = (size_t)plan.gx * plan.gy;
+    char* iptr = imageBuffer(required_bytes<ImageState>(N, Tn), image_user);
+    if (!iptr) throw Error("image allocator returned NULL");
+    ImageState img = ImageState::carve(iptr, N, Tn);
+
+    PassInfo* info_dev = nullptr;
+    const uint64_t ticket = new_ticket(dev, c, 0xFFFFFFFFu, &info_dev);
+    FwdPassArgs* d_args;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
     }
-    return c;
+    StageRun hooks{c.debug != 0};
+    FwdPassArgs args;
+    fill_fwd_args(args, plan, c, geom, nullptr, img, info_dev, ticket);
+    launch_write_args(d_args, args, s);
+    issue_forward(plan, d_args, s, 1, hooks, &geom);
+    // the one structural wait of this entry point (the reference's cudaMemcpy at rasterizer_impl.cu:446)
+    const volatile PassInfo* info = wait_info(dev, ticket);
+    const uint32_t R = info->num_rendered;
+    if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
+    plan.reserve = R ? R : 1u;
+    char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide), binning_user);
+    if (!bptr) throw Error("binning allocator returned NULL");
+    BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide);
+    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket);
+    launch_write_args(d_args, args, s);
+    issue_forward(plan, d_args, s, 2, hooks, &geom);
+    return (int)R;
+}
+
+// Reserved forward: caller-provided blobs, no host wait.  Returns the pass ticket.
+long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, const FwdCall& c)
+{
+    if (c.P <= 0) return 0;
+    if (reserve < 1) throw Error("the pair reservation must be >= 1");
+    if (!geom_buffer || !binning_buffer || !image_buffer) throw Error("state buffers must not be NULL");
+    validate_forward(c);
+    hipStream_t s = c.stream;
+    const int dev = current_device();
+    FwdPlan plan = make_fwd_plan(c, (uint32_t)reserve);
+    if (!plan.generic_depth_sort && take_prefer_generic(dev, c)) plan.generic_depth_sort = 1;
+    prepare_depth_bucket_sort(plan.nb);
+    const size_t depth_temp = cached_depth_temp((size_t)c.P);
+    GeomState geom = GeomState::carve(geom_buffer, (size_t)c.P, depth_temp);
+    ImageState img = ImageState::carve(image_buffer, (size_t)c.width * c.height, (size_t)plan.gx * plan.gy);
+    BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide);
+    PassInfo* info_dev = nullptr;
+    const uint64_t ticket = new_ticket(dev, c, plan.reserve, &info_dev);
+    FwdPassArgs args;
+    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket);
+    const bool direct = !graphs_enabled() || c.debug || plan.generic_depth_sort || (g_prof.mask.load() & kFwdStages);
+    if (direct) {
+        FwdPassArgs* d_args;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
+        }
+        StageRun hooks{c.debug != 0};
+        launch_write_args(d_args, args, s);
+        issue_forward(plan, d_args, s, 3, hooks, &geom);
+    } else {
+        const CtxKey key{dev, 0, s, c.P, c.M, c.width, c.height, plan.reserve, fwd_flags(plan, c)};
+        launch_graph(key, plan, args, s, [](const FwdPlan& p, const FwdPassArgs* d, hipStream_t cs) {
+            NoHooks nh;
+            issue_forward(p, d, cs, 3, nh, nullptr);
+        });
+    }
+    return (long long)ticket;
 }
 
 template <class F>
@@ -145,161 +741,59 @@ int guarded(F&& f)
     }
 }
 
-int forward_impl(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer, void* binning_user,
-                 r3dgs_alloc_fn imageBuffer, void* image_user, int P, const int* D, int M, const int* coeffsNum,
-                 const int* perBand, const int* cumSum, const float* background, int width, int height,
-                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
-                 float* out_color, int* out_touched_pixels, float* out_transmittance, int* radii,
-                 int calculate_mean_transmittance, int debug, void* stream)
+template <class F>
+long long guarded_ll(F&& f)
 {
-    using namespace r3;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (P <= 0) return 0;
-    if (!geometryBuffer || !binningBuffer || !imageBuffer) throw Error("allocator callbacks must not be NULL");
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !out_color)
-        throw Error("a required pointer is NULL");
-    if (!colors_precomp && !shs) throw Error("provide SHs or precomputed colours");
-    if (!cov3D_precomp && (!scales || !rotations)) throw Error("provide scale/rotation or a precomputed 3D covariance");
-    if (!colors_precomp && !coeffsNum && (M < 1 || M > 16)) throw Error("SH coefficient count M must be in [1,16]");
-    if (!colors_precomp && !coeffsNum && !D) throw Error("per-Gaussian degrees must be provided with SHs");
-    if (width <= 0 || height <= 0) throw Error("image size must be positive");
-    if (calculate_mean_transmittance && (!out_touched_pixels || !out_transmittance))
-        throw Error("counter mode needs out_touched_pixels and out_transmittance");
-
-    const int gx = (width + kTile - 1) / kTile, gy = (height + kTile - 1) / kTile;
-    const size_t depth_temp = cached_depth_temp((size_t)P);
-    char* gptr = geometryBuffer(required_bytes<GeomState>((size_t)P, depth_temp), geometry_user);
-    if (!gptr) throw Error("geometry allocator returned NULL");
-    GeomState geom = GeomState::carve(gptr, (size_t)P, depth_temp);
-    char* iptr = imageBuffer(required_bytes<ImageState>((size_t)width * height, (size_t)gx * gy), image_user);
-    if (!iptr) throw Error("image allocator returned NULL");
-    ImageState img = ImageState::carve(iptr, (size_t)width * height, (size_t)gx * gy);
-    if (!radii) radii = geom.radii_internal;
-
-    // (Clearing the tile ranges / pair flags on the side stream instead of the main one was tried: each cross-stream
-    // wait costs the main queue more than the ~5 us fill it saves -- step time went up by ~30 us.)
-    ReadbackCtx& rb = readback_ctx();
-    static const bool generic_env = [] {   // R3DGS_DEPTH_SORT=generic forces the rocPRIM path (A/B runs, tests)
-        const char* v = getenv("R3DGS_DEPTH_SORT");
-        return v && std::string(v) == "generic";
-    }();
-    const bool generic_sort = generic_env || P >= (1 << 24);   // the bucket histogram packs the count in 24 bits
-
-    FwdInputs in;
-    in.P = P;
-    in.M = M;
-    in.degrees = D;
-    in.means3D = means3D;
-    in.scales = scales;
-    in.rotations = rotations;
-    in.opacities = opacities;
-    in.shs = shs;
-    in.cov3D_precomp = cov3D_precomp;
-    in.colors_precomp = colors_precomp;
-    in.coeffs_num = coeffsNum;
-    in.per_band_count = perBand;
-    in.cumsum_count = cumSum;
-    ViewParams view;
-    view.view = viewmatrix;
-    view.proj = projmatrix;
-    view.campos = cam_pos;
-    view.bg = background;
-    view.tan_fovx = tan_fovx;
-    view.tan_fovy = tan_fovy;
-    view.W = width;
-    view.H = height;
-    view.scale_modifier = scale_modifier;
-
-    StageTimer t0(kPre, s);
-    launch_preprocess(in, view, geom, radii, s);
-    t0.stop();
-    check_launch("preprocess", s, debug);
-    // The SH -> RGB kernel needs only the geometry kernel's visibility: it starts now on the low-priority side stream,
-    // underneath the (latency-bound) header / depth-sort kernels of the main stream.
-    R3_HIP(hipEventRecord(rb.geom_done, s));
-    R3_HIP(hipStreamWaitEvent(rb.side, rb.geom_done, 0));
-    {
-        StageTimer tc(kColor, rb.side);
-        launch_preprocess_color(in, view, geom, rb.side);
-        tc.stop();
-        R3_HIP(hipEventRecord(rb.colored, rb.side));
+    try {
+        g_last_error.clear();
+        return f();
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -1;
     }
-    // The header the host needs: one workgroup turns the preprocess partials into num_rendered / visible count and
-    // the 16 bytes start their way to the host on the copy stream.  R does not depend on the depth order, so the
-    // structural host round trip -- size the binning blob, then enqueue the binning -- overlaps the whole depth sort.
-    // (Running the reduction on the copy stream as well keeps 12 us off the main chain but delays R by the
-    // cross-queue latency: 991 vs 1010 it/s on the same box, R3DGS_HEADER_SIDE=1 selects it.)
-    static const bool header_on_main = [] {
-        const char* v = getenv("R3DGS_HEADER_SIDE");
-        return !(v && v[0] == '1');
-    }();
-    if (header_on_main) {
-        run_header_reduce(P, geom, s);
-        R3_HIP(hipEventRecord(rb.after_pre, s));
-        R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_pre, 0));
+}
+
+#define R3_FWD_CALL(coeffs, perband, cumsum, Mval)                                                                      \
+    FwdCall c;                                                                                                          \
+    c.P = P;                                                                                                            \
+    c.D = D;                                                                                                            \
+    c.M = (Mval);                                                                                                       \
+    c.coeffsNum = (coeffs);                                                                                             \
+    c.perBand = (perband);                                                                                              \
+    c.cumSum = (cumsum);                                                                                                \
+    c.background = background;                                                                                          \
+    c.width = width;                                                                                                    \
+    c.height = height;                                                                                                  \
+    c.means3D = means3D;                                                                                                \
+    c.shs = shs;                                                                                                        \
+    c.colors_precomp = colors_precomp;                                                                                  \
+    c.opacities = opacities;                                                                                            \
+    c.scales = scales;                                                                                                  \
+    c.scale_modifier = scale_modifier;                                                                                  \
+    c.rotations = rotations;                                                                                            \
+    c.cov3D_precomp = cov3D_precomp;                                                                                    \
+    c.viewmatrix = viewmatrix;                                                                                          \
+    c.projmatrix = projmatrix;                                                                                          \
+    c.cam_pos = cam_pos;                                                                                                \
+    c.tan_fovx = tan_fovx;                                                                                              \
+    c.tan_fovy = tan_fovy;                                                                                              \
+    c.out_color = out_color;                                                                                            \
+    c.out_touched_pixels = out_touched_pixels;                                                                          \
+    c.out_transmittance = out_transmittance;                                                                            \
+    c.radii = radii;                                                                                                    \
+    c.calculate_mean_transmittance = calculate_mean_transmittance;                                                      \
+    c.debug = debug;                                                                                                    \
+    c.stream = static_cast<hipStream_t>(stream)
+
+void check_ragged(const float* colors_precomp, int bandsNum, const int*& coeffsNum, const int*& perBand, const int*& cumSum)
+{
+    if (!colors_precomp) {
+        if (bandsNum != 4) throw Error("ragged SH path expects 4 bands (degrees 0..3)");
+        if (!coeffsNum || !perBand || !cumSum)
+            throw Error("ragged SH path needs coeffsNum / perBandPrimitiveCount / cumSumPrimitiveCount");
     } else {
-        R3_HIP(hipStreamWaitEvent(rb.side2, rb.geom_done, 0));
-        run_header_reduce(P, geom, rb.side2);
+        coeffsNum = perBand = cumSum = nullptr;
     }
-    R3_HIP(hipMemcpyAsync(rb.pinned, geom.header, offsetof(GeomHeader, sort_overflow), hipMemcpyDeviceToHost, rb.side2));
-    R3_HIP(hipEventRecord(rb.copied, rb.side2));
-    StageTimer t1(kDepthSort, s);
-    if (generic_sort) {
-        run_depth_sort_and_scan(P, geom, s);
-    } else {
-        run_depth_histogram(P, geom, header_on_main, s);
-        // the bucket-overflow flags follow on the same copy stream
-        R3_HIP(hipEventRecord(rb.after_hist, s));
-        R3_HIP(hipStreamWaitEvent(rb.side2, rb.after_hist, 0));
-        R3_HIP(hipMemcpyAsync(rb.pinned->sort_overflow, geom.header->sort_overflow, sizeof(uint32_t) * kOverflowSlots,
-                              hipMemcpyDeviceToHost, rb.side2));
-        R3_HIP(hipEventRecord(rb.copied2, rb.side2));
-        run_depth_bucket_sort_and_scan(P, geom, s);
-    }
-    t1.stop();
-    // spin on the event instead of hipEventSynchronize: a blocking wait parks the host thread, and on an otherwise
-    // idle many-core host its wake-up (deep C-state exit) was observed to cost more than the whole forward
-    auto spin = [](hipEvent_t ev) {
-        for (;;) {
-            const hipError_t q = hipEventQuery(ev);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) R3_HIP(q);
-        }
-    };
-    spin(rb.copied);
-    const uint32_t R = rb.pinned->num_rendered;
-    if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
-    const size_t tile_temp = cached_tile_temp(R);
-    char* bptr = binningBuffer(required_bytes<BinState>((size_t)R, tile_temp), binning_user);   // host work, overlapped
-    if (!bptr) throw Error("binning allocator returned NULL");
-    BinState bin = BinState::carve(bptr, (size_t)R, tile_temp);
-    if (!generic_sort) {
-        spin(rb.copied2);
-        bool overflow = false;
-        for (int k = 0; k < kOverflowSlots; k++) overflow |= rb.pinned->sort_overflow[k] != 0;
-        if (overflow) {
-            // a depth bucket did not fit one workgroup's LDS (many splats at one depth): redo with the generic sort
-            StageTimer t1b(kDepthSort, s);
-            run_depth_sort_and_scan(P, geom, s);
-            t1b.stop();
-        }
-    }
-    check_launch("depth sort + scan", s, debug);
-
-    StageTimer t2(kBinning, s);
-    run_tile_binning(P, (int)R, gx, gy, geom, bin, img, s);
-    t2.stop();
-    check_launch("tile binning", s, debug);
-    R3_HIP(hipStreamWaitEvent(s, rb.colored, 0));  // the blend needs the colours
-    StageTimer t3(kBlendFwd, s);
-    launch_blend_forward(view, geom, bin, img, out_color, calculate_mean_transmittance ? out_touched_pixels : nullptr,
-                         calculate_mean_transmittance ? out_transmittance : nullptr, s);
-    t3.stop();
-    check_launch("blend forward", s, debug);
-    if (debug) R3_HIP(hipStreamSynchronize(rb.side));
-    return (int)R;
 }
 
 }  // namespace
@@ -308,11 +802,11 @@ int r3::guarded_call(const std::function<int()>& f) { return guarded(f); }
 
 extern "C" {
 
-const char* r3dgs_version(void) { return "r3dgs-hip gfx950 0.1"; }
+const char* r3dgs_version(void) { return "r3dgs-hip gfx950 0.2"; }
 const char* r3dgs_last_error(void) { return g_last_error.c_str(); }
 
-// The temp-storage part of the blob sizes comes from rocPRIM queries, which need a visible GPU;
-// without one these return 0 and set r3dgs_last_error().
+// The temp-storage part of the geometry blob comes from a rocPRIM query, which needs a visible GPU;
+// without one it returns 0 and sets r3dgs_last_error().
 size_t r3dgs_geometry_bytes(int P)
 {
     try {
@@ -323,11 +817,13 @@ size_t r3dgs_geometry_bytes(int P)
         return 0;
     }
 }
-size_t r3dgs_binning_bytes(int R)
+size_t r3dgs_binning_bytes(int P, int width, int height, int reserve)
 {
     try {
         g_last_error.clear();
-        return r3::required_bytes<r3::BinState>((size_t)R, cached_tile_temp((size_t)(R > 0 ? R : 1)));
+        const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
+        const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
+        return r3::required_bytes<r3::BinState>((size_t)(reserve > 0 ? reserve : 1), l.wide);
     } catch (const std::exception& e) {
         g_last_error = e.what();
         return 0;
@@ -337,6 +833,25 @@ size_t r3dgs_image_bytes(int width, int height)
 {
     const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
     return r3::required_bytes<r3::ImageState>((size_t)width * height, (size_t)gx * gy);
+}
+int r3dgs_binning_capacity(int P, int width, int height, size_t bytes)
+{
+    return guarded([&]() {
+        const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
+        const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
+        if (r3::required_bytes<r3::BinState>((size_t)1, l.wide) > bytes) return 0;
+        // largest R whose layout fits: every array size is monotone in R, so any R with the same total has the same
+        // offsets -- the capacity recovered from a blob's size reproduces the carve the forward used
+        long long lo = 1, hi = 0x7fffffffLL;
+        while (lo < hi) {
+            const long long mid = (lo + hi + 1) / 2;
+            if (r3::required_bytes<r3::BinState>((size_t)mid, l.wide) <= bytes)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        return (int)lo;
+    });
 }
 
 int r3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -363,11 +878,8 @@ int r3dgs_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
 {
     (void)prefiltered;
     return guarded([&]() {
-        return forward_impl(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D, M,
-                            nullptr, nullptr, nullptr, background, width, height, means3D, shs, colors_precomp,
-                            opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                            tan_fovx, tan_fovy, out_color, out_touched_pixels, out_transmittance, radii,
-                            calculate_mean_transmittance, debug, stream);
+        R3_FWD_CALL(nullptr, nullptr, nullptr, M);
+        return forward_exact(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, c);
     });
 }
 
@@ -384,19 +896,84 @@ int r3dgs_inference_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, 
 {
     (void)prefiltered;
     return guarded([&]() {
-        if (!colors_precomp) {
-            if (bandsNum != 4) throw r3::Error("ragged SH path expects 4 bands (degrees 0..3)");
-            if (!coeffsNum || !perBandPrimitiveCount || !cumSumPrimitiveCount)
-                throw r3::Error("ragged SH path needs coeffsNum / perBandPrimitiveCount / cumSumPrimitiveCount");
-        } else {
-            coeffsNum = perBandPrimitiveCount = cumSumPrimitiveCount = nullptr;
-        }
-        return forward_impl(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D, 16,
-                            coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount, background, width, height, means3D,
-                            shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
-                            projmatrix, cam_pos, tan_fovx, tan_fovy, out_color, out_touched_pixels, out_transmittance,
-                            radii, calculate_mean_transmittance, debug, stream);
+        check_ragged(colors_precomp, bandsNum, coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount);
+        R3_FWD_CALL(coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount, 16);
+        return forward_exact(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, c);
     });
+}
+
+int r3dgs_reserve_hint(int P, int width, int height)
+{
+    return guarded([&]() { return (int)reserve_hint(current_device(), P, width, height); });
+}
+
+long long r3dgs_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, int P,
+                                 const int* D, int M, const float* background, int width, int height,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                 int prefiltered, float* out_color, int* out_touched_pixels, float* out_transmittance,
+                                 int* radii, int calculate_mean_transmittance, int debug, void* stream)
+{
+    (void)prefiltered;
+    return guarded_ll([&]() {
+        R3_FWD_CALL(nullptr, nullptr, nullptr, M);
+        return forward_reserved(geom_buffer, binning_buffer, image_buffer, reserve, c);
+    });
+}
+
+long long r3dgs_inference_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve,
+                                           int P, const int* D, int bandsNum, const int* coeffsNum,
+                                           const int* perBandPrimitiveCount, const int* cumSumPrimitiveCount,
+                                           const float* background, int width, int height, const float* means3D,
+                                           const float* shs, const float* colors_precomp, const float* opacities,
+                                           const float* scales, float scale_modifier, const float* rotations,
+                                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                           float* out_color, int* out_touched_pixels, float* out_transmittance,
+                                           int* radii, int calculate_mean_transmittance, int debug, void* stream)
+{
+    (void)prefiltered;
+    return guarded_ll([&]() {
+        check_ragged(colors_precomp, bandsNum, coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount);
+        R3_FWD_CALL(coeffsNum, perBandPrimitiveCount, cumSumPrimitiveCount, 16);
+        return forward_reserved(geom_buffer, binning_buffer, image_buffer, reserve, c);
+    });
+}
+
+int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible, int* reserve, int* flags)
+{
+    return guarded([&]() {
+        if (ticket <= 0) throw r3::Error("not a pass ticket");
+        const int dev = current_device();
+        if (g_next_ticket.load() - (uint64_t)ticket >= kInfoRing) throw r3::Error("pass ticket expired (ring reused)");
+        const volatile r3::PassInfo* info = info_ring(dev).host + (uint64_t)ticket % kInfoRing;
+        if (wait)
+            info = wait_info(dev, (uint64_t)ticket);
+        else if (info->seq != (uint32_t)ticket)
+            return 0;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const uint32_t R = info->num_rendered, cap = info->reserve;
+        if (num_rendered) *num_rendered = (int)(R > 0x7fffffffu ? 0x7fffffffu : R);
+        if (visible) *visible = (int)info->visible;
+        if (reserve) *reserve = cap == 0xFFFFFFFFu ? -1 : (int)cap;
+        if (flags) *flags = (cap != 0xFFFFFFFFu && R > cap ? R3DGS_PASS_TRUNCATED : 0) |
+                            (info->sort_overflow ? R3DGS_PASS_DEPTH_BUCKET_OVERFLOW : 0);
+        return 1;
+    });
+}
+
+long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserve)
+{
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    try {
+        harvest_locked();
+    } catch (...) {
+    }
+    if (last_num_rendered) *last_num_rendered = (int)g_adv.last_overflow_rendered;
+    if (last_reserve) *last_reserve = (int)g_adv.last_overflow_reserve;
+    return (long long)g_adv.overflow_events;
 }
 
 int r3dgs_backward(int P, const int* D, int M, int R, const float* background, int width, int height,
@@ -411,20 +988,61 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         using namespace r3;
         hipStream_t s = static_cast<hipStream_t>(stream);
         if (P <= 0) return 0;
-        if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) throw Error("state buffers must not be NULL");
+        if (!geom_buffer || !image_buffer) throw Error("state buffers must not be NULL");
         if (!means3D || !viewmatrix || !projmatrix || !campos || !background || !dL_dpix)
             throw Error("a required pointer is NULL");
         if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
             throw Error("a gradient output pointer is NULL");
         if (shs && (!dL_dsh || !D || M < 1 || M > 16)) throw Error("SH gradients need dL_dsh, degrees and 1 <= M <= 16");
-        const int gx = (width + kTile - 1) / kTile, gy = (height + kTile - 1) / kTile;
+        static const int ppl0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
+        BwdPlan plan;
+        plan.P = P;
+        plan.M = M;
+        plan.W = width;
+        plan.H = height;
+        plan.gx = (width + kTile - 1) / kTile;
+        plan.gy = (height + kTile - 1) / kTile;
+        plan.layout = pair_layout(P, (size_t)plan.gx * plan.gy);
+        plan.bwd_ppl = ppl0 == 3 ? 4 : ppl0;
+        // R: the pair capacity the forward carved the binning blob with (num_rendered of an exact-size forward, the
+        // reservation of a reserved one); the pair count itself is read from the device header
+        plan.reserve = R > 0 ? (uint32_t)R : 1u;
+        plan.has_pairs = binning_buffer != nullptr ? 1 : 0;
+        const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
-        ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)gx * gy);
-        BinState bin = BinState::carve(binning_buffer, (size_t)R, cached_tile_temp((size_t)R));
-        if (R <= 0) bin.pair_grad = bin.wave_part = nullptr;
+        ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)plan.gx * plan.gy);
+        BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide);
         if (!radii) radii = geom.radii_internal;
 
-        FwdInputs in;
+        BwdPassArgs a;
+        memset(&a, 0, sizeof(a));
+        BlendBwdArgs& bb = a.blend;
+        bb.ranges = img.ranges;
+        bb.point_list = bin.point_list;
+        bb.rec = geom.rec;
+        bb.final_T = img.final_T;
+        bb.n_contrib = img.n_contrib;
+        bb.dL_dpix = dL_dpix;
+        bb.W = width;
+        bb.H = height;
+        bb.gx = plan.gx;
+        bb.nblocks = (uint32_t)(plan.gx * plan.gy * (4 / plan.bwd_ppl));
+        bb.bg = background;
+        bb.pair_grad = bin.pair_grad;
+        bb.pair_flag = bin.pair_flag;
+        PairReduceArgs& pr = a.reduce;
+        pr.hdr = geom.header;
+        pr.pair_grad = bin.pair_grad;
+        pr.pair_flag = bin.pair_flag;
+        pr.pair_rank = bin.pair_rank;
+        pr.rank_mask = plan.layout.wide ? 0xFFFFFFFFu : (1u << plan.layout.rank_bits) - 1u;
+        pr.order = geom.order;
+        pr.rec = geom.rec;
+        pr.tiles = geom.tiles;
+        pr.acc = geom.acc;
+        pr.wave_part = bin.wave_part;
+        PreBwdArgs& pb = a.pre;
+        FwdInputs& in = pb.in;
         in.P = P;
         in.M = M;
         in.degrees = D;
@@ -435,8 +1053,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         in.shs = colors_precomp ? nullptr : shs;
         in.cov3D_precomp = cov3D_precomp;
         in.colors_precomp = colors_precomp;
-        in.coeffs_num = in.per_band_count = in.cumsum_count = nullptr;
-        ViewParams view;
+        ViewParams& view = pb.view;
         view.view = viewmatrix;
         view.proj = projmatrix;
         view.campos = campos;
@@ -446,30 +1063,41 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         view.W = width;
         view.H = height;
         view.scale_modifier = scale_modifier;
+        pb.radii = radii;
+        pb.rec = geom.rec;
+        pb.tiles = geom.tiles;
+        pb.acc = geom.acc;
+        pb.wave_part = plan.has_pairs ? bin.wave_part : nullptr;
+        pb.header = geom.header;
+        pb.lambda_sh = lambda_sh_sparsity;
+        pb.out.dL_dmean2D = dL_dmean2D;
+        pb.out.dL_dopacity = dL_dopacity;
+        pb.out.dL_dcolor = dL_dcolor;
+        pb.out.dL_dmean3D = dL_dmean3D;
+        pb.out.dL_dcov3D = dL_dcov3D;
+        pb.out.dL_dsh = dL_dsh;
+        pb.out.dL_dscale = dL_dscale;
+        pb.out.dL_drot = dL_drot;
+        pb.out.dL_dconic = dL_dconic;
 
-        StageTimer t4(kBlendBwd, s);
-        if (R > 0) {
-            // bin.pair_flag is all zero here: the forward's tile_ranges kernel clears it and pair_reduce puts every
-            // flag it consumed back to zero, so neither pass pays for a fill of its own
-            launch_blend_backward(view, geom, bin, img, dL_dpix, s);
-            launch_pair_reduce(P, R, (size_t)gx * gy, geom, bin, s);
+        const bool direct = !graphs_enabled() || debug || (g_prof.mask.load() & kBwdStages);
+        if (direct) {
+            BwdPassArgs* d_args;
+            {
+                std::lock_guard<std::mutex> lk(g_ctx_mu);
+                d_args = static_cast<BwdPassArgs*>(direct_block(dev, 1, s, sizeof(BwdPassArgs)));
+            }
+            StageRun hooks{debug != 0};
+            launch_write_args(d_args, a, s);
+            issue_backward(plan, d_args, s, hooks);
+        } else {
+            const uint32_t flags = (uint32_t)plan.bwd_ppl | ((uint32_t)plan.has_pairs << 3) | ((uint32_t)plan.layout.wide << 4);
+            const CtxKey key{dev, 1, s, P, M, width, height, plan.reserve, flags};
+            launch_graph(key, plan, a, s, [](const BwdPlan& p, const BwdPassArgs* d, hipStream_t cs) {
+                NoHooks nh;
+                issue_backward(p, d, cs, nh);
+            });
         }
-        t4.stop();
-        check_launch("blend backward", s, debug);
-        BwdOutputs out;
-        out.dL_dmean2D = dL_dmean2D;
-        out.dL_dopacity = dL_dopacity;
-        out.dL_dcolor = dL_dcolor;
-        out.dL_dmean3D = dL_dmean3D;
-        out.dL_dcov3D = dL_dcov3D;
-        out.dL_dsh = dL_dsh;
-        out.dL_dscale = dL_dscale;
-        out.dL_drot = dL_drot;
-        out.dL_dconic = dL_dconic;
-        StageTimer t5(kPreBwd, s);
-        launch_preprocess_backward(in, view, radii, geom, bin, out, lambda_sh_sparsity, s);
-        t5.stop();
-        check_launch("preprocess backward", s, debug);
         return 0;
     });
 }
@@ -496,10 +1124,9 @@ int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg,
 
 int r3dgs_profile_enable(int on)
 {
-    // on == 0: off; on == 1: every stage; otherwise bit (s + 1) of `on` selects stage s alone -- each event record is
-    // a packet on the stream, and a dozen of them per pass cost a few percent of a 1 ms iteration
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.mask = on == 0 ? 0u : (on == 1 ? ~0u : ((unsigned)on >> 1));
+    // on == 0: off; on == 1: every stage; otherwise bit (s + 1) of `on` selects stage s alone.  A pass with a timed
+    // stage is issued with direct launches (events sit between its kernels); the other pass keeps its graph.
+    g_prof.mask.store(on == 0 ? 0u : (on == 1 ? ((1u << kNumStages) - 1u) : (((unsigned)on >> 1) & ((1u << kNumStages) - 1u))));
     return 0;
 }
 
@@ -508,7 +1135,7 @@ int r3dgs_profile_stage_count(void) { return kNumStages; }
 const char* r3dgs_profile_stage_name(int stage)
 {
     static const char* names[kNumStages] = {"preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd",
-                                            "blend_bwd",      "preprocess_bwd",  "sh_color_overlapped"};
+                                            "blend_bwd",      "preprocess_bwd",  "sh_color"};
     return (stage >= 0 && stage < kNumStages) ? names[stage] : "";
 }
 
@@ -534,7 +1161,7 @@ int r3dgs_profile_read(double* total_ms, int* launches)
     });
 }
 
-int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+int r3dgs_export_binning(int P, int R, int count, int width, int height, char* geom_buffer, char* binning_buffer,
                          char* image_buffer, uint64_t* keys, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib,
                          float* final_T, uint32_t* tiles_touched, void* stream)
 {
@@ -546,11 +1173,13 @@ int r3dgs_export_binning(int P, int R, int width, int height, char* geom_buffer,
         const size_t N = (size_t)width * height, Tn = (size_t)gx * gy;
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, N, Tn);
-        if (R > 0) {
-            BinState bin = BinState::carve(binning_buffer, (size_t)R, cached_tile_temp((size_t)R));
-            if (keys) launch_export_keys(P, R, Tn, bin, geom, keys, s);
+        if (count > R) throw Error("count exceeds the blob's pair capacity");
+        if (count > 0 && binning_buffer) {
+            const PairLayout l = pair_layout(P, Tn);
+            BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide);
+            if (keys) launch_export_keys(P, count, Tn, bin, geom, keys, s);
             if (point_list)
-                R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+                R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, s));
         }
         if (ranges) R3_HIP(hipMemcpyAsync(ranges, img.ranges, sizeof(uint2) * Tn, hipMemcpyDeviceToDevice, s));
         if (n_contrib) R3_HIP(hipMemcpyAsync(n_contrib, img.n_contrib, sizeof(uint32_t) * N, hipMemcpyDeviceToDevice, s));

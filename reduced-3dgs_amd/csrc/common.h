@@ -1,14 +1,24 @@
-// common.h -- buffer layouts, launch helpers and error plumbing shared by the HIP translation units.
+// common.h -- buffer layouts, pass argument blocks, launch helpers and error plumbing shared by the HIP
+// translation units.
 //
 // The three caller-owned byte buffers play the role of the reference's GeometryState / BinningState /
 // ImageState blobs (cuda_rasterizer/rasterizer_impl.h:21-73, rasterizer_impl.cu:163-202): produced by
-// forward through allocator callbacks, kept alive by the caller, handed back verbatim to backward.
+// forward, kept alive by the caller, handed back verbatim to backward.
 // Their internal layout is private to this library and is MI355X-first, not the reference's:
 //   * one 48-byte gather record per Gaussian (GRec) instead of five separate arrays,
-//   * depth-sorted Gaussian order + 32-bit tile keys instead of 64-bit (tile|depth) keys,
+//   * depth-sorted Gaussian order + packed (tile | depth rank) words instead of 64-bit (tile|depth) keys,
 //   * a per-(tile, Gaussian)-pair gradient slab for the backward (no float atomics anywhere).
 // The parts the backward needs sit at the FRONT of each blob so that their offsets do not depend on
 // library temp-storage sizes.
+//
+// How a pass is issued (capi.hip): every kernel of a pass reads its pointers and scalars from ONE device-resident
+// argument block (FwdPassArgs / BwdPassArgs) instead of from its kernel arguments.  The block is (re)written by a
+// one-workgroup kernel whose by-value argument IS the block, so a whole pass is "write the block, run a fixed chain
+// of kernels whose launch parameters never change": that chain is captured once per shape into a hipGraph and
+// replayed with one hipGraphLaunch per pass (the measured host cost of 20 direct launches is 54 us idle and
+// milliseconds on a loaded host; one graph launch is ~8 us either way).  Nothing the host does depends on
+// num_rendered any more: grids are sized by the caller's pair RESERVATION, the kernels read the pair count from the
+// device header.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -29,7 +39,7 @@ constexpr int kAccStride = 12;  // floats per Gaussian in the reduced 2D-stage g
 
 // Per-view counters.  Every preprocess workgroup stores one PrePartial (no atomics, nothing to pre-clear: the first
 // GPU profile showed 7.8k same-address atomics costing ~90 us, a sharded version still needed a fill of the header
-// in front of every pass); the depth-sort kernels reduce them, and one workgroup writes the header the host reads.
+// in front of every pass); one workgroup reduces them into the header.
 constexpr int kPreBlockSize = 256;
 struct PrePartial {
     uint32_t visible;        // #Gaussians with radii > 0 in the workgroup (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
@@ -37,25 +47,46 @@ struct PrePartial {
     uint32_t depth_max;      // max depth bits over the visible Gaussians (0 if none)
     uint32_t depth_inv_min;  // max of ~(depth bits), i.e. ~min (0 if none)
 };
-constexpr int kOverflowSlots = 32;
 struct GeomHeader {
     uint32_t visible, num_rendered, depth_max, depth_inv_min;
-    uint32_t sort_overflow[kOverflowSlots];  // one per column-scan workgroup: a depth bucket exceeds kBucketCap
-    uint32_t pad[28];
+    uint32_t num_pairs;       // min(num_rendered, reserve): the pairs every later kernel of the pass works on
+    uint32_t reserve;         // pair capacity of the binning blob of this pass
+    uint32_t sort_overflow;   // a depth bucket exceeded the LDS sort capacity (handled on the device; host hint only)
+    uint32_t pad[57];
 };
 static_assert(sizeof(GeomHeader) == 256, "header = 256 B");
 inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBlockSize; }
 
-// Bucketed depth sort (binning.hip): kDepthBuckets equal-width depth intervals between the view's min and max
-// depth, each sorted by one workgroup in LDS.
-constexpr int kDepthBuckets = 1024;
-constexpr int kBucketCap = 4096;   // (key, id) pairs one workgroup sorts in LDS (32 KB)
+// What the host may want to know about a pass, written by the pass's kernels into HOST-mapped memory (one ring slot
+// per pass ticket): the host never waits for it on the asynchronous path, and polls plain memory (no HIP calls) on
+// the exact path.  `seq` is stored last, after a system-scope fence.
+struct PassInfo {
+    uint32_t seq;            // low 32 bits of the ticket once num_rendered / visible are valid
+    uint32_t num_rendered;   // true pair count of the view (may exceed `reserve`: then the farthest pairs were dropped)
+    uint32_t visible;
+    uint32_t reserve;
+    uint32_t sort_overflow;  // hint: a depth bucket overflowed (slow in-kernel path was taken)
+    uint32_t pad[3];
+};
+static_assert(sizeof(PassInfo) == 32, "PassInfo = 32 B");
+
+// Bucketed depth sort (binning.hip): `nb` monotone buckets over [min depth bits, max depth bits], each sorted by one
+// workgroup in LDS.  nb scales with P (<= kMaxDepthBuckets).
+constexpr int kMinDepthBuckets = 1024;
+constexpr int kMaxDepthBuckets = 8192;
+constexpr int kBucketCap = 4096;     // (key, id) pairs one workgroup sorts in LDS (32 KB)
 constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
+inline int depth_bucket_count(size_t P)
+{
+    int nb = kMinDepthBuckets;
+    while (nb < kMaxDepthBuckets && P / (size_t)nb > 512) nb <<= 1;
+    return nb;
+}
 struct DepthSortScratch {
-    uint32_t depth_max, depth_inv_min, pad_[2];   // depth range of the visible Gaussians (histogram workgroup 0)
-    unsigned long long total[kDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [kDepthBuckets] = culled
-    uint32_t start[kDepthBuckets + 2];       // exclusive scan of the bucket sizes
-    uint32_t tile_base[kDepthBuckets + 2];   // exclusive scan of the buckets' tiles_touched sums
+    uint32_t depth_max, depth_inv_min, pad_[2];      // depth range of the visible Gaussians
+    unsigned long long total[kMaxDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [nb] = culled
+    uint32_t start[kMaxDepthBuckets + 2];            // exclusive scan of the bucket sizes
+    uint32_t tile_base[kMaxDepthBuckets + 2];        // exclusive scan of the buckets' tiles_touched sums
 };
 inline size_t depth_hist_rows(size_t P) { return (P + kHistPerBlock - 1) / kHistPerBlock; }
 
@@ -79,8 +110,8 @@ struct GeomState {
     GeomHeader* header;
     PrePartial* partials;     // [ceil(P / 256)]
     DepthSortScratch* dsort;
-    unsigned long long* hist_rows;  // [rows][kDepthBuckets + 1]  per-workgroup (tile sum << 24 | count) histograms
-    uint32_t* hist_base;            // [rows][kDepthBuckets + 1]  first slot of each workgroup inside each bucket
+    unsigned long long* hist_rows;  // [rows][nb + 1]  per-workgroup (tile sum << 24 | count) histograms
+    uint32_t* hist_base;            // [rows][nb + 1]  first slot of each workgroup inside each bucket
     GRec* rec;            // [P]
     float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward)
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
@@ -91,17 +122,20 @@ struct GeomState {
     uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
     uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
     int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
-    char* temp;           // sort / scan temp storage
+    uint32_t* ovf_key;    // [P]  ping-pong partner of key_sorted for a depth bucket that overflows the LDS sort
+    uint32_t* ovf_id;     // [P]  ... and of bucket_id
+    char* temp;           // rocPRIM temp storage of the generic depth sort
     size_t temp_bytes;
     static GeomState carve(char* base, size_t P, size_t temp_bytes)
     {
         Carver c(base);
         GeomState g;
+        const size_t nb = (size_t)depth_bucket_count(P);
         g.header = c.take<GeomHeader>(1);
         g.partials = c.take<PrePartial>(pre_partials(P));
         g.dsort = c.take<DepthSortScratch>(1);
-        g.hist_rows = c.take<unsigned long long>(depth_hist_rows(P) * (kDepthBuckets + 1));
-        g.hist_base = c.take<uint32_t>(depth_hist_rows(P) * (kDepthBuckets + 1));
+        g.hist_rows = c.take<unsigned long long>(depth_hist_rows(P) * (nb + 1));
+        g.hist_base = c.take<uint32_t>(depth_hist_rows(P) * (nb + 1));
         g.rec = c.take<GRec>(P);
         g.acc = c.take<float>(P * kAccStride);
         g.rect = c.take<ushort4>(P);
@@ -112,6 +146,8 @@ struct GeomState {
         g.order = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.radii_internal = c.take<int>(P);
+        g.ovf_key = c.take<uint32_t>(P);
+        g.ovf_id = c.take<uint32_t>(P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         g.end = c.p;
@@ -120,26 +156,53 @@ struct GeomState {
     char* end;
 };
 
-// Tile sort of the packed pair words (binning.hip): LSD radix, 7-bit digits, 1024 keys per workgroup.
-constexpr int kRadixBits = 7;
-constexpr int kRadixBins = 1 << kRadixBits;
+// rasterizer_impl.cu:43-58 getHigherMsb
+inline uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb)
+            msb += step;
+        else
+            msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+// Tile sort of the packed pair words (binning.hip): a pair travels as ONE word, tile << rank_bits | rank of its
+// Gaussian in depth order, through a key-only LSD radix sort on the tile bits (the Gaussian id is order[rank]).
+// 32-bit words while tile bits + rank bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | rank)
+// above -- every real scene.  Two or three stable passes of <= 8-bit digits, 1024 keys per workgroup.
+// Forward and backward derive the same layout from (P, #tiles) alone.
 constexpr int kRadixBlock = 1024;
+constexpr int kMaxRadixBins = 256;
+constexpr int kMaxRadixPasses = 3;
+struct PairLayout {
+    int tile_bits;   // bits holding the tile id
+    int rank_bits;   // shift of the tile id inside the word (32 for wide words)
+    int wide;        // 1: 64-bit words
+    int passes;      // radix passes over the tile bits
+    int digit_bits;  // bits per pass
+};
+PairLayout pair_layout(int P, size_t n_tiles);   // binning.hip (honours R3DGS_TILE_SORT=wide for A/B runs and tests)
 
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
     float* wave_part;      // [(R/64+1) * 2 * kPairGrad] leading / trailing partial run sums of each 64-pair group
     unsigned char* pair_flag;  // [R] 1 = the backward blend wrote this pair's row (only this is zeroed per pass)
-    uint32_t* tile_sorted; // [R] sorted keys: tile id (pair sort) or tile << rank_bits | depth rank (packed sort)
-    uint32_t* tile_in;     // [R] the same keys in emission (Gaussian-major) order
-    uint32_t* gauss_in;    // [R] Gaussian id per emitted pair (pair sort) / ping-pong buffer of the packed sort
-    uint32_t* radix_rows;  // [kRadixBins][R/kRadixBlock + 1] per-workgroup digit counts, digit-major
+    uint32_t* pair_rank;   // [R] depth rank of the emitted pair's Gaussian, emission order (run key of the backward's
+                           //     segmented sum); narrow words: aliases words_a (the low rank_bits of the word)
+    char* words_a;         // [R] packed words in emission order (narrow) / ping-pong buffer A (wide)
+    char* words_b;         // [R] ping-pong buffer B
+    char* words_c;         // [R] narrow only: third buffer, so that words_a survives for the backward
+    uint32_t* radix_rows;  // [bins][R/kRadixBlock + 1] per-workgroup digit counts, digit-major
     uint32_t* radix_base;  // same shape: first slot of each workgroup inside each digit
-    uint32_t* radix_total; // [2][kRadixBins] digit totals of the two passes
-    char* temp;
-    size_t temp_bytes;
+    uint32_t* radix_total; // [kMaxRadixPasses][kMaxRadixBins] digit totals of the passes
     char* end;
-    static BinState carve(char* base, size_t R, size_t temp_bytes)
+    static BinState carve(char* base, size_t R, int wide)
     {
         Carver c(base);
         BinState b;
@@ -147,14 +210,20 @@ struct BinState {
         b.pair_grad = c.take<float>(R * kPairGrad);
         b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
         b.pair_flag = c.take<unsigned char>(R);
-        b.tile_sorted = c.take<uint32_t>(R);
-        b.tile_in = c.take<uint32_t>(R);
-        b.gauss_in = c.take<uint32_t>(R);
-        b.radix_rows = c.take<uint32_t>((size_t)kRadixBins * (R / kRadixBlock + 1));
-        b.radix_base = c.take<uint32_t>((size_t)kRadixBins * (R / kRadixBlock + 1));
-        b.radix_total = c.take<uint32_t>(2 * kRadixBins);
-        b.temp = c.take<char>(temp_bytes);
-        b.temp_bytes = temp_bytes;
+        if (wide) {
+            b.pair_rank = c.take<uint32_t>(R);
+            b.words_a = reinterpret_cast<char*>(c.take<unsigned long long>(R));
+            b.words_b = reinterpret_cast<char*>(c.take<unsigned long long>(R));
+            b.words_c = nullptr;
+        } else {
+            b.words_a = reinterpret_cast<char*>(c.take<uint32_t>(R));
+            b.words_b = reinterpret_cast<char*>(c.take<uint32_t>(R));
+            b.words_c = reinterpret_cast<char*>(c.take<uint32_t>(R));
+            b.pair_rank = reinterpret_cast<uint32_t*>(b.words_a);
+        }
+        b.radix_rows = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
+        b.radix_base = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
+        b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.end = c.p;
         return b;
     }
@@ -184,9 +253,8 @@ size_t required_bytes(A... a)
     return (size_t)reinterpret_cast<uintptr_t>(s.end) + kAlign;
 }
 
-// temp-storage queries (binning.hip)
+// temp-storage query of the generic (rocPRIM) depth sort (binning.hip); needs a visible GPU
 size_t depth_sort_temp_bytes(size_t P);
-size_t tile_sort_temp_bytes(size_t R);
 
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -215,7 +283,7 @@ inline void check_launch(const char* what, hipStream_t s, bool debug)
 
 // Per-view parameters as they arrive at the boundary: the matrices, camera position and background
 // are DEVICE tensors (gaussian_renderer/__init__.py:37-50 passes CUDA tensors), so kernels read them
-// through wave-uniform (scalar) loads; only the plain scalars travel in the kernel argument.
+// through wave-uniform (scalar) loads.
 struct ViewParams {
     const float* view;    // [16] world->view, transposed/row-vector layout (scene/cameras.py:54)
     const float* proj;    // [16] full projection, same layout
@@ -249,7 +317,6 @@ __device__ __forceinline__ Camera load_camera(const ViewParams& v)
     return c;
 }
 
-// ---- per-stage host launchers (one per translation unit) ------------------------------------
 struct FwdInputs {
     int P, M;
     const int* degrees;
@@ -266,43 +333,6 @@ struct FwdInputs {
     const int* cumsum_count;
 };
 
-void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s);
-void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomState& g, hipStream_t s);
-void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
-
-// depth sort + scan; returns nothing (R is read back by the caller from g.offsets[P-1])
-void run_header_reduce(int P, GeomState& g, hipStream_t s);                // generic path: partials -> header
-void run_depth_sort_and_scan(int P, GeomState& g, hipStream_t s);          // generic (rocPRIM) path
-void run_depth_histogram(int P, GeomState& g, bool header_ready, hipStream_t s);  // bucketed path, step 1 (sets sort_overflow)
-void run_depth_bucket_sort_and_scan(int P, GeomState& g, hipStream_t s);   // bucketed path, steps 2-4
-// rasterizer_impl.cu:43-58 getHigherMsb
-inline uint32_t higher_msb(uint32_t n)
-{
-    uint32_t msb = sizeof(n) * 4, step = msb;
-    while (step > 1) {
-        step /= 2;
-        if (n >> msb)
-            msb += step;
-        else
-            msb -= step;
-    }
-    if (n >> msb) msb++;
-    return msb;
-}
-// Packed tile sort: when (tile bits + depth-rank bits) fit 32 bits the pairs travel as ONE word
-// (tile << rank_bits | rank in depth order) through a key-only radix sort on the tile bits -- half the sort traffic;
-// the Gaussian id is order[rank].  Returns rank_bits, or 0 for the (key, value) pair sort.  Forward and backward
-// take the same decision from (P, #tiles) alone.  R3DGS_TILE_SORT=pairs forces the pair sort.
-int tile_rank_bits(int P, size_t n_tiles);
-void run_tile_binning(int P, int R, int gx, int gy, GeomState& g, BinState& b, ImageState& img, hipStream_t s);
-void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
-                        hipStream_t s);
-
-void launch_blend_forward(const ViewParams& view, const GeomState& g, const BinState& b,
-                          ImageState& img, float* out_color, int* touched, float* transmittance, hipStream_t s);
-void launch_blend_backward(const ViewParams& view, const GeomState& g, BinState& b,
-                           const ImageState& img, const float* dL_dpix, hipStream_t s);
-
 struct BwdOutputs {
     float* dL_dmean2D;   // [P,3]
     float* dL_dopacity;  // [P,1]
@@ -314,12 +344,191 @@ struct BwdOutputs {
     float* dL_drot;      // [P,4]
     float* dL_dconic;    // [P,4] optional (nullptr: not exported)
 };
+
+// ---- per-kernel argument blocks (members of the pass blocks below) -----------------------------------------------
+struct PreArgs {          // preprocess.hip
+    FwdInputs in;
+    ViewParams view;
+    GRec* rec;
+    ushort4* rect;
+    uint32_t* depth_key;
+    uint32_t* tiles;
+    PrePartial* partials;
+    int* radii;
+    int color_blocks;     // workgroup-sized chunks of the colour kernel's persistent loop
+};
+struct HeaderArgs {       // binning.hip header_reduce_kernel
+    const PrePartial* parts;
+    int n_parts;
+    GeomHeader* hdr;
+    PassInfo* info;       // host-mapped slot of this pass
+    uint32_t ticket;
+    uint32_t reserve;
+};
+struct DepthArgs {        // binning.hip bucketed depth sort
+    int P, nb, rows;
+    const uint32_t* key;
+    const uint32_t* tiles;
+    GeomHeader* hdr;
+    PassInfo* info;
+    DepthSortScratch* ds;
+    unsigned long long* hist_rows;
+    uint32_t* hist_base;
+    uint32_t* key_sorted;
+    uint32_t* bucket_id;
+    uint32_t* ovf_key;
+    uint32_t* ovf_id;
+    uint32_t* order;
+    uint32_t* offsets;
+};
+struct EmitArgs {         // binning.hip emit_pairs_kernel
+    int P, gx;
+    const GeomHeader* hdr;
+    const uint32_t* order;
+    const uint32_t* offsets;
+    const ushort4* rect;
+    GRec* rec;
+    int rank_bits, digit_bits;
+    char* words_out;
+    uint32_t* pair_rank;   // wide words only (else nullptr)
+    uint2* ranges;
+    uint32_t n_tiles;
+    uint32_t* radix_rows;
+    uint32_t row_stride;   // workgroups of the emission / radix grids (reserve / kRadixBlock, rounded up)
+};
+struct RadixArgs {        // binning.hip one LSD pass (hist -> digit scan -> scatter)
+    const GeomHeader* hdr;
+    const char* in;
+    char* out;
+    int shift, digit_bits;
+    uint32_t* rows;
+    uint32_t* base;
+    uint32_t* total;
+    uint32_t row_stride;
+};
+struct RangesArgs {       // binning.hip tile_ranges_kernel
+    const GeomHeader* hdr;
+    const char* sorted;
+    int rank_bits;
+    const uint32_t* order;
+    uint32_t* point_list;
+    uint2* ranges;
+    unsigned char* pair_flag;
+};
+struct BlendFwdArgs {     // blend.hip
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const GRec* rec;
+    int W, H, gx;
+    uint32_t nblocks;
+    const float* bg;
+    float* out_color;
+    float* final_T;
+    uint32_t* n_contrib;
+    int* touched;
+    float* transmittance;
+};
+struct BlendBwdArgs {     // blend.hip
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const GRec* rec;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    int W, H, gx;
+    uint32_t nblocks;
+    const float* bg;
+    float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
+    unsigned char* pair_flag;  // [R] set for rows written in this pass
+};
+struct PairReduceArgs {   // preprocess_bwd.hip
+    const GeomHeader* hdr;
+    const float* pair_grad;
+    unsigned char* pair_flag;
+    const uint32_t* pair_rank;
+    uint32_t rank_mask;
+    const uint32_t* order;
+    const GRec* rec;
+    const uint32_t* tiles;
+    float* acc;
+    float* wave_part;
+};
+struct PreBwdArgs {       // preprocess_bwd.hip
+    FwdInputs in;
+    ViewParams view;
+    const int* radii;
+    const GRec* rec;
+    const uint32_t* tiles;
+    const float* acc;
+    const float* wave_part;
+    const GeomHeader* header;
+    float lambda_sh;
+    BwdOutputs out;
+};
+
+// The device-resident argument block of a forward / backward pass.
+struct FwdPassArgs {
+    PreArgs pre;
+    HeaderArgs header;
+    DepthArgs depth;
+    EmitArgs emit;
+    RadixArgs radix[kMaxRadixPasses];
+    RangesArgs ranges;
+    BlendFwdArgs blend;
+};
+struct BwdPassArgs {
+    BlendBwdArgs blend;
+    PairReduceArgs reduce;
+    PreBwdArgs pre;
+};
+static_assert(sizeof(FwdPassArgs) <= 3072 && sizeof(BwdPassArgs) <= 3072, "pass blocks travel as by-value kernel arguments");
+
+// Host-side constants of a pass: everything that shapes the launch chain (and therefore keys the graph cache).
+struct FwdPlan {
+    int P, M, W, H, gx, gy;
+    uint32_t reserve;      // pair capacity the binning blob was carved with (>= 1)
+    PairLayout layout;
+    int nb;                // depth buckets
+    int ragged, counters;  // ragged SH addressing; counter mode (calculate_mean_transmittance)
+    int fwd_ppl;           // pixels per lane of the forward blend
+    int color_grid;        // persistent-grid size of the SH -> RGB kernel
+    int generic_depth_sort;  // rocPRIM sort + scan instead of the bucketed sort (never inside a graph)
+};
+struct BwdPlan {
+    int P, M, W, H, gx, gy;
+    uint32_t reserve;
+    PairLayout layout;
+    int bwd_ppl;
+    int has_pairs;         // 0: the forward ran with an empty reservation (P > 0, no binning blob)
+};
+
+// stage ids of the optional per-stage timers (capi.hip)
+enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
+
+// ---- per-stage issue functions (one per translation unit).  `a` points INTO the device pass block. ----------------
+void issue_preprocess_geom(const FwdPlan& p, const PreArgs* a, hipStream_t s);
+void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
+
+void issue_header_reduce(const HeaderArgs* a, hipStream_t s);
+void prepare_depth_bucket_sort(int nb);   // one-time LDS opt-in of the large-bucket-count kernels (not a stream op)
+void issue_depth_bucket_sort(const FwdPlan& p, const DepthArgs* a, hipStream_t s);
+void run_generic_depth_sort(int P, GeomState& g, hipStream_t s);   // rocPRIM, host pointers: direct issue only
+void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);
+const char* sorted_words(const BinState& b, const PairLayout& l);   // which blob buffer holds the sorted words
+void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
+                        hipStream_t s);
+
+void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s);
+void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s);
+void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s);
+void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_t s);
+
 void launch_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg, const float* means3D,
                                        const float* cam_pos, const float* shs, const int* radii, const int* touched,
                                        const float* transmittance, float* wSum, float* wSumSq, float* mean,
                                        float* variance, float* accum, hipStream_t s);
-void launch_pair_reduce(int P, int R, size_t n_tiles, const GeomState& g, const BinState& b, hipStream_t s);
-void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
-                                const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s);
+
+int env_int(const char* env, int dflt, int lo, int hi);   // capi.hip
 
 }  // namespace r3

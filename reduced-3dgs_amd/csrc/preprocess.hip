@@ -31,17 +31,6 @@ struct ShRowLds {
     __device__ __forceinline__ float at(int e) const { return base[skew(roff + e)]; }
 };
 
-struct PreArgs {
-    FwdInputs in;
-    ViewParams view;
-    GRec* rec;
-    ushort4* rect;
-    uint32_t* depth_key;
-    uint32_t* tiles;
-    PrePartial* partials;
-    int* radii;
-};
-
 // forward.cu:19-36 getSHOffset (float3 units)
 __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const int* perband, const int* cumsum, int* deg)
 {
@@ -63,8 +52,9 @@ __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const i
 // cull, projection, conic, radius, tile rect, depth key, per-view counters.  Reads 44 B per Gaussian.  Its
 // outputs are everything the depth sort / binning needs, so the SH -> RGB kernel below can run on a side
 // stream underneath the (launch-latency-bound) sort.
-__global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
+__global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(const PreArgs* __restrict__ ap)
 {
+    const PreArgs& a = *ap;   // pass block in device memory: wave-uniform (scalar) loads of the fields used
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P;
     const int i = blockIdx.x * kPreBlock + tid;
@@ -102,7 +92,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
             r.r = r.g = r.b = 0.f;  // filled in by the colour kernel
             r.rect_min = (uint32_t)o.rmin[0] | ((uint32_t)o.rmin[1] << 16);
             r.width_clamp = (uint32_t)(o.rmax[0] - o.rmin[0]);  // clamp bits OR-ed in by the colour kernel
-            r.pair_start = 0;                                      // filled in by the pair-emission kernel
+            r.pair_start = 0xFFFFFFFFu;   // filled in by the pair-emission kernel (stays ~0 if no pair was emitted)
             a.rec[i] = r;
             a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
                                      (unsigned short)o.rmax[1]);
@@ -151,9 +141,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(PreArgs a)
 // latency-bound depth-sort kernels of the main stream, and a full grid's LDS footprint (3 x 49 KB per CU) left their
 // workgroups no room -- the depth scatter kernel took 46 us instead of 14 us beside it.
 template <bool RAGGED>
-__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a, int n_blocks)
+__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(const PreArgs* __restrict__ ap)
 {
     __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
+    const PreArgs& a = *ap;
+    const int n_blocks = a.color_blocks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
   for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -247,42 +239,20 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(PreArgs a, 
   }
 }
 
-void launch_preprocess(const FwdInputs& in, const ViewParams& view, GeomState& g, int* radii, hipStream_t s)
+void issue_preprocess_geom(const FwdPlan& p, const PreArgs* a, hipStream_t s)
 {
-    PreArgs a;
-    a.in = in;
-    a.view = view;
-    a.rec = g.rec;
-    a.rect = g.rect;
-    a.depth_key = g.depth_key;
-    a.tiles = g.tiles;
-    a.partials = g.partials;
-    a.radii = radii;
-    const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
+    const int blocks = (p.P + kPreBlock - 1) / kPreBlock;
     hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, a);
 }
 
-void launch_preprocess_color(const FwdInputs& in, const ViewParams& view, GeomState& g, hipStream_t s)
+void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s)
 {
-    PreArgs a;
-    a.in = in;
-    a.view = view;
-    a.rec = g.rec;
-    a.rect = g.rect;
-    a.depth_key = g.depth_key;
-    a.tiles = g.tiles;
-    a.partials = g.partials;
-    a.radii = nullptr;
-    const int blocks = (in.P + kPreBlock - 1) / kPreBlock;
-    static const int max_grid = [] {   // R3DGS_COLOR_GRID: persistent-grid size (0 = one workgroup per 256 Gaussians)
-        const char* v = getenv("R3DGS_COLOR_GRID");
-        return v ? atoi(v) : 512;
-    }();
-    const int grid = max_grid > 0 && blocks > max_grid ? max_grid : blocks;
-    if (in.coeffs_num)
-        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), 0, s, a, blocks);
+    const int blocks = (p.P + kPreBlock - 1) / kPreBlock;   // == a->color_blocks
+    const int grid = p.color_grid > 0 && blocks > p.color_grid ? p.color_grid : blocks;
+    if (p.ragged)
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), 0, s, a, blocks);
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), 0, s, a);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2

@@ -39,14 +39,20 @@ struct ShRowLdsRW {
 // No atomics, fixed summation order: the backward is bit-reproducible.  (Letting each Gaussian's lane loop
 // over its own pairs instead cost 0.86 ms: the largest splats own 600+ pairs.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const float* __restrict__ pair_grad,
-                                                          unsigned char* __restrict__ pair_flag,
-                                                          const uint32_t* __restrict__ pair_gid, uint32_t rank_mask,
-                                                          const uint32_t* __restrict__ order,
-                                                          const GRec* __restrict__ rec,
-                                                          const uint32_t* __restrict__ tiles, float* __restrict__ acc,
-                                                          float* __restrict__ wave_part)
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* __restrict__ ap)
 {
+    const PairReduceArgs& a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    if (blockIdx.x * 256u >= R) return;   // the grid covers the reservation, not the actual pair count
+    const float* __restrict__ pair_grad = a.pair_grad;
+    unsigned char* __restrict__ pair_flag = a.pair_flag;
+    const uint32_t* __restrict__ pair_gid = a.pair_rank;
+    const uint32_t rank_mask = a.rank_mask;
+    const uint32_t* __restrict__ order = a.order;
+    const GRec* __restrict__ rec = a.rec;
+    const uint32_t* __restrict__ tiles = a.tiles;
+    float* __restrict__ acc = a.acc;
+    float* __restrict__ wave_part = a.wave_part;
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = e < R;
@@ -96,31 +102,16 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(uint32_t R, const floa
     }
 }
 
-void launch_pair_reduce(int P, int R, size_t n_tiles, const GeomState& g, const BinState& b, hipStream_t s)
+void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
 {
-    if (R <= 0) return;
-    const int rank_bits = tile_rank_bits(P, n_tiles);
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.pair_grad, b.pair_flag,
-                       rank_bits ? b.tile_in : b.gauss_in, rank_bits ? (1u << rank_bits) - 1u : 0xFFFFFFFFu,
-                       rank_bits ? g.order : nullptr, g.rec, g.tiles, g.acc, b.wave_part);
+    if (!p.has_pairs) return;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.reserve + 255u) / 256u), dim3(256), 0, s, a);
 }
 
-struct PreBwdArgs {
-    FwdInputs in;
-    ViewParams view;
-    const int* radii;
-    const GRec* rec;
-    const uint32_t* tiles;
-    const float* acc;
-    const float* wave_part;  // nullptr when num_rendered == 0
-    const GeomHeader* header;
-    float lambda_sh;
-    BwdOutputs out;
-};
-
-__global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
+__global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
 {
     __shared__ float s_sh[kBwdBlock / 64][kBwdWaveShFloats];
+    const PreBwdArgs& a = *ap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
     const int i = blockIdx.x * kBwdBlock + tid;
@@ -149,9 +140,13 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
     if (vis) {
         const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
         const GRec r = a.rec[i];
-        if (a.wave_part) {  // 2D-stage gradient row: final in acc[], or in <= tiles/64 + 2 ordered pieces
+        // 2D-stage gradient row: final in acc[], or in <= tiles/64 + 2 ordered pieces.  A Gaussian whose pairs did not
+        // all fit the pass's pair reservation (num_rendered > reserve: the farthest pairs were dropped and the pass is
+        // flagged) gets zero 2D-stage gradients instead of a partial sum.
+        const uint32_t start = r.pair_start, ntile = a.tiles[i];
+        if (a.wave_part && start != 0xFFFFFFFFu && start + ntile <= a.header->num_pairs) {
             float acc9[kPairGrad];
-            const uint32_t start = r.pair_start, last = start + a.tiles[i] - 1u;
+            const uint32_t last = start + ntile - 1u;
             const uint32_t w0 = start >> 6, w1 = last >> 6;
             if (w0 == w1) {
                 const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
@@ -252,21 +247,9 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(PreBwdArgs a)
     }
 }
 
-void launch_preprocess_backward(const FwdInputs& in, const ViewParams& view, const int* radii, const GeomState& g,
-                                const BinState& b, const BwdOutputs& out, float lambda_sh_sparsity, hipStream_t s)
+void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_t s)
 {
-    PreBwdArgs a;
-    a.in = in;
-    a.view = view;
-    a.radii = radii;
-    a.rec = g.rec;
-    a.tiles = g.tiles;
-    a.acc = g.acc;
-    a.wave_part = b.wave_part;  // nullptr when num_rendered == 0
-    a.header = g.header;
-    a.lambda_sh = lambda_sh_sparsity;
-    a.out = out;
-    const int blocks = (in.P + kBwdBlock - 1) / kBwdBlock;
+    const int blocks = (p.P + kBwdBlock - 1) / kBwdBlock;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kBwdBlock), 0, s, a);
 }
 

@@ -24,11 +24,14 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 _lib.r3dgs_version.restype = C.c_char_p
 _lib.r3dgs_last_error.restype = C.c_char_p
-for _n in ("r3dgs_geometry_bytes", "r3dgs_binning_bytes"):
-    getattr(_lib, _n).restype = C.c_size_t
-    getattr(_lib, _n).argtypes = [_i]
+_lib.r3dgs_geometry_bytes.restype = C.c_size_t
+_lib.r3dgs_geometry_bytes.argtypes = [_i]
+_lib.r3dgs_binning_bytes.restype = C.c_size_t
+_lib.r3dgs_binning_bytes.argtypes = [_i, _i, _i, _i]
 _lib.r3dgs_image_bytes.restype = C.c_size_t
 _lib.r3dgs_image_bytes.argtypes = [_i, _i]
+_lib.r3dgs_binning_capacity.restype = _i
+_lib.r3dgs_binning_capacity.argtypes = [_i, _i, _i, C.c_size_t]
 _lib.r3dgs_mark_visible.restype = _i
 _lib.r3dgs_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
 _FWD_TAIL = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i,
@@ -37,11 +40,21 @@ _lib.r3dgs_forward.restype = _i
 _lib.r3dgs_forward.argtypes = [_ALLOC, _vp, _ALLOC, _vp, _ALLOC, _vp, _i, _vp, _i] + _FWD_TAIL
 _lib.r3dgs_inference_forward.restype = _i
 _lib.r3dgs_inference_forward.argtypes = [_ALLOC, _vp, _ALLOC, _vp, _ALLOC, _vp, _i, _vp, _i, _vp, _vp, _vp] + _FWD_TAIL
+_lib.r3dgs_reserve_hint.restype = _i
+_lib.r3dgs_reserve_hint.argtypes = [_i, _i, _i]
+_lib.r3dgs_forward_reserved.restype = C.c_longlong
+_lib.r3dgs_forward_reserved.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _i] + _FWD_TAIL
+_lib.r3dgs_inference_forward_reserved.restype = C.c_longlong
+_lib.r3dgs_inference_forward_reserved.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp] + _FWD_TAIL
+_lib.r3dgs_pass_query.restype = _i
+_lib.r3dgs_pass_query.argtypes = [C.c_longlong, _i, _vp, _vp, _vp, _vp]
+_lib.r3dgs_reserve_overflow_events.restype = C.c_longlong
+_lib.r3dgs_reserve_overflow_events.argtypes = [_vp, _vp]
 _lib.r3dgs_backward.restype = _i
 _lib.r3dgs_backward.argtypes = ([_i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                  _vp, _vp, _vp, _vp] + [_vp] * 10 + [_f, _i, _vp])
 _lib.r3dgs_export_binning.restype = _i
-_lib.r3dgs_export_binning.argtypes = [_i, _i, _i, _i] + [_vp] * 10
+_lib.r3dgs_export_binning.argtypes = [_i, _i, _i, _i, _i] + [_vp] * 10
 
 _lib.r3dgs_colour_variance_accumulate.restype = _i
 _lib.r3dgs_colour_variance_accumulate.argtypes = [_i, _vp, _i, _i] + [_vp] * 12
@@ -132,10 +145,15 @@ class _Blob:
     def __init__(self, dev):
         self.dev = dev
         self.tensor = torch.empty(0, dtype=torch.uint8, device=dev)
+        self.error = None
 
         def alloc(nbytes, _user):
-            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
-            return self.tensor.data_ptr()
+            try:
+                self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+                return self.tensor.data_ptr()
+            except Exception as e:  # an exception cannot cross the C frame: keep it, hand back NULL
+                self.error = e
+                return None
 
         self.cb = _ALLOC(alloc)
 
@@ -144,20 +162,145 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~10 us)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+class NumRendered:
+    """The `num_rendered` slot of the forward's return tuple (rasterize_points.cu:221).  The asynchronous forward
+    does not wait for the number: it lives on the device, and this object fetches it the first time someone looks
+    (int(), index, comparison, print) -- the training loop never does, it only hands the object back to
+    rasterize_gaussians_backward.  `.capacity` is the pair capacity the binning buffer was sized with."""
+
+    __slots__ = ("ticket", "capacity", "_value", "_flags")
+
+    def __init__(self, ticket, capacity, value=None):
+        self.ticket, self.capacity, self._value, self._flags = ticket, capacity, value, 0
+
+    def _resolve(self, wait=True):
+        if self._value is None:
+            r, v, cap, fl = _i(), _i(), _i(), _i()
+            st = _check(_lib.r3dgs_pass_query(self.ticket, int(wait), C.byref(r), C.byref(v), C.byref(cap),
+                                              C.byref(fl)), "num_rendered")
+            if st == 1:
+                self._value, self._flags = r.value, fl.value
+        return self._value
+
+    @property
+    def truncated(self):
+        """True if num_rendered exceeded the reservation of this pass (the farthest pairs were dropped)."""
+        self._resolve()
+        return bool(self._flags & 1)
+
+    def ready(self):
+        return self._resolve(wait=False) is not None
+
+    def __int__(self):
+        return self._resolve()
+
+    __index__ = __int__
+
+    def __float__(self):
+        return float(self._resolve())
+
+    def __eq__(self, other):
+        return int(self) == other
+
+    def __lt__(self, other):
+        return int(self) < other
+
+    def __le__(self, other):
+        return int(self) <= other
+
+    def __gt__(self, other):
+        return int(self) > other
+
+    def __ge__(self, other):
+        return int(self) >= other
+
+    def __hash__(self):
+        return hash(int(self))
+
+    def __bool__(self):
+        return int(self) != 0
+
+    def __repr__(self):
+        return str(int(self))
+
+
+_size_cache = {}
+
+
+def _blob_bytes(kind, *key):
+    k = (kind,) + key
+    v = _size_cache.get(k)
+    if v is None:
+        if kind == "geom":
+            v = _lib.r3dgs_geometry_bytes(*key)
+        elif kind == "bin":
+            v = _lib.r3dgs_binning_bytes(*key)
+        else:
+            v = _lib.r3dgs_image_bytes(*key)
+        if v == 0:
+            raise RuntimeError(f"rasterize_gaussians: {_lib.r3dgs_last_error().decode()}")
+        if len(_size_cache) > 4096:
+            _size_cache.clear()
+        _size_cache[k] = v
+    return v
+
+
+_overflow_seen = 0
+_calls = 0
+
+
+def reserve_overflow_events():
+    """Passes whose num_rendered exceeded their pair reservation so far (the reservation grows afterwards)."""
+    return int(_lib.r3dgs_reserve_overflow_events(None, None))
+
+
+def _watch_overflow():
+    global _overflow_seen, _calls
+    _calls += 1
+    if _calls & 15:
+        return
+    r, cap = _i(), _i()
+    n = int(_lib.r3dgs_reserve_overflow_events(C.byref(r), C.byref(cap)))
+    if n > _overflow_seen:
+        _overflow_seen = n
+        import warnings
+        warnings.warn(f"diff_gaussian_rasterization: a pass needed {r.value} (tile, Gaussian) pairs but {cap.value} "
+                      "were reserved; its farthest pairs were dropped and the reservation has been raised "
+                      "(raster_settings.debug=True or R3DGS_RESERVE=off selects the exact-size path)", RuntimeWarning)
+
+
 def _forward_common(ragged, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                     viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
-                    prefiltered, debug, counters=None):
+                    prefiltered, debug, counters=None, exact=False, _reserve=None):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:158-161
     dev = means3D.device
     if dev.type != "cuda":
         raise RuntimeError("the MI355X rasterizer needs device tensors (no CPU path)")
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    geom, binning, img = _Blob(dev), _Blob(dev), _Blob(dev)
+    u8 = dict(dtype=torch.uint8, device=dev)
     if P == 0:
         out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((0,), dtype=torch.int32, device=dev)
-        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor
+        e = torch.empty(0, **u8)
+        return NumRendered(0, 0, 0), out_color, radii, e, e.clone(), e.clone()
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     bg = _dev_f32(background, dev)
@@ -168,28 +311,49 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
     touched = transm = None
     if counters is not None:
         touched, transm = counters
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         tail = (_ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot),
                 _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                 _ptr(out_color), _ptr(touched), _ptr(transm), _ptr(radii), int(counters is not None),
                 int(bool(debug)), _stream())
         if ragged is None:
-            M = int(shc.size(1)) if shc is not None else 0
-            rendered = _lib.r3dgs_forward(geom.cb, None, binning.cb, None, img.cb, None, P, _ptr(deg), M, *tail)
+            head = (P, _ptr(deg), int(shc.size(1)) if shc is not None else 0)
+            fn_exact, fn_reserved = _lib.r3dgs_forward, _lib.r3dgs_forward_reserved
         else:
             coeffs, perband, cumsum = (_dev_i32(t, dev) for t in ragged)
-            bands = int(perband.numel()) if perband is not None else 0
-            rendered = _lib.r3dgs_inference_forward(geom.cb, None, binning.cb, None, img.cb, None, P, _ptr(deg), bands,
-                                                    _ptr(coeffs), _ptr(perband), _ptr(cumsum), *tail)
+            head = (P, _ptr(deg), int(perband.numel()) if perband is not None else 0, _ptr(coeffs), _ptr(perband),
+                    _ptr(cumsum))
+            fn_exact, fn_reserved = _lib.r3dgs_inference_forward, _lib.r3dgs_inference_forward_reserved
+        # Asynchronous path: blobs sized up front from a pair reservation, nothing waits for num_rendered.  The exact-size
+        # path (allocator callbacks, one wait) runs when nothing is known about this view size yet, in debug mode, or
+        # when asked for.
+        reserve = 0 if (exact or debug) else _lib.r3dgs_reserve_hint(P, W, H)
+        if _reserve is not None:   # tests: a chosen reservation
+            reserve = int(_reserve)
+        if reserve > 0:
+            geom = torch.empty(_blob_bytes("geom", P), **u8)
+            binning = torch.empty(_blob_bytes("bin", P, W, H, reserve), **u8)
+            img = torch.empty(_blob_bytes("img", W, H), **u8)
+            ticket = fn_reserved(geom.data_ptr(), binning.data_ptr(), img.data_ptr(), reserve, *head, *tail)
+            if ticket < 0:
+                _check(-1, "rasterize_gaussians")
+            _watch_overflow()
+            return NumRendered(ticket, reserve), out_color, radii, geom, binning, img
+        geom, binning, img = _Blob(dev), _Blob(dev), _Blob(dev)
+        rendered = fn_exact(geom.cb, None, binning.cb, None, img.cb, None, *head, *tail)
+    for blob in (geom, binning, img):
+        if blob.error is not None:   # e.g. torch OOM inside the allocator callback: surface the original exception
+            raise blob.error
     _check(rendered, "rasterize_gaussians")
-    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+    return NumRendered(0, max(rendered, 1), rendered), out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
                         prefiltered, debug):
     """RasterizeGaussiansCUDA (rasterize_points.cu:136-222) ->
-    (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer).
+    num_rendered is a NumRendered: an int-like that is only fetched from the device when looked at."""
     return _forward_common(None, background, means3D, colors, opacity, scales, rotations, scale_modifier,
                            cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
                            degrees, campos, prefiltered, debug)
@@ -248,8 +412,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     col, sc, rot, cov = (_dev_f32(t, dev) for t in (colors, scales, rotations, cov3D_precomp))
     vm, pm, cp = _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev), _dev_f32(campos, dev)
     g, shc, deg, rad = _dev_f32(dL_dout_color, dev), _dev_f32(sh, dev), _dev_i32(degrees, dev), _dev_i32(radii, dev)
-    with torch.cuda.device(dev):
-        st = _lib.r3dgs_backward(P, _ptr(deg), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
+    if isinstance(R, NumRendered):
+        cap = R.capacity
+    else:   # a plain int from an older caller: the capacity is what the binning buffer was sized with
+        cap = _lib.r3dgs_binning_capacity(P, W, H, int(binningBuffer.numel())) if binningBuffer.numel() else 0
+    with _on_device(dev):
+        st = _lib.r3dgs_backward(P, _ptr(deg), M, int(cap), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
                                  float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp),
                                  float(tan_fovx), float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer),
                                  _ptr(imageBuffer), _ptr(g), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
@@ -267,7 +435,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P:
         m3, vm, pm = _dev_f32(means3D, dev), _dev_f32(viewmatrix, dev), _dev_f32(projmatrix, dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _check(_lib.r3dgs_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), _ptr(present), _stream()), "mark_visible")
     return present
 
@@ -277,14 +445,19 @@ def export_binning(P, R, H, W, geomBuffer, binningBuffer, imageBuffer):
     ranges, n_contrib, final T and tiles_touched of a finished forward -- for bit-exact integer parity tests."""
     dev = geomBuffer.device
     gx, gy = (W + 15) // 16, (H + 15) // 16
+    if isinstance(R, NumRendered):
+        cap, R = R.capacity, int(R)
+    else:
+        cap = _lib.r3dgs_binning_capacity(P, W, H, int(binningBuffer.numel())) if binningBuffer.numel() else 0
+    R = min(int(R), cap)
     keys = torch.empty((R,), dtype=torch.int64, device=dev)
     plist = torch.empty((R,), dtype=torch.int32, device=dev)
     ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
     n_contrib = torch.empty((H * W,), dtype=torch.int32, device=dev)
     final_T = torch.empty((H * W,), dtype=torch.float32, device=dev)
     tiles = torch.empty((P,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        _check(_lib.r3dgs_export_binning(P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+    with _on_device(dev):
+        _check(_lib.r3dgs_export_binning(P, cap, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
                                          _ptr(keys), _ptr(plist), _ptr(ranges), _ptr(n_contrib), _ptr(final_T),
                                          _ptr(tiles), _stream()), "export_binning")
     return dict(keys=keys, point_list=plist, ranges=ranges, n_contrib=n_contrib, final_T=final_T, tiles_touched=tiles)
@@ -333,7 +506,7 @@ def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotation
                                   cam_projmatrices[i], txs[i], tys[i], Hs[i], Ws[i], shc, deg, cams[i], False, False,
                                   counters=(touched, transm))
             radii = out[2]
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 _check(_lib.r3dgs_colour_variance_accumulate(P, _ptr(deg), M, D, _ptr(m3), cams[i].data_ptr(),
                                                              _ptr(shc), _ptr(radii), _ptr(touched), _ptr(transm),
                                                              _ptr(wSum), _ptr(wSumSq), _ptr(mean), _ptr(variance),
@@ -366,7 +539,7 @@ def find_minimum_projected_pixel_size(w2ndc_transforms, w2ndc_transforms_inverse
     if P:
         m, mi = _dev_f32(w2ndc_transforms, dev), _dev_f32(w2ndc_transforms_inverse, dev)
         Hs, Ws = _dev_i32(image_height, dev), _dev_i32(image_width, dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _check(_lib.r3dgs_min_pixel_size(P, int(w2ndc_transforms.size(0)), _ptr(m), _ptr(mi), _ptr(_dev_f32(means3D, dev)),
                                              _ptr(Hs), _ptr(Ws), _ptr(out), _stream()),
                    "find_minimum_projected_pixel_size")
@@ -384,7 +557,7 @@ def sphere_ellipsoid_intersection(means3D, scales, rotations, neighbours_indices
         nbr = _dev_i32(neighbours_indices, dev)
         if nbr.numel() != P * knn:
             raise RuntimeError("neighbours_indices must hold P * knn entries")
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _check(_lib.r3dgs_sphere_ellipsoid_intersection(
                 P, knn, _ptr(_dev_f32(means3D, dev)), _ptr(_dev_f32(scales, dev)), _ptr(_dev_f32(rotations, dev)),
                 _ptr(nbr), _ptr(_dev_f32(sphere_radius, dev)), _ptr(red), mask.data_ptr() if knn else None,
@@ -401,7 +574,7 @@ def allocate_minimum_redundancy_value(redundancy_values, neighbours_indices, int
         nbr, msk = _dev_i32(neighbours_indices, dev), _dev_u8(intersection_mask, dev)
         if nbr.numel() != P * knn or msk.numel() != P * knn:
             raise RuntimeError("neighbours_indices / intersection_mask must hold P * knn entries")
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _check(_lib.r3dgs_min_redundancy(P, knn, _ptr(_dev_i32(redundancy_values, dev)), _ptr(nbr), _ptr(msk),
                                              _ptr(out), _stream()), "allocate_minimum_redundancy_value")
     return (out,)
@@ -416,7 +589,7 @@ def kmeans_cuda(values, centers, tol, max_iterations, _want_iterations=False):
     ids = torch.zeros((n, 1), dtype=torch.int32, device=dev)
     new_centers = torch.empty((nc,), dtype=torch.float32, device=dev)
     iters = torch.zeros((1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws_bytes = _lib.r3dgs_kmeans_workspace_bytes(n, nc)
         if ws_bytes == 0:
             raise RuntimeError(f"kmeans_cuda: {_lib.r3dgs_last_error().decode()}")
@@ -441,6 +614,6 @@ def pack_view_stats(viewspace_grad, radii, grad_norm_out, visible_out, radii_out
     for t, dt in ((grad_norm_out, torch.float32), (visible_out, torch.float32), (radii_out, torch.int32)):
         if t.device != dev or t.dtype != dt or t.numel() != P or not t.is_contiguous():
             raise RuntimeError("pack_view_stats: outputs must be contiguous [P] tensors on the same GPU")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(_lib.r3dgs_pack_view_stats(P, _ptr(vg), _ptr(rd), _ptr(grad_norm_out), _ptr(visible_out), _ptr(radii_out),
                                           _stream()), "pack_view_stats")

@@ -3,6 +3,8 @@ import json
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -14,16 +16,28 @@ def test_stage_bytes_add_up_to_the_iteration_formula():
     # B_iter = P(718 + 36 K) + 280 R + 40 N + the 8 Tn ranges term; 24 R x 6 passes is the reference's 45-bit sort
     total = sum(sb.values())
     assert abs(total - (P * (718 + 36 * K) + 280 * R + 40 * N + 8 * Tn)) < 1e-6 * total
-    assert set(sb) == set(bench.STAGE_KERNELS) | {"depth_sort_scan"}
+    assert set(sb) == set(bench.STAGE_KERNELS)
 
 
 def test_pmc_traffic_uses_the_committed_counters():
     import bench
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+    path = os.path.join(ROOT, bench.PMC_SUMMARY)
+    if not os.path.exists(path):
+        pytest.skip("no PMC summary committed for this round yet")
+    pmc = json.load(open(path))
     for stage, kernels in bench.STAGE_KERNELS.items():
-        for name, launches in kernels:
+        for name, launches, wide in kernels:
             assert name in pmc, name
     t = bench.pmc_traffic("blend_bwd", "metric_500k_1600x1062")
-    want = sum((2 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024 for k in ("r3::blend_bwd_kernel<4>", "r3::pair_reduce_kernel"))
-    assert t == int(want) and 3e8 < t < 7e8
+    # the x2 FETCH_SIZE correction only for the kernel with 16-B/lane loads
+    want = ((2 * pmc["r3::blend_bwd_kernel<4>"]["FETCH_SIZE"] + pmc["r3::blend_bwd_kernel<4>"]["WRITE_SIZE"]) +
+            (pmc["r3::pair_reduce_kernel"]["FETCH_SIZE"] + pmc["r3::pair_reduce_kernel"]["WRITE_SIZE"])) * 1024
+    assert t == int(want) and 1e8 < t < 7e8
     assert bench.pmc_traffic("blend_bwd", "some_other_workload") is None
+
+
+def test_cgroup_probe_never_raises():
+    import bench
+    cg = bench.cgroup_cpu()
+    assert cg is None or {"quota_cpus", "nr_throttled", "throttled_usec", "usage_usec"} <= set(cg)
+    assert bench.effective_cpus() >= 1

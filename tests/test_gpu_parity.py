@@ -43,12 +43,19 @@ def dev(a, dtype=None):
     return t.cuda()
 
 
-def hip_forward(C_, bg, g, cam, H, W, colors=None, cov=None, use_sh=True, use_sr=True, mod=1.0, debug=False):
+def hip_forward(C_, bg, g, cam, H, W, colors=None, cov=None, use_sh=True, use_sr=True, mod=1.0, debug=False,
+                exact=False):
+    """Through `_C.rasterize_gaussians`, i.e. whichever path the library picks: the exact-size path the first time a
+    view size is seen (and with debug=True), the asynchronous reserved path (one graph launch) afterwards.  A pass
+    whose pair count outgrew a reservation learnt from an unrelated earlier test scene is redone exactly."""
     args = (dev(bg), dev(g["means3D"]), dev(colors), dev(g["opacity"]), dev(g["scales"] if use_sr else None),
             dev(g["rotations"] if use_sr else None), mod, dev(cov), dev(cam.world_view_transform),
             dev(cam.full_proj_transform), cam.tanfovx, cam.tanfovy, H, W, dev(g["sh"] if use_sh else None),
             dev(g["degrees"]), dev(cam.camera_center), False, debug)
-    return args, C_.rasterize_gaussians(*args)
+    out = C_._forward_common(None, *args, exact=True) if exact else C_.rasterize_gaussians(*args)
+    if out[0].truncated:
+        out = C_._forward_common(None, *args, exact=True)
+    return args, out
 
 
 def hip_backward(C_, fargs, fout, dl, lam, debug=False):
@@ -70,6 +77,7 @@ def check_forward(C_, fout, ref, H, W, P):
     st = ref["state"]
     assert R == ref["num_rendered"]
     np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
+    assert not R.truncated
     ex = C_.export_binning(P, R, H, W, geom, binning, img)
     np.testing.assert_array_equal(ex["tiles_touched"].cpu().numpy().astype(np.uint32), st["tiles_touched"])
     np.testing.assert_array_equal(ex["keys"].cpu().numpy().view(np.uint64), st["keys"])
@@ -167,8 +175,8 @@ def test_oracle_parity_larger(C_, kw):
 @pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])
 def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     """Depth-sort corner cases of the bucketed sort (binning.hip): `plane` puts 20k splats at ONE depth (a single
-    bucket far above its LDS capacity -> the generic-sort fallback, and every tie is decided by the Gaussian index,
-    rasterizer_impl.cu:110-113); `few_depths` has 7 distinct depths (huge buckets next to empty ones);
+    bucket far above its LDS capacity -> the workgroup's global-memory radix sort, and every tie is decided by the
+    Gaussian index, rasterizer_impl.cu:110-113); `few_depths` has 7 distinct depths (huge buckets next to empty ones);
     `two_far_apart` stretches the depth range so that nearly everything lands in the first bucket."""
     W, H, P = 320, 240, 20_000
     cam = ss.make_camera(W, H, 250.0)          # R = I, T = 0: view depth == world z exactly
@@ -191,6 +199,11 @@ def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     gr = orc.backward(ref["state"], dl, 0.05)
     bout = hip_backward(C_, fargs, fout, dl, 0.05, debug=True)
     check_backward(bout, gr, ref["state"], 16)
+    # the same through the asynchronous path (graph replay; the library may also route it through the generic sort
+    # once it has seen the overflow hint): identical integers and image
+    _, fout2 = hip_forward(C_, bg, g, cam, H, W)
+    check_forward(C_, fout2, ref, H, W, P)
+    assert torch.equal(fout2[1], fout[1])
 
 
 @pytest.mark.parametrize("kw", [
@@ -199,7 +212,7 @@ def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     dict(P=65, W=130, H=70, f=80.0, scale_mu=0.2, mod=0.7),
     dict(P=2500, W=96, H=80, f=70.0, scale_mu=1.2, mod=1.0),   # every splat covers most tiles: lists of ~2000
     dict(P=4000, W=320, H=200, f=200.0, scale_mu=0.08, mod=1.6),
-    # 256 x 144 = 36864 tiles (16 tile bits): beyond the two 7-bit digits of the own radix sort -> rocPRIM key sort.
+    # 256 x 144 = 36864 tiles (16 tile bits): two 8-bit digits instead of two 7-bit ones.
     # 9.4 Mpix with few splats: the ~170 threshold-ambiguous pixels (excluded from the image checks) each move a
     # gradient by one pixel's worth, which is 4e-4 of the largest gradient here -> looser gradient bar for this case.
     dict(P=3000, W=4096, H=2304, f=3000.0, scale_mu=0.03, mod=1.0, grad_rel=2e-3),
@@ -336,8 +349,8 @@ def test_empty_and_all_culled(C_):
 # -------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=["metric_500k_1600x1062", "garden_like_2M_1600x1062"])
 def metric_scene(request):
-    """The bench workload, and the 2 M-Gaussian one: 21 depth-rank bits + 13 tile bits > 32, i.e. the (tile, id) pair
-    sort, four times the depth-histogram rows, 14.5 M pairs."""
+    """The bench workload, and the 2 M-Gaussian one: 21 depth-rank bits + 13 tile bits > 32, i.e. 64-bit pair words,
+    four times the depth-histogram rows and twice the depth buckets, 14.5 M pairs."""
     w = ss.WORKLOADS[request.param]
     cam = ss.make_camera(w["W"], w["H"], w["f"], None)
     g = ss.make_gaussians(w["P"], cam, seed=0, degree_mode=w["degree_mode"])
@@ -411,8 +424,8 @@ def test_full_size_properties(C_, metric_scene):
 def test_repeated_backward_and_pair_sort_path(C_):
     """(1) Two backward passes over one forward state (retain_graph): the per-pair "row written" flags are cleared
     by the forward and again by every backward, so the second pass must equal the first bit for bit.
-    (2) The (key, value) pair tile sort, used when tile bits + depth-rank bits exceed 32, gives the same integer
-    outputs as the packed key-only sort: forced here in a child process via R3DGS_TILE_SORT=pairs."""
+    (2) The 64-bit pair words, used when tile bits + depth-rank bits exceed 32, give the same integer outputs as the
+    32-bit ones: forced here in a child process via R3DGS_TILE_SORT=wide (together with the generic depth sort)."""
     import subprocess
     import sys
     W, H, P = 320, 240, 6000
@@ -444,7 +457,7 @@ def test_repeated_backward_and_pair_sort_path(C_):
         "t.check_forward(_C, fout, ref, 240, 320, 6000)\n"
         "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), t.orc.backward(ref['state'], dl, 0.1), ref['state'], 16)\n"
         "print('pairs-path-ok')\n") % (ROOT, os.path.join(ROOT, "reduced-3dgs_amd"))
-    env = dict(os.environ, R3DGS_TILE_SORT="pairs", R3DGS_DEPTH_SORT="generic")
+    env = dict(os.environ, R3DGS_TILE_SORT="wide", R3DGS_DEPTH_SORT="generic")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert "pairs-path-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -503,3 +516,95 @@ def test_optimisation_through_the_boundary_fits_target_views(C_):
     end_held = l1(4)
     assert end_train < 0.45 * start_train, (start_train, end_train)
     assert end_held < 0.7 * start_held, (start_held, end_held)
+
+
+# -------------------------------------------------------------------------------------------------
+# the asynchronous path: pair reservation instead of a num_rendered read-back, one graph launch per pass
+# -------------------------------------------------------------------------------------------------
+def test_reserved_graph_path_equals_exact_path(C_):
+    """Two different scenes / cameras of one shape, alternating through the reserved path (fresh tensors every pass, so
+    every pointer of the replayed graph changes) against the exact-size path: images, radii, sorted lists and all
+    gradients bit for bit."""
+    W, H, P = 352, 208, 9000
+    scenes = []
+    for seed, cam_seed in ((31, 2), (32, 5)):
+        cam = ss.make_camera(W, H, 260.0, cam_seed)
+        g = ss.make_gaussians(P, cam, seed=seed, degree_mode="mixed", scale_mu=0.03)
+        bg = np.array([0.1 * seed % 1.0, 0.5, 0.2], np.float32)
+        dl = ss.upstream_grad(W, H, seed=seed) * (W * H)
+        fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
+        assert fout[0].ticket == 0   # exact-size pass
+        bout = hip_backward(C_, fargs, fout, dl, 0.03)
+        ex = C_.export_binning(P, fout[0], H, W, fout[3], fout[4], fout[5])
+        scenes.append((cam, g, bg, dl, fout, bout, ex))
+    taken = 0
+    for rep in range(3):
+        for cam, g, bg, dl, fout, bout, ex in scenes:
+            fargs2, fout2 = hip_forward(C_, bg, g, cam, H, W)
+            R2 = fout2[0]
+            if R2.ticket:
+                taken += 1
+                assert R2.capacity > int(R2) and not R2.truncated
+            assert R2 == int(fout[0])
+            assert torch.equal(fout2[1], fout[1]) and torch.equal(fout2[2], fout[2])
+            ex2 = C_.export_binning(P, R2, H, W, fout2[3], fout2[4], fout2[5])
+            for k in ("keys", "point_list", "ranges", "n_contrib", "final_T", "tiles_touched"):
+                assert torch.equal(ex2[k], ex[k]), k
+            bout2 = hip_backward(C_, fargs2, fout2, dl, 0.03)
+            for a, b in zip(bout, bout2):
+                assert torch.equal(a, b)
+    assert taken >= 5   # the library did switch to the reserved path after the first exact pass
+
+
+def test_truncated_pass_drops_the_farthest_pairs_and_is_flagged(C_):
+    """num_rendered above the reservation: the pass keeps the `reserve` nearest pairs (emission is in depth order),
+    stays self-consistent (sorted list, ranges, finite image and gradients, zero gradients for dropped Gaussians), is
+    flagged, and the next hint covers the view."""
+    W, H, P = 320, 240, 8000
+    cam = ss.make_camera(W, H, 250.0, 6)
+    g = ss.make_gaussians(P, cam, seed=40, degree_mode="all3", scale_mu=0.03)
+    bg = np.array([0.3, 0.2, 0.1], np.float32)
+    dl = ss.upstream_grad(W, H, seed=7) * (W * H)
+    fargs, fex = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    R = int(fex[0])
+    events0 = C_.reserve_overflow_events()
+    reserve = R // 2
+    out = C_._forward_common(None, *fargs, _reserve=reserve)
+    nr = out[0]
+    assert nr.capacity == reserve and int(nr) == R and nr.truncated
+    assert torch.equal(out[2], fex[2])                                   # radii come from the geometry stage
+    assert bool(torch.isfinite(out[1]).all())
+    ex = C_.export_binning(P, nr, H, W, out[3], out[4], out[5])           # exports min(R, capacity) entries
+    keys, pl = ex["keys"], ex["point_list"].to(torch.int64)
+    assert keys.numel() == reserve and bool((keys[1:] >= keys[:-1]).all())
+    rng_ = ex["ranges"].to(torch.int64)
+    assert int((rng_[:, 1] - rng_[:, 0]).sum()) == reserve
+    depth = torch.from_numpy(oracle_forward(bg, g, cam, H, W)["state"]["depths"]).cuda()
+    kept = torch.zeros(P, dtype=torch.bool, device="cuda")
+    kept[pl] = True
+    vis = fex[2] > 0
+    assert float(depth[kept].max()) <= float(depth[vis & ~kept].min())   # what was dropped lies behind what was kept
+    bout = C_.rasterize_gaussians_backward(fargs[0], fargs[1], out[2], fargs[2], fargs[4], fargs[5], fargs[6], fargs[7],
+                                           fargs[8], fargs[9], fargs[10], fargs[11], dev(dl), fargs[14], fargs[15],
+                                           fargs[16], out[3], nr, out[4], out[5], 0.0, False)
+    assert all(bool(torch.isfinite(t).all()) for t in bout)
+    assert bool((bout[0][vis & ~kept] == 0).all())                       # no 2D-stage gradient for dropped Gaussians
+    # the event is counted (harvested lazily) and the hint now covers the view
+    torch.cuda.synchronize()
+    assert C_.reserve_overflow_events() == events0 + 1
+    _, again = hip_forward(C_, bg, g, cam, H, W)
+    assert not again[0].truncated and torch.equal(again[1], fex[1])
+
+
+def test_num_rendered_is_lazy_and_queryable(C_):
+    W, H, P = 256, 160, 5000
+    cam = ss.make_camera(W, H, 200.0, 3)
+    g = ss.make_gaussians(P, cam, seed=50, degree_mode="all0", scale_mu=0.03)
+    bg = np.zeros(3, np.float32)
+    _, first = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    _, out = hip_forward(C_, bg, g, cam, H, W)
+    nr = out[0]
+    assert nr.ticket > 0
+    torch.cuda.synchronize()
+    assert nr.ready() and int(nr) == int(first[0]) and f"{nr}" == str(int(first[0]))
+    assert list(range(10))[:nr] == list(range(10))[:int(nr)]            # usable as an index
