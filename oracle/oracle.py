@@ -165,6 +165,33 @@ def backward(st, dL_dout_color, lambda_sh_sparsity=0.0):
                 dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale, dL_drotations=drot, dL_dconic=dconic)
 
 
+def sh_backward(means3D, sh, degrees, campos, clamped, dL_dcolor):
+    """The SH part of the per-Gaussian backward alone (backward.cu:20-172 computeColorFromSH as restated in
+    orc_preprocess_bwd): dL/dsh [P,M,3] and the view-direction part of dL/dmeans [P,3] for a given dL/dcolor, with every
+    other upstream gradient zero and a dummy, well-conditioned camera (points ~10 units in front)."""
+    L = lib()
+    means3D, sh, campos, dcolor = _f32(means3D), _f32(sh), _f32(campos), _f32(dL_dcolor)
+    degrees = _i32(degrees)
+    P, M = sh.shape[0], sh.shape[1]
+    clamped = np.ascontiguousarray(clamped, dtype=np.uint8)
+    vm = np.eye(4, dtype=np.float32)
+    vm[3, 2] = 10.0
+    pm = vm.copy()
+    radii = np.ones(P, np.int32)
+    scales = np.full((P, 3), 0.01, np.float32)
+    rots = np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1))
+    cov = np.tile(np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32), (P, 1))
+    conic_op = np.tile(np.array([1, 0, 1, 0.5], np.float32), (P, 1))
+    z3, z4, z1 = np.zeros((P, 3), np.float32), np.zeros((P, 4), np.float32), np.zeros((P, 1), np.float32)
+    dmean3D, dcov3D = np.zeros((P, 3), np.float32), np.zeros((P, 6), np.float32)
+    dsh, dscale, drot = np.zeros((P, M, 3), np.float32), np.zeros((P, 3), np.float32), np.zeros((P, 4), np.float32)
+    L.orc_preprocess_bwd(C.c_int(P), C.c_int(M), _p(degrees), _p(means3D), _p(radii), _p(sh), _p(clamped), _p(scales),
+                         _p(rots), C.c_float(1.0), _p(cov), _p(vm), _p(pm), _p(campos), C.c_int(64), C.c_int(64),
+                         C.c_float(1.0), C.c_float(1.0), _p(z3), _p(conic_op), _p(z4), _p(dmean3D), _p(dcolor),
+                         _p(dcov3D), _p(dsh), _p(dscale), _p(drot), _p(z1), C.c_float(0.0))
+    return dsh, dmean3D
+
+
 def mark_visible(means3D, viewmatrix):
     L = lib()
     means3D = _f32(means3D)

@@ -21,9 +21,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libr3dgs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
-          "-Wno-unused-function", "-I", CSRC]
+          "-Wno-unused-function", "-I", CSRC] + (
+    # the first kernel arguments (the pointer into the pass block) arrive in SGPRs instead of through a load
+    [] if os.environ.get("R3DGS_NO_KERNARG_PRELOAD") else ["-mllvm", "-amdgpu-kernarg-preload-count=8"])
 EXACT = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
-UNITS = {
+UNITS = {  # depth_sort.h roles are instantiated in preprocess.hip (fused with the colour stream)
     "preprocess.hip": EXACT,
     "preprocess_bwd.hip": EXACT,
     "binning.hip": [],
@@ -34,7 +36,7 @@ UNITS = {
     "blend.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
     "capi.hip": [],
 }
-HEADERS = ["common.h", "gauss_math.h", "blend_math.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h"),
+HEADERS = ["common.h", "gauss_math.h", "blend_math.h", "depth_sort.h", os.path.join("..", "..", "include", "r3dgs_rasterizer.h"),
            os.path.join("..", "..", "include", "r3dgs_reduction.h")]
 
 

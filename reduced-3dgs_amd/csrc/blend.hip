@@ -150,7 +150,7 @@ template <int PPL, bool COUNTERS>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __restrict__ ap)
 {
     __shared__ LdsRec s_rec[kChunk];
-    const BlendFwdArgs& a = *ap;   // pass block in device memory (scalar loads)
+    const BlendFwdArgs a = *ap;   // pass block in device memory: scalar loads, once
     __shared__ uint32_t s_id[kChunk];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -168,8 +168,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     for (int q = 0; q < PPL; q++) {
         int px, py;
         pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
-        qx0[q] = (float)(px - (lane & 7));  // first pixel column / row of quadrant q (wave-uniform)
-        qy0[q] = (float)(py - (lane >> 3));
+        const int b4 = part * PPL + q;
+        qx0[q] = (float)(tile_x * kTile + (b4 & 1) * 8);   // first pixel column / row of quadrant q: wave-uniform,
+        qy0[q] = (float)(tile_y * kTile + (b4 >> 1) * 8);  // computed from scalars so that it stays in SGPRs
         pxf[q] = (float)px;
         pyf[q] = (float)py;
         inside[q] = px < a.W && py < a.H;
@@ -290,12 +291,12 @@ void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
-// 5 waves per SIMD for the 4-pixel-per-lane variant: 100 -> 96 VGPRs, no spills
-template <int PPL>
-__global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
+// OCC waves per SIMD: 5 (96 VGPRs) by default; 6 (80 VGPRs, a few spills outside the entry loop) is R3DGS_BWD_OCC=6
+template <int PPL, int OCC = 5>
+__global__ __launch_bounds__(64, OCC) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
 {
     __shared__ LdsRec s_rec[kChunk];
-    const BlendBwdArgs& a = *ap;
+    const BlendBwdArgs a = *ap;
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -314,8 +315,9 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(const B
     for (int q = 0; q < PPL; q++) {
         int px, py;
         pixel_of<PPL>(tile_x, tile_y, part, q, lane, &px, &py);
-        qx0[q] = (float)(px - (lane & 7));
-        qy0[q] = (float)(py - (lane >> 3));
+        const int b4 = part * PPL + q;
+        qx0[q] = (float)(tile_x * kTile + (b4 & 1) * 8);
+        qy0[q] = (float)(tile_y * kTile + (b4 >> 1) * 8);
         pxf[q] = (float)px;
         pyf[q] = (float)py;
         const bool inside = px < a.W && py < a.H;
@@ -419,13 +421,13 @@ __global__ __launch_bounds__(64, PPL == 4 ? 5 : 1) void blend_bwd_kernel(const B
 void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s)
 {
     if (!p.has_pairs) return;
-    const uint32_t nblocks = (uint32_t)(p.gx * p.gy * (4 / p.bwd_ppl));   // == a->nblocks
-    if (p.bwd_ppl == 4)
-        hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, a);
-    else if (p.bwd_ppl == 2)
-        hipLaunchKernelGGL((blend_bwd_kernel<2>), dim3(nblocks), dim3(64), 0, s, a);
+    // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
+    const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == a->nblocks
+    static const int occ = env_int("R3DGS_BWD_OCC", 5, 5, 6);
+    if (occ == 6)
+        hipLaunchKernelGGL((blend_bwd_kernel<4, 6>), dim3(nblocks), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((blend_bwd_kernel<1>), dim3(nblocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((blend_bwd_kernel<4, 5>), dim3(nblocks), dim3(64), 0, s, a);
 }
 
 }  // namespace r3

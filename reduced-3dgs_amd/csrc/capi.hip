@@ -45,6 +45,11 @@ int env_int(const char* env, int dflt, int lo, int hi)
     const int p = atoi(v);
     return (p >= lo && p <= hi) ? p : dflt;
 }
+int depth_bucket_load()
+{
+    static const int load = env_int("R3DGS_DEPTH_BUCKET_LOAD", 256, 32, 2048);
+    return load;
+}
 }  // namespace r3
 
 namespace {
@@ -344,11 +349,13 @@ void issue_forward(const FwdPlan& p, const FwdPassArgs* d, hipStream_t s, int ph
         if (p.generic_depth_sort)
             run_generic_depth_sort(p.P, *g_host, s);
         else
-            issue_depth_bucket_sort(p, &d->depth, s);
+            issue_depth_sort_and_color(p, d, s);   // the SH -> RGB stream rides in spare workgroups of these kernels
         h.end(kDepthSort, "depth sort + scan", s);
-        h.begin(kColor, s);
-        issue_preprocess_color(p, &d->pre, s);
-        h.end(kColor, "SH colours", s);
+        if (p.generic_depth_sort) {
+            h.begin(kColor, s);
+            issue_preprocess_color(p, &d->pre, s);
+            h.end(kColor, "SH colours", s);
+        }
         h.begin(kBinning, s);
         issue_tile_binning(p, d, s);
         h.end(kBinning, "tile binning", s);
@@ -481,6 +488,12 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     p.counters = c.calculate_mean_transmittance ? 1 : 0;
     p.fwd_ppl = ppl0 == 3 ? 2 : ppl0;
     p.color_grid = color_grid;
+    static const int fuse = env_int("R3DGS_COLOR_FUSE", 1, 0, 1);
+    static const int split0 = env_int("R3DGS_COLOR_SPLIT0", 20, 0, 100), split1 = env_int("R3DGS_COLOR_SPLIT1", 35, 0, 100);
+    p.color_fuse = fuse;
+    p.color_split[0] = split0;
+    p.color_split[1] = split0 + split1 > 100 ? 100 - split0 : split1;
+    p.color_split[2] = 100 - p.color_split[0] - p.color_split[1];
     p.generic_depth_sort = (generic_env || c.P >= (1 << 24)) ? 1 : 0;   // the bucket histogram packs the count in 24 bits
     return p;
 }
@@ -613,7 +626,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
 {
     return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
-           ((uint32_t)p.layout.wide << 5) | ((uint32_t)(c.colors_precomp != nullptr) << 6);
+           ((uint32_t)p.layout.wide << 5) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7);
 }
 
 int current_device()
@@ -994,7 +1007,6 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
             throw Error("a gradient output pointer is NULL");
         if (shs && (!dL_dsh || !D || M < 1 || M > 16)) throw Error("SH gradients need dL_dsh, degrees and 1 <= M <= 16");
-        static const int ppl0 = env_int("R3DGS_BWD_PPL", 4, 1, 4);
         BwdPlan plan;
         plan.P = P;
         plan.M = M;
@@ -1003,7 +1015,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         plan.gx = (width + kTile - 1) / kTile;
         plan.gy = (height + kTile - 1) / kTile;
         plan.layout = pair_layout(P, (size_t)plan.gx * plan.gy);
-        plan.bwd_ppl = ppl0 == 3 ? 4 : ppl0;
+        plan.bwd_ppl = 4;   // one wave per tile: the per-pair gradient slab has ONE owner per (tile, Gaussian)
         // R: the pair capacity the forward carved the binning blob with (num_rendered of an exact-size forward, the
         // reservation of a reserved one); the pair count itself is read from the device header
         plan.reserve = R > 0 ? (uint32_t)R : 1u;

@@ -76,10 +76,12 @@ constexpr int kMinDepthBuckets = 1024;
 constexpr int kMaxDepthBuckets = 8192;
 constexpr int kBucketCap = 4096;     // (key, id) pairs one workgroup sorts in LDS (32 KB)
 constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
+int depth_bucket_load();   // mean Gaussians per bucket aimed for (R3DGS_DEPTH_BUCKET_LOAD, default 256); capi.hip
 inline int depth_bucket_count(size_t P)
 {
     int nb = kMinDepthBuckets;
-    while (nb < kMaxDepthBuckets && P / (size_t)nb > 512) nb <<= 1;
+    const size_t load = (size_t)depth_bucket_load();
+    while (nb < kMaxDepthBuckets && P / (size_t)nb > load) nb <<= 1;
     return nb;
 }
 struct DepthSortScratch {
@@ -491,7 +493,9 @@ struct FwdPlan {
     int nb;                // depth buckets
     int ragged, counters;  // ragged SH addressing; counter mode (calculate_mean_transmittance)
     int fwd_ppl;           // pixels per lane of the forward blend
-    int color_grid;        // persistent-grid size of the SH -> RGB kernel
+    int color_grid;        // workgroups of the SH -> RGB stream (per launch that carries it)
+    int color_fuse;        // 1: the colour chunks ride in spare workgroups of the depth-sort kernels
+    int color_split[3];    // percent of the colour chunks in the histogram / scatter / bucket-sort launches
     int generic_depth_sort;  // rocPRIM sort + scan instead of the bucketed sort (never inside a graph)
 };
 struct BwdPlan {
@@ -511,8 +515,8 @@ void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
 void issue_header_reduce(const HeaderArgs* a, hipStream_t s);
-void prepare_depth_bucket_sort(int nb);   // one-time LDS opt-in of the large-bucket-count kernels (not a stream op)
-void issue_depth_bucket_sort(const FwdPlan& p, const DepthArgs* a, hipStream_t s);
+void prepare_depth_bucket_sort(int nb);   // one-time LDS opt-in of the depth-sort kernels (not a stream op)
+void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);   // preprocess.hip
 void run_generic_depth_sort(int P, GeomState& g, hipStream_t s);   // rocPRIM, host pointers: direct issue only
 void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);
 const char* sorted_words(const BinState& b, const PairLayout& l);   // which blob buffer holds the sorted words

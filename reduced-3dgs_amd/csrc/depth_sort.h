@@ -1,0 +1,381 @@
+// depth_sort.h -- the bucketed depth sort of the P Gaussians (+ the fused inclusive scan of tiles_touched), written
+// as workgroup ROLES so that the kernels that run them can carry a second, independent role in their spare
+// workgroups (preprocess.hip fuses the SH -> RGB stream into them: the sort kernels are latency-bound and leave most
+// of the chip idle, the colour kernel is bandwidth-bound, and a graph with a side branch costs the host as much as
+// twenty direct launches).
+//
+// Replaces, together with binning.hip, rasterizer_impl.cu:441 (InclusiveSum) and the depth half of the 64-bit
+// (tile|depth) key sort of rasterizer_impl.cu:465-473 of
+// /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer.
+//
+// A generic device sort is launch-latency bound at this size (rocPRIM: block sort + 9 merge passes, ~125 us for 500k
+// keys).  The keys are view depths whose range the preprocess kernel already knows, so:
+//   (1) every workgroup histograms its 4096 Gaussians over nb monotone buckets of [min depth, max depth] and stores its
+//       row -- no global atomics: device-scope atomics on the same few lines were the cost of the first version;
+//   (2) a column-wise scan of the rows (each workgroup's first slot inside each bucket) and the bucket totals;
+//   (3) (key, id) scatter into the bucket regions -- slot = bucket start (scan of the totals, redone per workgroup
+//       in LDS) + row base + LDS rank, again no global atomics;
+//   (4) one workgroup per bucket sorts its pairs in LDS as 64-bit (key << 32 | id) words and scans tiles_touched in
+//       that order on top of the bucket's base.
+// The bucket function is monotone in the key, so concatenating the sorted buckets is the stable sort by depth bits
+// the reference's 64-bit key sort implies.  Buckets are equal-width in the key's BIT PATTERN (positive floats order
+// like their bits), i.e. roughly logarithmic in depth: an unbounded scene with its content at 2..8 units and a
+// background out to 100 puts ~a quarter of the buckets under the content instead of 6% of them.  nb grows with P
+// (mean load <= 512).  A bucket that still exceeds the LDS capacity (a fronto-parallel plane of splats) is sorted by
+// its workgroup with a radix sort in global memory -- correct, slow, and flagged in the header / PassInfo so that
+// the host can route later passes of such a view through the generic sort.
+#pragma once
+#include "common.h"
+
+namespace r3 {
+
+// Inclusive scan across a 256-thread workgroup: shuffles inside each wave, one LDS exchange of the four wave totals
+// (two barriers instead of the sixteen of a Hillis-Steele pass in LDS).  s_w: 4 words of LDS.
+template <class T>
+__device__ inline T block256_inclusive_scan(T v, T* s_w)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const T up = __shfl_up(v, off);
+        if (lane >= off) v += up;
+    }
+    __syncthreads();   // s_w may still be read from a previous use
+    if (lane == 63) s_w[w] = v;
+    __syncthreads();
+    T add = 0;
+    for (int k = 0; k < w; k++) add += s_w[k];
+    return v + add;
+}
+
+// Stable partition of one wave's 64 digits: lanes holding the same digit as this lane (including itself).
+template <int BITS>
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+constexpr int kHistPerThread = kHistPerBlock / 256;
+constexpr int kCountBits = 24;
+constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
+constexpr int kMaxBucketsPerThread = (kMaxDepthBuckets + 1 + 255) / 256;
+
+struct DepthRange {
+    uint32_t kmin;
+    float scale;
+    int nb;
+};
+__device__ inline DepthRange make_depth_range(uint32_t mx, uint32_t mi, int nb)
+{
+    DepthRange r;
+    const uint32_t kmax = mx, kmin = ~mi;
+    r.kmin = kmin;
+    r.nb = nb;
+    r.scale = kmax >= kmin ? (float)nb / ((float)(kmax - kmin) + 1.0f) : 0.0f;   // no visible Gaussian: nothing is looked up
+    return r;
+}
+// Monotone in key (conversion, multiplication by a positive constant and truncation all are), which is all the sort
+// needs; fp32 rounding only moves bucket boundaries.
+__device__ inline int depth_bucket(uint32_t key, const DepthRange& r)
+{
+    if (key == 0xFFFFFFFFu) return r.nb;   // culled
+    const int b = (int)((float)(key - r.kmin) * r.scale);
+    return min(max(b, 0), r.nb - 1);
+}
+
+// LDS bytes of each role (the kernels size their dynamic LDS as the maximum over the roles they carry)
+inline size_t depth_hist_lds(int nb) { return (size_t)(nb + 1) * sizeof(unsigned long long); }
+inline size_t depth_scatter_lds(int nb) { return (size_t)3 * (nb + 2) * sizeof(uint32_t) + 256 * sizeof(unsigned long long); }
+constexpr size_t kBucketSortLds = (size_t)kBucketCap * 8 + 256 * 4 + (256 + 256 + 4 * 256 + 4) * 4;
+
+// (1) workgroup `wg` of depth_hist_rows(P): histogram of its 4096 Gaussians
+__device__ inline void depth_hist_role(const DepthArgs& a, char* smem, int wg)
+{
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);   // [nb + 1]
+    const int P = a.P, nb = a.nb;
+    for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;
+    const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
+    const int base = wg * kHistPerBlock;
+    uint32_t kv[kHistPerThread], tv[kHistPerThread];
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++) {   // all loads in flight before the first LDS atomic
+        const int i = base + k * 256 + threadIdx.x;
+        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
+        tv[k] = i < P ? a.tiles[i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++)
+        if (base + k * 256 + (int)threadIdx.x < P)
+            atomicAdd(&hist[depth_bucket(kv[k], rng)], ((unsigned long long)tv[k] << kCountBits) | 1ull);
+    __syncthreads();
+    unsigned long long* row = a.hist_rows + (size_t)wg * (nb + 1);
+    for (int b = threadIdx.x; b <= nb; b += 256) row[b] = hist[b];
+}
+
+// (2) 64 columns per workgroup of 1024 threads, a contiguous band of rows per wave: per column the exclusive prefix
+// of the counts down the rows (each histogram workgroup's first slot inside the bucket) and the column total.
+constexpr int kColWaves = 16;
+__device__ inline void depth_colscan_role(const DepthArgs& a, int wg)
+{
+    __shared__ unsigned long long s_part[kColWaves][64];
+    __shared__ uint32_t s_over;
+    const int n_rows = a.rows, nb = a.nb;
+    const unsigned long long* __restrict__ rows = a.hist_rows;
+    uint32_t* __restrict__ row_base = a.hist_base;
+    if (threadIdx.x == 0) s_over = 0u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = wg * 64 + lane;
+    const bool live = c <= nb;
+    const int kStride = nb + 1;
+    const int band = (n_rows + kColWaves - 1) / kColWaves;
+    const int r_lo = min(n_rows, w * band), r_hi = min(n_rows, r_lo + band);
+    unsigned long long mine = 0;
+    if (live) {
+#pragma unroll 8
+        for (int r = r_lo; r < r_hi; r++) mine += rows[(size_t)r * kStride + c];
+    }
+    s_part[w][lane] = mine;
+    __syncthreads();
+    unsigned long long acc = 0, total = 0;
+    if (live) {
+        for (int k = 0; k < kColWaves; k++) {
+            if (k < w) acc += s_part[k][lane];
+            total += s_part[k][lane];
+        }
+#pragma unroll 8
+        for (int r = r_lo; r < r_hi; r++) {
+            const unsigned long long v = rows[(size_t)r * kStride + c];
+            row_base[(size_t)r * kStride + c] = (uint32_t)(acc & kCountMask);
+            acc += v;
+        }
+        if (w == 0) {
+            a.ds->total[c] = total;
+            if (c < nb && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) s_over = 1u;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_over) {   // both were zeroed by header_reduce_kernel earlier in this pass
+        a.hdr->sort_overflow = 1u;
+        if (a.info) a.info->sort_overflow = 1u;
+    }
+}
+
+// Exclusive scan of the nb + 1 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
+// by a 256-thread workgroup into LDS.
+__device__ inline void scan_bucket_totals(const DepthSortScratch* ds, int nb, uint32_t* s_start, uint32_t* s_tile,
+                                          unsigned long long* s_tmp)
+{
+    const int per = (nb + 1 + 255) / 256;
+    unsigned long long c[kMaxBucketsPerThread], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBucketsPerThread; k++) {
+        const int b = threadIdx.x * per + k;
+        c[k] = (k < per && b <= nb) ? ds->total[b] : 0ull;
+        sum += c[k];
+    }
+    unsigned long long run = block256_inclusive_scan(sum, s_tmp) - sum;
+#pragma unroll
+    for (int k = 0; k < kMaxBucketsPerThread; k++) {
+        const int b = threadIdx.x * per + k;
+        if (k < per && b <= nb + 1) {
+            s_start[b] = (uint32_t)(run & kCountMask);
+            s_tile[b] = (uint32_t)(run >> kCountBits);
+        }
+        run += c[k];
+    }
+    __syncthreads();
+}
+
+// (3) (key, id) into the bucket regions; the culled Gaussians go straight to their final place.
+__device__ inline void depth_scatter_role(const DepthArgs& a, char* smem, int wg)
+{
+    const int P = a.P, nb = a.nb;
+    unsigned long long* s_tmp = reinterpret_cast<unsigned long long*>(smem);   // [256]
+    uint32_t* slot0 = reinterpret_cast<uint32_t*>(smem + 256 * sizeof(unsigned long long));   // bucket starts, then this
+    uint32_t* s_tile = slot0 + (nb + 2);                                       // workgroup's first slot of each bucket
+    uint32_t* rank = slot0 + 2 * (nb + 2);
+    DepthSortScratch* ds = a.ds;
+    scan_bucket_totals(ds, nb, slot0, s_tile, s_tmp);
+    if (wg == 0)   // published for the per-bucket sort kernel
+        for (int b = threadIdx.x; b <= nb + 1; b += 256) {
+            ds->start[b] = slot0[b];
+            ds->tile_base[b] = s_tile[b];
+        }
+    const uint32_t R = s_tile[nb];   // culled Gaussians add no tiles: their scan value is the total
+    __syncthreads();
+    const uint32_t* mybase = a.hist_base + (size_t)wg * (nb + 1);
+    for (int b = threadIdx.x; b <= nb; b += 256) {
+        slot0[b] += mybase[b];
+        rank[b] = 0;
+    }
+    const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
+    const int base = wg * kHistPerBlock;
+    uint32_t kv[kHistPerThread];
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++) {
+        const int i = base + k * 256 + threadIdx.x;
+        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kHistPerThread; k++) {
+        const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
+        if ((int)id < P) {
+            const int b = depth_bucket(kv[k], rng);
+            const uint32_t slot = slot0[b] + atomicAdd(&rank[b], 1u);   // any order: the bucket is sorted next
+            if (b == nb) {
+                a.order[slot] = id;
+                a.offsets[slot] = R;
+            } else {
+                a.key_sorted[slot] = kv[k];
+                a.bucket_id[slot] = id;
+            }
+        }
+    }
+}
+
+// Slow path of the bucket sort: n (key, id) pairs in global memory, sorted by (key, id) by ONE 256-thread workgroup
+// with a stable LSD radix sort (8-bit digits; digits on which all pairs agree are skipped -- a bucket's keys share
+// their high bits).  Ping-pongs between (k0, v0) and (k1, v1); returns 0 / 1 = which pair of arrays holds the result.
+// lds: 256 + 256 + 4 * 256 + 4 words.
+__device__ inline int block_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, uint32_t* lds)
+{
+    uint32_t* s_hist = lds;
+    uint32_t* s_base = lds + 256;
+    uint32_t(*s_wc)[256] = reinterpret_cast<uint32_t(*)[256]>(lds + 512);
+    uint32_t* s_skip = lds + 512 + 4 * 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int cur = 0;
+    for (int pass = 0; pass < 7; pass++) {   // id bytes 0..2 (P < 2^24), then key bytes 0..3
+        const uint32_t* kin = cur ? k1 : k0;
+        const uint32_t* vin = cur ? v1 : v0;
+        uint32_t* kout = cur ? k0 : k1;
+        uint32_t* vout = cur ? v0 : v1;
+        const bool on_id = pass < 3;
+        const int shift = on_id ? 8 * pass : 8 * (pass - 3);
+        s_hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) *s_skip = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            atomicAdd(&s_hist[((on_id ? vin[i] : kin[i]) >> shift) & 255u], 1u);
+        __syncthreads();
+        const uint32_t cnt = s_hist[threadIdx.x];
+        if (cnt == n) *s_skip = 1;   // every pair has this digit: the pass would not move anything
+        const uint32_t incl = block256_inclusive_scan(cnt, s_base);   // s_base doubles as the scan's 4-word scratch
+        __syncthreads();
+        const bool skip = *s_skip != 0;
+        __syncthreads();
+        s_base[threadIdx.x] = incl - cnt;
+        __syncthreads();
+        if (skip) continue;
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {   // chunks in order: stability
+            const uint32_t i = c0 + threadIdx.x;
+            const bool valid = i < n;
+            const uint32_t kk = valid ? kin[i] : 0u, vv = valid ? vin[i] : 0u;
+            const uint32_t d = ((on_id ? vv : kk) >> shift) & 255u;
+            for (int t = threadIdx.x; t < 4 * 256; t += 256) (&s_wc[0][0])[t] = 0;
+            __syncthreads();
+            const unsigned long long peers = match_digit<8>(d, valid);
+            if (valid && (peers & below) == 0ull) s_wc[w][d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t pos = s_base[d] + (uint32_t)__popcll(peers & below);
+                for (int k = 0; k < w; k++) pos += s_wc[k][d];
+                kout[pos] = kk;
+                vout[pos] = vv;
+            }
+            __syncthreads();
+            s_base[threadIdx.x] += s_wc[0][threadIdx.x] + s_wc[1][threadIdx.x] + s_wc[2][threadIdx.x] + s_wc[3][threadIdx.x];
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// (4) workgroup b of nb: sort the (key << 32 | id) words of bucket b in LDS, then the inclusive scan of tiles_touched
+// in that order on top of the bucket's base (rasterizer_impl.cu:441 InclusiveSum, fused).
+__device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, int b)
+{
+    unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);                     // [kBucketCap]
+    uint32_t* s_sum = reinterpret_cast<uint32_t*>(smem + (size_t)kBucketCap * 8);            // [256]
+    uint32_t* s_radix = s_sum + 256;                                                          // slow path scratch
+    const DepthSortScratch* __restrict__ ds = a.ds;
+    const uint32_t* __restrict__ tiles = a.tiles;
+    uint32_t* __restrict__ order = a.order;
+    uint32_t* __restrict__ offsets = a.offsets;
+    const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
+    if (n == 0) return;
+    if (n > (uint32_t)kBucketCap) {
+        // the bucket does not fit the LDS sort: radix sort in global memory, then the scan in strides of 256
+        const int cur = block_radix_sort_pairs(a.key_sorted + start, a.bucket_id + start, a.ovf_key + start,
+                                               a.ovf_id + start, n, s_radix);
+        const uint32_t* ids = (cur ? a.ovf_id : a.bucket_id) + start;
+        uint32_t run = ds->tile_base[b];
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+            const uint32_t r = c0 + threadIdx.x;
+            const uint32_t id = r < n ? ids[r] : 0u;
+            const uint32_t t = r < n ? tiles[id] : 0u;
+            const uint32_t incl = block256_inclusive_scan(t, s_sum);
+            if (r < n) {
+                order[start + r] = id;
+                offsets[start + r] = run + incl;
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) s_sum[4] = incl;
+            __syncthreads();
+            run += s_sum[4];
+        }
+        return;
+    }
+    const uint32_t* __restrict__ in_key = a.key_sorted;
+    const uint32_t* __restrict__ in_id = a.bucket_id;
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t r = threadIdx.x; r < N; r += 256)
+        s[r] = r < n ? ((unsigned long long)in_key[start + r] << 32) | in_id[start + r] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;   // lo has bit j clear
+                const unsigned long long x = s[lo], y = s[hi];
+                const bool up = (lo & k) == 0;
+                if ((x > y) == up) {
+                    s[lo] = y;
+                    s[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    // scan: each thread owns `per` consecutive sorted entries
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t r0 = threadIdx.x * per;
+    uint32_t tl[kBucketCap / 256], mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t r = r0 + k;
+        tl[k] = r < n ? tiles[(uint32_t)s[r]] : 0u;
+        mine += tl[k];
+    }
+    uint32_t run = ds->tile_base[b] + block256_inclusive_scan(mine, s_sum) - mine;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t r = r0 + k;
+        if (r < n) {
+            run += tl[k];
+            order[start + r] = (uint32_t)s[r];
+            offsets[start + r] = run;
+        }
+    }
+}
+
+}  // namespace r3

@@ -13,8 +13,9 @@
 // the tile rect, the depth sort key and tiles_touched.
 // Built with -ffp-contract=off: radii / rects / tiles_touched are bit-exact against the oracle.
 #include <cstdlib>
+#include <mutex>
 
-#include "common.h"
+#include "depth_sort.h"
 
 namespace r3 {
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const i
 // stream underneath the (launch-latency-bound) sort.
 __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(const PreArgs* __restrict__ ap)
 {
-    const PreArgs& a = *ap;   // pass block in device memory: wave-uniform (scalar) loads of the fields used
+    const PreArgs a = *ap;   // pass block in device memory: wave-uniform (scalar) loads of the fields used, once
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P;
     const int i = blockIdx.x * kPreBlock + tid;
@@ -140,15 +141,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(const PreArg
 // Launched as a SMALL persistent grid (launch_preprocess_color): the kernel is bandwidth-bound filler next to the
 // latency-bound depth-sort kernels of the main stream, and a full grid's LDS footprint (3 x 49 KB per CU) left their
 // workgroups no room -- the depth scatter kernel took 46 us instead of 14 us beside it.
+constexpr size_t kColorLds = sizeof(float) * (kPreBlock / 64) * kWaveShFloats;
+
+// chunks [first + wg, last) in steps of n_wg, 256 Gaussians each; smem: kColorLds bytes
 template <bool RAGGED>
-__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(const PreArgs* __restrict__ ap)
+__device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int first, int last, int wg, int n_wg)
 {
-    __shared__ float s_sh[kPreBlock / 64][kWaveShFloats];
-    const PreArgs& a = *ap;
-    const int n_blocks = a.color_blocks;
+    float(*s_sh)[kWaveShFloats] = reinterpret_cast<float(*)[kWaveShFloats]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
-  for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+  for (int blk = first + wg; blk < last; blk += n_wg) {
     const int i = blk * kPreBlock + tid;
     const bool valid = i < P;
     const int wave_first = blk * kPreBlock + wave * 64;
@@ -239,6 +241,44 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(const PreAr
   }
 }
 
+// standalone colour kernel (generic depth sort path, R3DGS_COLOR_FUSE=0): small persistent grid
+template <bool RAGGED>
+__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(const PreArgs* __restrict__ ap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PreArgs a = *ap;
+    color_role<RAGGED>(a, smem, 0, a.color_blocks, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- depth-sort kernels carrying a share of the colour stream in extra workgroups -------------------------------
+// Workgroups [0, n_sort) run the depth-sort role, workgroups [n_sort, n_sort + n_color) the colour chunks
+// [c0, c1).  One dynamic LDS window serves whichever role a workgroup has.
+template <int STEP, bool RAGGED>
+__global__ __launch_bounds__(kPreBlock) void depth_sort_color_kernel(const FwdPassArgs* __restrict__ pa, int n_sort,
+                                                                     int c0, int c1)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wg = (int)blockIdx.x;
+    if (wg < n_sort) {
+        const DepthArgs d = pa->depth;
+        if (STEP == 0)
+            depth_hist_role(d, smem, wg);
+        else if (STEP == 1)
+            depth_scatter_role(d, smem, wg);
+        else
+            depth_bucket_sort_role(d, smem, wg);
+    } else {
+        const PreArgs a = pa->pre;
+        color_role<RAGGED>(a, smem, c0, c1, wg - n_sort, (int)gridDim.x - n_sort);
+    }
+}
+
+__global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(const DepthArgs* __restrict__ ap)
+{
+    const DepthArgs d = *ap;
+    depth_colscan_role(d, (int)blockIdx.x);
+}
+
 void issue_preprocess_geom(const FwdPlan& p, const PreArgs* a, hipStream_t s)
 {
     const int blocks = (p.P + kPreBlock - 1) / kPreBlock;
@@ -250,9 +290,84 @@ void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s)
     const int blocks = (p.P + kPreBlock - 1) / kPreBlock;   // == a->color_blocks
     const int grid = p.color_grid > 0 && blocks > p.color_grid ? p.color_grid : blocks;
     if (p.ragged)
-        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), kColorLds, s, a);
     else
-        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), 0, s, a);
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), kColorLds, s, a);
+}
+
+template <int STEP, bool RAGGED>
+static void launch_sort_color(const FwdPassArgs* pa, int n_sort, int n_color, int c0, int c1, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL((depth_sort_color_kernel<STEP, RAGGED>), dim3(n_sort + n_color), dim3(kPreBlock), lds, s, pa,
+                       n_sort, c0, c1);
+}
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+template <int STEP, bool RAGGED>
+static void opt_in_lds(size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depth_sort_color_kernel<STEP, RAGGED>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+// Not a stream operation: called before a chain is captured / issued, once per bucket count.
+void prepare_depth_bucket_sort(int nb)
+{
+    static std::mutex mu;
+    static int prepared_nb = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (nb <= prepared_nb) return;
+    const size_t h = max_sz(depth_hist_lds(nb), kColorLds), sc = max_sz(depth_scatter_lds(nb), kColorLds),
+                 bs = max_sz(kBucketSortLds, kColorLds);
+    opt_in_lds<0, false>(h);
+    opt_in_lds<0, true>(h);
+    opt_in_lds<1, false>(sc);
+    opt_in_lds<1, true>(sc);
+    opt_in_lds<2, false>(bs);
+    opt_in_lds<2, true>(bs);
+    if (kColorLds > 48 * 1024) {
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
+    }
+    prepared_nb = nb;
+}
+
+// Bucketed depth sort with the SH -> RGB stream riding in spare workgroups of three of its four kernels.  The colour
+// chunks are split p.color_split[0..2] percent over the histogram / scatter / bucket-sort launches (each share about
+// as long as the sort role it hides behind); with fusion off (p.color_fuse == 0) the colour kernel runs on its own
+// after the sort.
+void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* pa, hipStream_t s)
+{
+    const int rows = (int)depth_hist_rows((size_t)p.P), nb = p.nb;
+    const int chunks = (p.P + kPreBlock - 1) / kPreBlock;
+    int c[4] = {0, 0, 0, chunks};
+    if (p.color_fuse) {
+        c[1] = (int)((long long)chunks * p.color_split[0] / 100);
+        c[2] = c[1] + (int)((long long)chunks * p.color_split[1] / 100);
+    } else {
+        c[1] = c[2] = c[3] = 0;
+    }
+    const int cw = p.color_grid > 0 ? p.color_grid : 512;
+    auto n_color = [&](int k) { const int n = c[k + 1] - c[k]; return n < cw ? n : cw; };
+    const size_t lds0 = n_color(0) ? max_sz(depth_hist_lds(nb), kColorLds) : depth_hist_lds(nb);
+    const size_t lds1 = n_color(1) ? max_sz(depth_scatter_lds(nb), kColorLds) : depth_scatter_lds(nb);
+    const size_t lds2 = n_color(2) ? max_sz(kBucketSortLds, kColorLds) : kBucketSortLds;
+    if (p.ragged) {
+        launch_sort_color<0, true>(pa, rows, n_color(0), c[0], c[1], lds0, s);
+        hipLaunchKernelGGL(depth_colscan_kernel, dim3((nb + 1 + 63) / 64), dim3(64 * kColWaves), 0, s, &pa->depth);
+        launch_sort_color<1, true>(pa, rows, n_color(1), c[1], c[2], lds1, s);
+        launch_sort_color<2, true>(pa, nb, n_color(2), c[2], c[3], lds2, s);
+    } else {
+        launch_sort_color<0, false>(pa, rows, n_color(0), c[0], c[1], lds0, s);
+        hipLaunchKernelGGL(depth_colscan_kernel, dim3((nb + 1 + 63) / 64), dim3(64 * kColWaves), 0, s, &pa->depth);
+        launch_sort_color<1, false>(pa, rows, n_color(1), c[1], c[2], lds1, s);
+        launch_sort_color<2, false>(pa, nb, n_color(2), c[2], c[3], lds2, s);
+    }
+    if (!p.color_fuse) issue_preprocess_color(p, &pa->pre, s);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2

@@ -41,7 +41,7 @@ struct ShRowLdsRW {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* __restrict__ ap)
 {
-    const PairReduceArgs& a = *ap;
+    const PairReduceArgs a = *ap;
     const uint32_t R = a.hdr->num_pairs;
     if (blockIdx.x * 256u >= R) return;   // the grid covers the reservation, not the actual pair count
     const float* __restrict__ pair_grad = a.pair_grad;
@@ -111,7 +111,7 @@ void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
 __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
 {
     __shared__ float s_sh[kBwdBlock / 64][kBwdWaveShFloats];
-    const PreBwdArgs& a = *ap;
+    const PreBwdArgs a = *ap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
     const int i = blockIdx.x * kBwdBlock + tid;

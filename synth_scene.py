@@ -123,4 +123,15 @@ WORKLOADS = {
     "lego_like_300k_800": dict(P=300_000, W=800, H=800, f=600.0, degree_mode="all3"),
     "metric_500k_1600x1062": dict(P=500_000, W=1600, H=1062, f=1200.0, degree_mode="all3"),
     "garden_like_2M_1600x1062": dict(P=2_000_000, W=1600, H=1062, f=1200.0, degree_mode="mixed"),
+    # configs[3] / configs[4] stand-ins: smaller splats, as a densified scene has (R stays ~10 per Gaussian)
+    "bicycle_like_5M_1600x1062": dict(P=5_000_000, W=1600, H=1062, f=1200.0, degree_mode="mixed", scale_mu=0.008),
+    "train_like_6M_1920x1080": dict(P=6_000_000, W=1920, H=1080, f=1400.0, degree_mode="mixed", scale_mu=0.008),
 }
+
+
+def make_workload(name, seed=0):
+    """-> (workload dict, camera 0, gaussians) of a named workload."""
+    w = WORKLOADS[name]
+    cam = make_camera(w["W"], w["H"], w["f"], None)
+    g = make_gaussians(w["P"], cam, seed=seed, degree_mode=w["degree_mode"], scale_mu=w.get("scale_mu", 0.012))
+    return w, cam, g

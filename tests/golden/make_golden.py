@@ -14,6 +14,10 @@ Fixtures are data (inputs + expected outputs); no reference source travels.
                      render() path passes as cov3D_precomp when compute_cov3D_python is set            (reference Python)
  ref_pixel_size.npz: scene/__init__.py:103-141 find_minimum_projected_pixel_size_python -- the reference's own torch
                      version of the find_minimum_projected_pixel_size operator, run on CPU      (reference Python)
+ ref_sh_backward.npz: autograd through utils/sh_utils.py:57-112 eval_sh exactly as render() composes it
+                     (gaussian_renderer/__init__.py:74-81: direction = normalise(xyz - camera_center),
+                     clamp_min(eval_sh + 0.5, 0)) -- dL/dsh and the direction part of dL/dmeans for deg 0..3, i.e. the
+                     SH backward of backward.cu:20-172 incl. the clamp mask and the normalisation Jacobian  (reference Python)
  oracle_case_*.npz : outputs of the repo's own CPU oracle on small seeded scenes (regression
                      anchors + GPU parity targets that do not need a compiler on the GPU box)
 """
@@ -47,6 +51,33 @@ def ref_sh():
         shs_view = torch.tensor(sh[:, :K]).transpose(1, 2)  # [n,3,K] as gaussian_renderer/__init__.py:76
         out[f"rgb_deg{deg}"] = eval_sh(deg, shs_view, torch.tensor(d)).numpy()
     np.savez_compressed(os.path.join(HERE, "ref_sh_eval.npz"), sh=sh, dirs=d, **out)
+
+
+def ref_sh_backward():
+    from utils.sh_utils import eval_sh
+    rng = np.random.default_rng(23)
+    n = 301
+    sh = rng.normal(0, 0.4, (n, 16, 3)).astype(np.float32)
+    means = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    campos = np.array([0.3, -0.2, -4.0], np.float32)
+    dL_dcolor = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    out = {}
+    for deg in range(4):
+        K = (deg + 1) ** 2
+        sh_t = torch.tensor(sh[:, :K].copy(), requires_grad=True)
+        xyz = torch.tensor(means, requires_grad=True)
+        shs_view = sh_t.transpose(1, 2).view(-1, 3, K)                       # gaussian_renderer/__init__.py:76
+        dir_pp = xyz - torch.tensor(campos).repeat(n, 1)                       # :77
+        dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)          # :78
+        sh2rgb = eval_sh(deg, shs_view, dir_pp_normalized)                     # :79
+        colors = torch.clamp_min(sh2rgb + 0.5, 0.0)                            # :80
+        (colors * torch.tensor(dL_dcolor)).sum().backward()
+        out[f"dsh_deg{deg}"] = sh_t.grad.numpy()
+        out[f"dmeans_deg{deg}"] = xyz.grad.numpy() if xyz.grad is not None else np.zeros_like(means)  # deg 0: no direction
+        out[f"clamped_deg{deg}"] = (sh2rgb.detach().numpy() + 0.5 < 0)
+        out[f"margin_deg{deg}"] = np.abs(sh2rgb.detach().numpy() + 0.5)       # distance of each channel from the clamp
+    np.savez_compressed(os.path.join(HERE, "ref_sh_backward.npz"), sh=sh, means=means, campos=campos,
+                        dL_dcolor=dL_dcolor, **out)
 
 
 def ref_camera():
@@ -173,7 +204,11 @@ if __name__ == "__main__":
     if "--only-pixel-size" in sys.argv:
         ref_pixel_size()
         sys.exit(0)
+    if "--only-sh-backward" in sys.argv:
+        ref_sh_backward()
+        sys.exit(0)
     ref_sh()
+    ref_sh_backward()
     ref_cov3d()
     ref_pixel_size()
     ref_camera()

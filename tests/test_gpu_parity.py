@@ -347,14 +347,13 @@ def test_empty_and_all_culled(C_):
 # -------------------------------------------------------------------------------------------------
 # BASELINE.json metric shape: size-independent properties (the oracle needs minutes here)
 # -------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["metric_500k_1600x1062", "garden_like_2M_1600x1062"])
+@pytest.fixture(scope="module", params=["metric_500k_1600x1062", "garden_like_2M_1600x1062",
+                                        "bicycle_like_5M_1600x1062", "train_like_6M_1920x1080"])
 def metric_scene(request):
     """The bench workload, and the 2 M-Gaussian one: 21 depth-rank bits + 13 tile bits > 32, i.e. 64-bit pair words,
-    four times the depth-histogram rows and twice the depth buckets, 14.5 M pairs."""
-    w = ss.WORKLOADS[request.param]
-    cam = ss.make_camera(w["W"], w["H"], w["f"], None)
-    g = ss.make_gaussians(w["P"], cam, seed=0, degree_mode=w["degree_mode"])
-    return w, cam, g
+    four times the depth-histogram rows and more depth buckets, 14.5 M pairs.  The 5 M / 6 M ones stand in for
+    BASELINE.json configs[3] / configs[4] (bicycle, Tanks&Temples train at 1920x1080 = 8160 tiles)."""
+    return ss.make_workload(request.param)
 
 
 def test_full_size_properties(C_, metric_scene):
@@ -419,6 +418,22 @@ def test_full_size_properties(C_, metric_scene):
         assert torch.equal(b1[k], b1_again[k]), k
     inv = radii == 0
     assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())
+
+
+@pytest.mark.parametrize("name", ["metric_500k_1600x1062", "garden_like_2M_1600x1062"])
+def test_full_size_elementwise_vs_oracle(C_, name):
+    """The BASELINE.json metric shape (and the 2 M-Gaussian one) element-wise against the CPU oracle: the oracle needs
+    about a second per pass here on the GPU box's cores.  Same bars as the small cases."""
+    w, cam, g = ss.make_workload(name)
+    W, H, P = w["W"], w["H"], w["P"]
+    bg = np.zeros(3, np.float32)
+    dl = ss.upstream_grad(W, H, seed=1) * (W * H)
+    ref = oracle_forward(bg, g, cam, H, W)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    check_forward(C_, fout, ref, H, W, P)
+    gr = orc.backward(ref["state"], dl, 0.1)
+    bout = hip_backward(C_, fargs, fout, dl, 0.1)
+    check_backward(bout, gr, ref["state"], 16)
 
 
 def test_repeated_backward_and_pair_sort_path(C_):

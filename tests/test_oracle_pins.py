@@ -41,6 +41,25 @@ def test_sh_colour_matches_reference_eval_sh(golden_dir, deg):
     assert (clamped == ((z[f"rgb_deg{deg}"] + 0.5) < 0)[vis]).mean() > 0.995
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_backward_matches_autograd_through_reference_eval_sh(golden_dir, deg):
+    """oracle SH backward (backward.cu:20-172 restated: dL/dsh, and dL/dmeans through the normalised view direction,
+    auxiliary.h:107-117 dnormvdv) == torch autograd through the reference's own eval_sh composed as render() does
+    (gaussian_renderer/__init__.py:74-81), clamp mask included."""
+    z = _load(golden_dir, "ref_sh_backward.npz")
+    sh, means, campos, dcol = z["sh"], z["means"], z["campos"], z["dL_dcolor"]
+    n = sh.shape[0]
+    clamped = z[f"clamped_deg{deg}"]
+    dsh, dmeans = orc.sh_backward(means, sh, np.full((n, 1), deg, np.int32), campos, clamped, dcol)
+    K = (deg + 1) ** 2
+    np.testing.assert_allclose(dsh[:, :K], z[f"dsh_deg{deg}"], rtol=2e-5, atol=2e-6)
+    assert (dsh[:, K:] == 0).all()
+    scale = np.abs(z[f"dmeans_deg{deg}"]).max() + 1e-30
+    np.testing.assert_allclose(dmeans, z[f"dmeans_deg{deg}"], rtol=0, atol=2e-5 * max(scale, 1.0))
+    if deg == 0:
+        assert (dmeans == 0).all() and (z["dmeans_deg0"] == 0).all()   # degree 0 has no view dependence
+
+
 def test_camera_builders_match_reference(golden_dir):
     z = _load(golden_dir, "ref_camera.npz")
     for i in range(4):
