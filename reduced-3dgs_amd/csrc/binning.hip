@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
             const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
             const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
             const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)a.gx + (uint32_t)r.x + tx;
-            out[pos] = ((Word)tile << rank_bits) | (Word)(j_lo + lo);   // one word: tile | rank in depth order
-            if (sizeof(Word) == 8) a.pair_rank[pos] = j_lo + lo;
+            out[pos] = ((Word)tile << rank_bits) | (Word)s_id[lo];   // one word: tile | Gaussian id
+            if (sizeof(Word) == 8) a.pair_rank[pos] = s_id[lo];
             atomicAdd(&s_hist[tile & (uint32_t)(bins - 1)], 1u);
         }
     }
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __r
     }
 }
 
-// rasterizer_impl.cu:124-146 identifyTileRanges on the sorted words; the Gaussian ids (point_list[i] = order[rank])
-// are materialised here too.
+// rasterizer_impl.cu:124-146 identifyTileRanges on the sorted words; the Gaussian ids (the low bits of the words)
+// are split off into point_list here too.
 template <class Word>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __restrict__ ap)
 {
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __re
     {
         const Word mask = (((Word)1) << rank_bits) - 1;
         uint32_t id[4];
-        for (int k = 0; k < 4; k++) id[k] = k < n ? a.order[(uint32_t)(key[k] & mask)] : 0u;
+        for (int k = 0; k < 4; k++) id[k] = (uint32_t)(key[k] & mask);
         if (n == 4)
             *reinterpret_cast<uint4*>(point_list + i0) = make_uint4(id[0], id[1], id[2], id[3]);
         else

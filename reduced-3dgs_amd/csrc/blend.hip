@@ -291,9 +291,10 @@ void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
-// OCC waves per SIMD: 5 (96 VGPRs) by default; 6 (80 VGPRs, a few spills outside the entry loop) is R3DGS_BWD_OCC=6
-template <int PPL, int OCC = 5>
-__global__ __launch_bounds__(64, OCC) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
+// 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
+// (0.5174 vs 0.5170 ms): occupancy is not what limits this kernel.
+template <int PPL>
+__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
 {
     __shared__ LdsRec s_rec[kChunk];
     const BlendBwdArgs a = *ap;
@@ -407,12 +408,12 @@ __global__ __launch_bounds__(64, OCC) void blend_bwd_kernel(const BlendBwdArgs* 
             const uint32_t rect_min = __float_as_uint(c.y), width = __float_as_uint(c.z) & 0xffffu;
             const uint32_t slot = __float_as_uint(c.w) + ((uint32_t)tile_y - (rect_min >> 16)) * width +
                                   ((uint32_t)tile_x - (rect_min & 0xffffu));
-            float* dst = a.pair_grad + (size_t)slot * kPairGrad;
+            float4* dst = reinterpret_cast<float4*>(a.pair_grad + (size_t)slot * kPairStride);   // 48-B row, 3 x 16 B
             const float* src = s_grad + lane * kGradStride;
-            dst[0] = src[0] * half_w;  // viewport factors of backward.cu:498-499, applied once
-            dst[1] = src[1] * half_h;
-#pragma unroll
-            for (int k = 2; k < 9; k++) dst[k] = src[k];
+            // viewport factors of backward.cu:498-499, applied once
+            dst[0] = make_float4(src[0] * half_w, src[1] * half_h, src[2], src[3]);
+            dst[1] = make_float4(src[4], src[5], src[6], src[7]);
+            dst[2] = make_float4(src[8], 0.f, 0.f, 0.f);
             a.pair_flag[slot] = 1;
         }
     }
@@ -423,11 +424,7 @@ void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s
     if (!p.has_pairs) return;
     // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
     const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == a->nblocks
-    static const int occ = env_int("R3DGS_BWD_OCC", 5, 5, 6);
-    if (occ == 6)
-        hipLaunchKernelGGL((blend_bwd_kernel<4, 6>), dim3(nblocks), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((blend_bwd_kernel<4, 5>), dim3(nblocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, a);
 }
 
 }  // namespace r3

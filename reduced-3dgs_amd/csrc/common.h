@@ -36,6 +36,8 @@ constexpr size_t kAlign = 256;
 constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the backward blend:
                               // dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb
 constexpr int kAccStride = 12;  // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
+constexpr int kPairStride = 12; // floats per row of the per-pair slab: 48-B rows, written / read as three float4
+                                // (36-B rows measured 2.4x write amplification: partial lines, nine dword accesses)
 
 // Per-view counters.  Every preprocess workgroup stores one PrePartial (no atomics, nothing to pre-clear: the first
 // GPU profile showed 7.8k same-address atomics costing ~90 us, a sharded version still needed a fill of the header
@@ -73,10 +75,20 @@ static_assert(sizeof(PassInfo) == 32, "PassInfo = 32 B");
 // Bucketed depth sort (binning.hip): `nb` monotone buckets over [min depth bits, max depth bits], each sorted by one
 // workgroup in LDS.  nb scales with P (<= kMaxDepthBuckets).
 constexpr int kMinDepthBuckets = 1024;
-constexpr int kMaxDepthBuckets = 8192;
+constexpr int kMaxDepthBuckets = 16384;
 constexpr int kBucketCap = 4096;     // (key, id) pairs one workgroup sorts in LDS (32 KB)
-constexpr int kHistPerBlock = 4096;  // Gaussians per histogram workgroup (16 per thread)
-int depth_bucket_load();   // mean Gaussians per bucket aimed for (R3DGS_DEPTH_BUCKET_LOAD, default 256); capi.hip
+constexpr int kHistBatch = 4096;     // Gaussians a histogram / scatter workgroup handles per round (16 per thread)
+// Gaussians per histogram / scatter workgroup: rounds of kHistBatch, as many as keep the row count near 256 (one
+// workgroup per CU: their nb-entry LDS tables leave room for no more at large nb).  Every such workgroup carries
+// nb-entry tables (its histogram row, its scan of the bucket totals), so with a fixed 4096 Gaussians per workgroup
+// the table traffic grew like P * nb: 0.44 ms for the scatter alone at 6 M Gaussians.
+inline size_t depth_hist_per_block(size_t P)
+{
+    const size_t want = (P + 255) / 256;
+    const size_t per = ((want + kHistBatch - 1) / kHistBatch) * kHistBatch;
+    return per < (size_t)kHistBatch ? (size_t)kHistBatch : per;
+}
+int depth_bucket_load();   // mean Gaussians per bucket aimed for (R3DGS_DEPTH_BUCKET_LOAD, default 128); capi.hip
 inline int depth_bucket_count(size_t P)
 {
     int nb = kMinDepthBuckets;
@@ -90,7 +102,7 @@ struct DepthSortScratch {
     uint32_t start[kMaxDepthBuckets + 2];            // exclusive scan of the bucket sizes
     uint32_t tile_base[kMaxDepthBuckets + 2];        // exclusive scan of the buckets' tiles_touched sums
 };
-inline size_t depth_hist_rows(size_t P) { return (P + kHistPerBlock - 1) / kHistPerBlock; }
+inline size_t depth_hist_rows(size_t P) { const size_t per = depth_hist_per_block(P); return (P + per - 1) / per; }
 
 struct Carver {
     char* p;
@@ -173,9 +185,10 @@ inline uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-// Tile sort of the packed pair words (binning.hip): a pair travels as ONE word, tile << rank_bits | rank of its
-// Gaussian in depth order, through a key-only LSD radix sort on the tile bits (the Gaussian id is order[rank]).
-// 32-bit words while tile bits + rank bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | rank)
+// Tile sort of the packed pair words (binning.hip): a pair travels as ONE word, tile << rank_bits | Gaussian id,
+// through a key-only, stable LSD radix sort on the tile bits; emission is in depth order, so the order inside a
+// tile is (depth, id) without the depth ever being part of the key.
+// 32-bit words while tile bits + id bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | id)
 // above -- every real scene.  Two or three stable passes of <= 8-bit digits, 1024 keys per workgroup.
 // Forward and backward derive the same layout from (P, #tiles) alone.
 constexpr int kRadixBlock = 1024;
@@ -183,7 +196,7 @@ constexpr int kMaxRadixBins = 256;
 constexpr int kMaxRadixPasses = 3;
 struct PairLayout {
     int tile_bits;   // bits holding the tile id
-    int rank_bits;   // shift of the tile id inside the word (32 for wide words)
+    int rank_bits;   // shift of the tile id inside the word = bits holding the Gaussian id (32 for wide words)
     int wide;        // 1: 64-bit words
     int passes;      // radix passes over the tile bits
     int digit_bits;  // bits per pass
@@ -195,8 +208,8 @@ struct BinState {
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
     float* wave_part;      // [(R/64+1) * 2 * kPairGrad] leading / trailing partial run sums of each 64-pair group
     unsigned char* pair_flag;  // [R] 1 = the backward blend wrote this pair's row (only this is zeroed per pass)
-    uint32_t* pair_rank;   // [R] depth rank of the emitted pair's Gaussian, emission order (run key of the backward's
-                           //     segmented sum); narrow words: aliases words_a (the low rank_bits of the word)
+    uint32_t* pair_rank;   // [R] Gaussian id of the emitted pair, emission order (run key of the backward's segmented
+                           //     sum); narrow words: aliases words_a (the low rank_bits of the word)
     char* words_a;         // [R] packed words in emission order (narrow) / ping-pong buffer A (wide)
     char* words_b;         // [R] ping-pong buffer B
     char* words_c;         // [R] narrow only: third buffer, so that words_a survives for the backward
@@ -209,7 +222,7 @@ struct BinState {
         Carver c(base);
         BinState b;
         b.point_list = c.take<uint32_t>(R);
-        b.pair_grad = c.take<float>(R * kPairGrad);
+        b.pair_grad = c.take<float>(R * kPairStride);
         b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
         b.pair_flag = c.take<unsigned char>(R);
         if (wide) {
@@ -367,8 +380,8 @@ struct HeaderArgs {       // binning.hip header_reduce_kernel
     uint32_t ticket;
     uint32_t reserve;
 };
-struct DepthArgs {        // binning.hip bucketed depth sort
-    int P, nb, rows;
+struct DepthArgs {        // depth_sort.h bucketed depth sort
+    int P, nb, rows, per_block;
     const uint32_t* key;
     const uint32_t* tiles;
     GeomHeader* hdr;

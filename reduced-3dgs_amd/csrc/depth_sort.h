@@ -61,10 +61,11 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
     return peers;
 }
 
-constexpr int kHistPerThread = kHistPerBlock / 256;
+constexpr int kWaveSortMax = 512;    // largest bucket one wave sorts in registers (8 words per lane)
+constexpr int kBucketsPerGroup = 4;  // buckets per 256-thread workgroup of the bucket-sort kernel: one per wave
+constexpr int kHistPerThread = kHistBatch / 256;
 constexpr int kCountBits = 24;
 constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
-constexpr int kMaxBucketsPerThread = (kMaxDepthBuckets + 1 + 255) / 256;
 
 struct DepthRange {
     uint32_t kmin;
@@ -91,29 +92,30 @@ __device__ inline int depth_bucket(uint32_t key, const DepthRange& r)
 
 // LDS bytes of each role (the kernels size their dynamic LDS as the maximum over the roles they carry)
 inline size_t depth_hist_lds(int nb) { return (size_t)(nb + 1) * sizeof(unsigned long long); }
-inline size_t depth_scatter_lds(int nb) { return (size_t)3 * (nb + 2) * sizeof(uint32_t) + 256 * sizeof(unsigned long long); }
+inline size_t depth_scatter_lds(int nb) { return (size_t)2 * (nb + 2) * sizeof(uint32_t) + 256 * sizeof(unsigned long long); }
 constexpr size_t kBucketSortLds = (size_t)kBucketCap * 8 + 256 * 4 + (256 + 256 + 4 * 256 + 4) * 4;
 
-// (1) workgroup `wg` of depth_hist_rows(P): histogram of its 4096 Gaussians
+// (1) workgroup `wg` of depth_hist_rows(P): histogram of its per_block Gaussians, kHistBatch at a time
 __device__ inline void depth_hist_role(const DepthArgs& a, char* smem, int wg)
 {
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);   // [nb + 1]
     const int P = a.P, nb = a.nb;
     for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;
     const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
-    const int base = wg * kHistPerBlock;
-    uint32_t kv[kHistPerThread], tv[kHistPerThread];
-#pragma unroll
-    for (int k = 0; k < kHistPerThread; k++) {   // all loads in flight before the first LDS atomic
-        const int i = base + k * 256 + threadIdx.x;
-        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
-        tv[k] = i < P ? a.tiles[i] : 0u;
-    }
     __syncthreads();
+    for (int base = wg * a.per_block; base < min(P, (wg + 1) * a.per_block); base += kHistBatch) {
+        uint32_t kv[kHistPerThread], tv[kHistPerThread];
 #pragma unroll
-    for (int k = 0; k < kHistPerThread; k++)
-        if (base + k * 256 + (int)threadIdx.x < P)
-            atomicAdd(&hist[depth_bucket(kv[k], rng)], ((unsigned long long)tv[k] << kCountBits) | 1ull);
+        for (int k = 0; k < kHistPerThread; k++) {   // all loads in flight before the first LDS atomic
+            const int i = base + k * 256 + threadIdx.x;
+            kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
+            tv[k] = i < P ? a.tiles[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kHistPerThread; k++)
+            if (base + k * 256 + (int)threadIdx.x < P)
+                atomicAdd(&hist[depth_bucket(kv[k], rng)], ((unsigned long long)tv[k] << kCountBits) | 1ull);
+    }
     __syncthreads();
     unsigned long long* row = a.hist_rows + (size_t)wg * (nb + 1);
     for (int b = threadIdx.x; b <= nb; b += 256) row[b] = hist[b];
@@ -167,28 +169,27 @@ __device__ inline void depth_colscan_role(const DepthArgs& a, int wg)
     }
 }
 
-// Exclusive scan of the nb + 1 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24),
-// by a 256-thread workgroup into LDS.
-__device__ inline void scan_bucket_totals(const DepthSortScratch* ds, int nb, uint32_t* s_start, uint32_t* s_tile,
-                                          unsigned long long* s_tmp)
+// Exclusive scan of the nb + 1 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24) by a
+// 256-thread workgroup: bucket starts into LDS, and -- by the publishing workgroup only -- starts and tile bases into
+// global memory for the bucket-sort kernel.  The totals are read twice (L2) instead of being held in registers.
+__device__ inline void scan_bucket_totals(DepthSortScratch* ds, int nb, uint32_t* s_start, unsigned long long* s_tmp,
+                                          bool publish)
 {
-    const int per = (nb + 1 + 255) / 256;
-    unsigned long long c[kMaxBucketsPerThread], sum = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxBucketsPerThread; k++) {
-        const int b = threadIdx.x * per + k;
-        c[k] = (k < per && b <= nb) ? ds->total[b] : 0ull;
-        sum += c[k];
-    }
+    const int per = (nb + 2 + 255) / 256;
+    const int b0 = threadIdx.x * per;
+    unsigned long long sum = 0;
+    for (int k = 0; k < per; k++) sum += b0 + k <= nb ? ds->total[b0 + k] : 0ull;
     unsigned long long run = block256_inclusive_scan(sum, s_tmp) - sum;
-#pragma unroll
-    for (int k = 0; k < kMaxBucketsPerThread; k++) {
-        const int b = threadIdx.x * per + k;
-        if (k < per && b <= nb + 1) {
+    for (int k = 0; k < per; k++) {
+        const int b = b0 + k;
+        if (b <= nb + 1) {
             s_start[b] = (uint32_t)(run & kCountMask);
-            s_tile[b] = (uint32_t)(run >> kCountBits);
+            if (publish) {
+                ds->start[b] = (uint32_t)(run & kCountMask);
+                ds->tile_base[b] = (uint32_t)(run >> kCountBits);
+            }
+            run += b <= nb ? ds->total[b] : 0ull;
         }
-        run += c[k];
     }
     __syncthreads();
 }
@@ -199,46 +200,86 @@ __device__ inline void depth_scatter_role(const DepthArgs& a, char* smem, int wg
     const int P = a.P, nb = a.nb;
     unsigned long long* s_tmp = reinterpret_cast<unsigned long long*>(smem);   // [256]
     uint32_t* slot0 = reinterpret_cast<uint32_t*>(smem + 256 * sizeof(unsigned long long));   // bucket starts, then this
-    uint32_t* s_tile = slot0 + (nb + 2);                                       // workgroup's first slot of each bucket
-    uint32_t* rank = slot0 + 2 * (nb + 2);
-    DepthSortScratch* ds = a.ds;
-    scan_bucket_totals(ds, nb, slot0, s_tile, s_tmp);
-    if (wg == 0)   // published for the per-bucket sort kernel
-        for (int b = threadIdx.x; b <= nb + 1; b += 256) {
-            ds->start[b] = slot0[b];
-            ds->tile_base[b] = s_tile[b];
-        }
-    const uint32_t R = s_tile[nb];   // culled Gaussians add no tiles: their scan value is the total
-    __syncthreads();
+    uint32_t* rank = slot0 + (nb + 2);                                         // workgroup's first slot of each bucket
+    scan_bucket_totals(a.ds, nb, slot0, s_tmp, wg == 0);   // workgroup 0 publishes for the per-bucket sort kernel
+    const uint32_t R = a.hdr->num_rendered;   // culled Gaussians add no tiles: their scan value is the total
     const uint32_t* mybase = a.hist_base + (size_t)wg * (nb + 1);
     for (int b = threadIdx.x; b <= nb; b += 256) {
         slot0[b] += mybase[b];
         rank[b] = 0;
     }
     const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
-    const int base = wg * kHistPerBlock;
-    uint32_t kv[kHistPerThread];
-#pragma unroll
-    for (int k = 0; k < kHistPerThread; k++) {
-        const int i = base + k * 256 + threadIdx.x;
-        kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
-    }
     __syncthreads();
+    for (int base = wg * a.per_block; base < min(P, (wg + 1) * a.per_block); base += kHistBatch) {
+        uint32_t kv[kHistPerThread];
 #pragma unroll
-    for (int k = 0; k < kHistPerThread; k++) {
-        const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
-        if ((int)id < P) {
-            const int b = depth_bucket(kv[k], rng);
-            const uint32_t slot = slot0[b] + atomicAdd(&rank[b], 1u);   // any order: the bucket is sorted next
-            if (b == nb) {
-                a.order[slot] = id;
-                a.offsets[slot] = R;
-            } else {
-                a.key_sorted[slot] = kv[k];
-                a.bucket_id[slot] = id;
+        for (int k = 0; k < kHistPerThread; k++) {
+            const int i = base + k * 256 + threadIdx.x;
+            kv[k] = i < P ? a.key[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kHistPerThread; k++) {
+            const uint32_t id = (uint32_t)(base + k * 256 + threadIdx.x);
+            if ((int)id < P) {
+                const int b = depth_bucket(kv[k], rng);
+                const uint32_t slot = slot0[b] + atomicAdd(&rank[b], 1u);   // any order: the bucket is sorted next
+                if (b == nb) {
+                    a.order[slot] = id;
+                    a.offsets[slot] = R;
+                } else {
+                    a.key_sorted[slot] = kv[k];
+                    a.bucket_id[slot] = id;
+                }
             }
         }
     }
+}
+
+// Bitonic sort of 64 * E words held E per lane by ONE wave (element r * 64 + lane in v[r]): no barriers, no LDS
+// arrays -- compare-exchanges with a partner >= 64 elements away are register-local, the others one 64-bit
+// shuffle per element.  Ascending; pad with ~0.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[E], int lane)
+{
+    constexpr int N = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dr = j / 64;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & dr) == 0) {
+                        const bool up = ((r * 64) & k) == 0;   // k > j >= 64: decided by the register index alone
+                        const unsigned long long x = v[r], y = v[r | dr];
+                        const bool sw = (x > y) == up;
+                        v[r] = sw ? y : x;
+                        v[r | dr] = sw ? x : y;
+                    }
+                }
+            } else {
+                const bool lower = (lane & j) == 0;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const unsigned long long other = __shfl_xor(v[r], j);
+                    const bool up = ((r * 64 + lane) & k) == 0;
+                    const bool take_min = lower == up;
+                    v[r] = ((v[r] < other) == take_min) ? v[r] : other;
+                }
+            }
+        }
+    }
+}
+
+// full-wave inclusive scan (result in every lane) and total
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, off);
+        if (lane >= off) v += up;
+    }
+    return v;
 }
 
 // Slow path of the bucket sort: n (key, id) pairs in global memory, sorted by (key, id) by ONE 256-thread workgroup
@@ -303,8 +344,8 @@ __device__ inline int block_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_
     return cur;
 }
 
-// (4) workgroup b of nb: sort the (key << 32 | id) words of bucket b in LDS, then the inclusive scan of tiles_touched
-// in that order on top of the bucket's base (rasterizer_impl.cu:441 InclusiveSum, fused).
+// Workgroup-level sort of ONE bucket b (the big ones, see depth_bucket_group_role): the (key << 32 | id) words in LDS,
+// then the inclusive scan of tiles_touched in that order on top of the bucket's base.
 __device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, int b)
 {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);                     // [kBucketCap]
@@ -340,12 +381,29 @@ __device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, in
     }
     const uint32_t* __restrict__ in_key = a.key_sorted;
     const uint32_t* __restrict__ in_id = a.bucket_id;
-    uint32_t N = 2;
+    uint32_t N = 2 * kWaveSortMax;
     while (N < n) N <<= 1;
-    for (uint32_t r = threadIdx.x; r < N; r += 256)
-        s[r] = r < n ? ((unsigned long long)in_key[start + r] << 32) | in_id[start + r] : ~0ull;
+    // levels k <= kWaveSortMax of the bitonic network: every wave sorts 512-word chunks in registers and parks them in
+    // LDS, ascending for even chunks and descending for odd ones (what the network leaves after its k = 512 level)
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (uint32_t c = (uint32_t)w; c < N / kWaveSortMax; c += 4) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t i = c * kWaveSortMax + (uint32_t)(r * 64 + lane);
+                v[r] = i < n ? ((unsigned long long)in_key[start + i] << 32) | in_id[start + i] : ~0ull;
+            }
+            wave_bitonic_sort<8>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t i = (uint32_t)(r * 64 + lane);
+                s[c * kWaveSortMax + ((c & 1u) ? (uint32_t)kWaveSortMax - 1u - i : i)] = v[r];
+            }
+        }
+    }
     __syncthreads();
-    for (uint32_t k = 2; k <= N; k <<= 1)
+    for (uint32_t k = 2 * kWaveSortMax; k <= N; k <<= 1)   // the remaining levels merge through LDS
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
                 const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;   // lo has bit j clear
@@ -374,6 +432,69 @@ __device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, in
             run += tl[k];
             order[start + r] = (uint32_t)s[r];
             offsets[start + r] = run;
+        }
+    }
+}
+
+// One wave sorts bucket b (n <= 64 * E pairs) in registers and scans tiles_touched in sorted order.
+template <int E>
+__device__ __forceinline__ void wave_sort_bucket(const DepthArgs& a, uint32_t start, uint32_t n, uint32_t tile_base,
+                                                 int lane)
+{
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const uint32_t i = (uint32_t)(r * 64 + lane);
+        v[r] = i < n ? ((unsigned long long)a.key_sorted[start + i] << 32) | a.bucket_id[start + i] : ~0ull;
+    }
+    wave_bitonic_sort<E>(v, lane);
+    uint32_t t[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) t[r] = (uint32_t)(r * 64 + lane) < n ? a.tiles[(uint32_t)v[r]] : 0u;
+    uint32_t run = tile_base;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const uint32_t i = (uint32_t)(r * 64 + lane);
+        const uint32_t incl = wave_inclusive_scan(t[r], lane);
+        if (i < n) {
+            a.order[start + i] = (uint32_t)v[r];
+            a.offsets[start + i] = run + incl;
+        }
+        run += (uint32_t)__shfl((int)incl, 63);
+    }
+}
+
+
+// (4) workgroup wg of nb / 4: each of its four waves sorts one bucket's (key << 32 | id) words in registers and scans
+// tiles_touched in that order on top of the bucket's base (rasterizer_impl.cu:441 InclusiveSum, fused); buckets above
+// kWaveSortMax pairs are then sorted by the whole workgroup in LDS (<= kBucketCap) or in global memory.
+__device__ inline void depth_bucket_group_role(const DepthArgs& a, char* smem, int wg)
+{
+    const DepthSortScratch* __restrict__ ds = a.ds;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const int b = wg * kBucketsPerGroup + w;
+        if (b < a.nb) {
+            const uint32_t start = ds->start[b], n = ds->start[b + 1] - start, tb = ds->tile_base[b];
+            if (n == 0) {
+            } else if (n <= 64) {
+                wave_sort_bucket<1>(a, start, n, tb, lane);
+            } else if (n <= 128) {
+                wave_sort_bucket<2>(a, start, n, tb, lane);
+            } else if (n <= 256) {
+                wave_sort_bucket<4>(a, start, n, tb, lane);
+            } else if (n <= (uint32_t)kWaveSortMax) {
+                wave_sort_bucket<8>(a, start, n, tb, lane);
+            }
+        }
+    }
+    for (int q = 0; q < kBucketsPerGroup; q++) {   // workgroup-uniform: the big buckets, all four waves together
+        const int b = wg * kBucketsPerGroup + q;
+        if (b >= a.nb) break;
+        const uint32_t n = ds->start[b + 1] - ds->start[b];
+        if (n > (uint32_t)kWaveSortMax) {
+            __syncthreads();
+            depth_bucket_sort_role(a, smem, b);
         }
     }
 }

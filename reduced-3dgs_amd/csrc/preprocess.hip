@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kPreBlock) void depth_sort_color_kernel(const FwdPa
         else if (STEP == 1)
             depth_scatter_role(d, smem, wg);
         else
-            depth_bucket_sort_role(d, smem, wg);
+            depth_bucket_group_role(d, smem, wg);
     } else {
         const PreArgs a = pa->pre;
         color_role<RAGGED>(a, smem, c0, c1, wg - n_sort, (int)gridDim.x - n_sort);
@@ -360,12 +360,12 @@ void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* pa, hipStre
         launch_sort_color<0, true>(pa, rows, n_color(0), c[0], c[1], lds0, s);
         hipLaunchKernelGGL(depth_colscan_kernel, dim3((nb + 1 + 63) / 64), dim3(64 * kColWaves), 0, s, &pa->depth);
         launch_sort_color<1, true>(pa, rows, n_color(1), c[1], c[2], lds1, s);
-        launch_sort_color<2, true>(pa, nb, n_color(2), c[2], c[3], lds2, s);
+        launch_sort_color<2, true>(pa, (nb + kBucketsPerGroup - 1) / kBucketsPerGroup, n_color(2), c[2], c[3], lds2, s);
     } else {
         launch_sort_color<0, false>(pa, rows, n_color(0), c[0], c[1], lds0, s);
         hipLaunchKernelGGL(depth_colscan_kernel, dim3((nb + 1 + 63) / 64), dim3(64 * kColWaves), 0, s, &pa->depth);
         launch_sort_color<1, false>(pa, rows, n_color(1), c[1], c[2], lds1, s);
-        launch_sort_color<2, false>(pa, nb, n_color(2), c[2], c[3], lds2, s);
+        launch_sort_color<2, false>(pa, (nb + kBucketsPerGroup - 1) / kBucketsPerGroup, n_color(2), c[2], c[3], lds2, s);
     }
     if (!p.color_fuse) issue_preprocess_color(p, &pa->pre, s);
 }

@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
 #pragma unroll
     for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
     if (valid) {
-        // run key: the Gaussian id (pair sort) or its rank in depth order (packed sort: low bits of the pair word)
+        // run key: the Gaussian id (low bits of the pair word)
         key = pair_gid[e] & rank_mask;
         if (pair_flag[e]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
             pair_flag[e] = 0;  // consumed: all flags are zero again when this kernel ends (next backward pass)
-            const float* src = pair_grad + (size_t)e * kPairGrad;
-#pragma unroll
-            for (int k = 0; k < kPairGrad; k++) v[k] = src[k];
+            const float4* src = reinterpret_cast<const float4*>(pair_grad + (size_t)e * kPairStride);
+            const float4 r0 = src[0], r1 = src[1];
+            v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w;
+            v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
+            v[8] = pair_grad[(size_t)e * kPairStride + 8];
         }
     }
 #pragma unroll

@@ -410,7 +410,7 @@ def test_full_size_properties(C_, metric_scene):
     for k in (0, 2, 3, 5, 6, 7):
         lin = 0.5 * b1[k] - 2.0 * b2[k]
         scale = float(lin.abs().max()) + 1e-30
-        assert float((b3[k] - lin).abs().max()) <= 2e-4 * scale, k
+        assert float((b3[k] - lin).abs().max()) <= 5e-4 * scale, k   # fp32 rounding of sums over up to ~30 M pairs
     assert all(bool(torch.isfinite(t).all()) for t in b1[:8])
     # the backward has no float atomics: two passes over the same forward state are bit-identical
     b1_again = hip_backward(C_, fargs, fout, g1, 0.0)
