@@ -163,12 +163,16 @@ def main():
     settings = [dgr.GaussianRasterizationSettings(H, W, c.tanfovx, c.tanfovy, bg, 1.0, dv(c.world_view_transform),
                                                   dv(c.full_proj_transform), 3, dv(c.camera_center), False, False)
                 for c in cams]
+    # all-to-all + local combine + all-gather needs RCCL; the single-device gloo dry run falls back to all-reduces
+    two_phase = os.environ.get("R3DGS_BENCH_BACKEND", "nccl") == "nccl"
     exch = ViewParallelExchange({"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)},
-                                P, device) if world > 1 else None
+                                P, device, two_phase=two_phase) if world > 1 else None
     if exch is not None and os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
         _C.set_gradient_arena(exch.arena)   # parameter gradients are written straight into the exchange buffer
 
     born_in_buffer = [None]
+    pending = [None]     # exchange of the previous step still in flight
+    overlap = [os.environ.get("R3DGS_BENCH_NO_OVERLAP") != "1"]
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
@@ -189,8 +193,20 @@ def main():
                                         g_.data_ptr() == exch.arena(k, tuple(g_.shape)).data_ptr()
                                         for k, g_ in grads.items())
             exch.pack(grads, means2D.grad, radii)
-            exch.exchange()
+            if overlap[0]:
+                # The exchange of step k travels while step k+1 renders (double-buffered arena, own stream); the
+                # optimizer of step k would run where the wait is, one step later.
+                if pending[0] is not None:
+                    exch.wait(pending[0])
+                pending[0] = exch.exchange_async()
+            else:
+                exch.exchange()
         return radii
+
+    def drain():
+        if exch is not None and pending[0] is not None:
+            exch.wait(pending[0])
+            pending[0] = None
 
     # num_rendered per camera (property of the input; every per-pair byte term scales with it); these passes also
     # teach the library the pair reservation of this view size
@@ -209,6 +225,7 @@ def main():
 
     for i in range(args.warmup):
         train_step(i)
+    drain()
     torch.cuda.synchronize()
     # Timed region: HIP events around the DOMINANT stage only.  A pass with a timed stage is issued with direct
     # launches (the events sit between its kernels) instead of its graph, so the full per-stage breakdown is taken in
@@ -232,6 +249,7 @@ def main():
         th = time.perf_counter()
         train_step(args.warmup + i)
         host_ms.append(1e3 * (time.perf_counter() - th))
+    drain()
     ev1.record()
     t_enq = time.perf_counter()
     # The host is done long before the GPU.  Wait without burning the container's CPU quota (a spinning
@@ -249,9 +267,33 @@ def main():
     _C.profile_enable(True)
     for i in range(min(args.steps, 20)):
         train_step(args.warmup + i)
+    drain()
     torch.cuda.synchronize()
     prof = _C.profile_read()
     _C.profile_enable(False)
+    # N > 1: the exchange alone (events around a synchronous exchange) and the same steps with the exchange
+    # serialised behind the backward, to see how much of it the overlap hides
+    exchange_ms = sync_ms_per_step = None
+    if exch is not None:
+        n_x = min(args.steps, 10)
+        overlap[0] = False
+        xa, xb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        xa.record()
+        for _ in range(n_x):
+            exch.exchange()
+        xb.record()
+        torch.cuda.synchronize()
+        exchange_ms = xa.elapsed_time(xb) / n_x
+        barrier()
+        ts0 = time.perf_counter()
+        for i in range(n_x):
+            train_step(args.warmup + i)
+        torch.cuda.synchronize()
+        barrier()
+        sync_ms_per_step = 1e3 * (time.perf_counter() - ts0) / n_x
+        overlap[0] = os.environ.get("R3DGS_BENCH_NO_OVERLAP") != "1"
     if prof_timed.get(dom_stage, (0, 0))[1]:
         prof[dom_stage] = prof_timed[dom_stage]  # the roofline kernel's time is the one from the timed region
     if world > 1:
@@ -316,12 +358,18 @@ def main():
         "config": {"workload": args.workload, "gaussians": P, "width": W, "height": H, "sh_degree": 3,
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                   "exchange": "RCCL reduce-scatter+all-gather of 59 fp32 grads + 2 stats / Gaussian, MAX radii"
-                   if world > 1 else None,
+                   "exchange": ("all-to-all + local SUM/MAX combine + all-gather of one flat buffer (59 fp32 grads + 2 "
+                                "stats + radii per Gaussian), own stream, double-buffered: overlapped with the next "
+                                "step's render") if world > 1 else None,
                    "grads_born_in_exchange_buffer": born_in_buffer[0],
                    "issue": "one hipGraph launch per forward, direct launches for the (event-timed) backward; "
                             "pair reservation instead of a num_rendered read-back",
                    "reserve_overflows_in_run": _C.reserve_overflow_events() - overflow0},
+        "exchange_ms": round(exchange_ms, 4) if exchange_ms is not None else None,
+        "exchange_bytes_per_rank": (exch.flat.numel() * 4) if exch is not None else None,
+        "step_ms_exchange_serialised": round(sync_ms_per_step, 4) if sync_ms_per_step is not None else None,
+        "overlap_frac": (round(max(0.0, min(1.0, (sync_ms_per_step - 1e3 * elapsed / args.steps) / exchange_ms)), 3)
+                         if exchange_ms else None),
         "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
         "render_fps": round(args.steps / render_s, 1),
         "roofline": roofline,

@@ -73,6 +73,13 @@ int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, flo
 int r3dgs_pack_view_stats(int P, const float* viewspace_grad, const int* radii, float* grad_norm, float* visible,
                           int* radii_out, void* stream);
 
+/* Local reduction of the view-parallel exchange: `recv` holds `world` copies (one per rank, in rank order) of this
+ * rank's shard of the flat exchange buffer, `shard` 4-byte elements each, the shard starting at element `shard_begin`
+ * of the buffer.  Elements of the buffer below `sum_len` are fp32 and are SUMmed, the rest are int32 and MAXed
+ * (radii).  out: [shard].  The combination order is the rank order, so all replicas compute identical bits. */
+int r3dgs_reduce_shards(int world, long long shard, long long shard_begin, long long sum_len, const float* recv,
+                        float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

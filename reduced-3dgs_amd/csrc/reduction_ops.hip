@@ -157,6 +157,27 @@ __global__ __launch_bounds__(kBlock) void pack_view_stats_kernel(int P, const fl
     radii_out[i] = r;
 }
 
+// Local half of the view-parallel exchange (multiview.py): after the all-to-all every rank holds, for ITS shard of the
+// flat buffer, one copy per rank; combine them in rank order -- SUM for the fp32 part of the buffer (gradients,
+// densification statistics), MAX for the int32 tail (radii).  Fixed order: every replica computes identical bits.
+__global__ __launch_bounds__(kBlock) void reduce_shards_kernel(const float* __restrict__ recv, int world, long long shard,
+                                                               long long shard_begin, long long sum_len,
+                                                               float* __restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= shard) return;
+    if (shard_begin + j < sum_len) {
+        float acc = recv[j];
+        for (int w = 1; w < world; w++) acc += recv[(long long)w * shard + j];
+        out[j] = acc;
+    } else {
+        const int* ri = reinterpret_cast<const int*>(recv);
+        int m = ri[j];
+        for (int w = 1; w < world; w++) m = max(m, ri[(long long)w * shard + j]);
+        reinterpret_cast<int*>(out)[j] = m;
+    }
+}
+
 int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -231,6 +252,19 @@ int r3dgs_pack_view_stats(int P, const float* viewspace_grad, const int* radii, 
         hipStream_t s = static_cast<hipStream_t>(stream);
         pack_view_stats_kernel<<<grid_for(P), kBlock, 0, s>>>(P, viewspace_grad, radii, grad_norm, visible, radii_out);
         r3::check_launch("pack view stats", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_reduce_shards(int world, long long shard, long long shard_begin, long long sum_len, const float* recv,
+                        float* out, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (shard <= 0) return 0;
+        if (world < 1 || !recv || !out) throw r3::Error("reduce_shards: bad arguments");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        reduce_shards_kernel<<<grid_for(shard), kBlock, 0, s>>>(recv, world, shard, shard_begin, sum_len, out);
+        r3::check_launch("reduce shards", s, false);
         return 0;
     });
 }

@@ -70,6 +70,8 @@ _lib.r3dgs_kmeans.restype = _i
 _lib.r3dgs_kmeans.argtypes = [_i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.r3dgs_pack_view_stats.restype = _i
 _lib.r3dgs_pack_view_stats.argtypes = [_i] + [_vp] * 6
+_lib.r3dgs_reduce_shards.restype = _i
+_lib.r3dgs_reduce_shards.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
 _lib.r3dgs_profile_enable.argtypes = [_i]
 _lib.r3dgs_profile_stage_name.restype = C.c_char_p
 _lib.r3dgs_profile_stage_name.argtypes = [_i]
@@ -475,13 +477,12 @@ def rasterize_gaussians_counters(*args):
     return out + (touched, transm)
 
 
-def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotations, cam_viewmatrices, cam_projmatrices,
-                               tan_fovxs, tan_fovys, image_height, image_width, sh, degrees, max_sh_deg):
-    """Reduced3DGS::calculateColourVariance (reduced_3dgs.cu:41-203) ->
-    (colourDistances[P,max_sh_deg], variance[P,1,3], mean[P,1,3]).  Per camera: the counter-mode forward
-    (touched pixels + summed transmittance per Gaussian) followed by ONE fused per-Gaussian accumulate kernel,
-    instead of the reference's ~25 small torch operators per camera.  The four per-camera parameter tensors are
-    read back once (the reference does a blocking .item() per value and camera)."""
+def calculate_colours_variance_partial(cam_positions, means3D, opacity, scales, rotations, cam_viewmatrices,
+                                       cam_projmatrices, tan_fovxs, tan_fovys, image_height, image_width, sh, degrees,
+                                       max_sh_deg):
+    """The accumulation part of Reduced3DGS::calculateColourVariance (reduced_3dgs.cu:41-198) over the given cameras,
+    WITHOUT the final divisions: (accum[P,max_sh_deg], wSum[P,1], mean[P,1,3], S[P,1,3]).  A camera-sharded run calls
+    this per rank and merges the partials (multiview.merge_colour_variance)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = means3D.device
@@ -499,7 +500,7 @@ def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotation
         txs, tys = tan_fovxs.tolist(), tan_fovys.tolist()
         bg = torch.zeros(3, **opts)
         empty = torch.Tensor([])
-        for i in range(int(cams.size(0))):
+        for i in range(int(cams.size(0)) if cams is not None else 0):
             touched = torch.zeros((P,), dtype=torch.int32, device=dev)
             transm = torch.zeros((P,), **opts)
             out = _forward_common(None, bg, m3, empty, opacity, scales, rotations, 1.0, empty, cam_viewmatrices[i],
@@ -511,6 +512,19 @@ def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotation
                                                              _ptr(shc), _ptr(radii), _ptr(touched), _ptr(transm),
                                                              _ptr(wSum), _ptr(wSumSq), _ptr(mean), _ptr(variance),
                                                              _ptr(accum), _stream()), "calculate_colours_variance")
+    return accum, wSum, mean, variance
+
+
+def calculate_colours_variance(cam_positions, means3D, opacity, scales, rotations, cam_viewmatrices, cam_projmatrices,
+                               tan_fovxs, tan_fovys, image_height, image_width, sh, degrees, max_sh_deg):
+    """Reduced3DGS::calculateColourVariance (reduced_3dgs.cu:41-203) ->
+    (colourDistances[P,max_sh_deg], variance[P,1,3], mean[P,1,3]).  Per camera: the counter-mode forward
+    (touched pixels + summed transmittance per Gaussian) followed by ONE fused per-Gaussian accumulate kernel,
+    instead of the reference's ~25 small torch operators per camera.  The four per-camera parameter tensors are
+    read back once (the reference does a blocking .item() per value and camera)."""
+    accum, wSum, mean, variance = calculate_colours_variance_partial(
+        cam_positions, means3D, opacity, scales, rotations, cam_viewmatrices, cam_projmatrices, tan_fovxs, tan_fovys,
+        image_height, image_width, sh, degrees, max_sh_deg)
     return accum / wSum, variance / wSum.view(-1, 1, 1), mean
 
 
@@ -617,3 +631,15 @@ def pack_view_stats(viewspace_grad, radii, grad_norm_out, visible_out, radii_out
     with _on_device(dev):
         _check(_lib.r3dgs_pack_view_stats(P, _ptr(vg), _ptr(rd), _ptr(grad_norm_out), _ptr(visible_out), _ptr(radii_out),
                                           _stream()), "pack_view_stats")
+
+
+def reduce_shards(recv, world, shard_begin, sum_len, out):
+    """Local half of the view-parallel exchange (include/r3dgs_reduction.h r3dgs_reduce_shards): recv [world, shard]
+    fp32 buffer whose tail (global element index >= sum_len) holds int32 radii -> out [shard]."""
+    dev = _need_gpu(recv, "reduce_shards")
+    shard = int(out.numel())
+    if recv.numel() != world * shard or not recv.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("reduce_shards: recv must be a contiguous [world, shard] buffer")
+    with _on_device(dev):
+        _check(_lib.r3dgs_reduce_shards(int(world), shard, int(shard_begin), int(sum_len), recv.data_ptr(),
+                                        out.data_ptr(), _stream()), "reduce_shards")

@@ -30,7 +30,7 @@ def _rank_inputs(rank):
     return grads, vgrad, radii
 
 
-def _worker(rank, world, port, two_phase, q, arena=False):
+def _worker(rank, world, port, two_phase, q, arena=False, use_async=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,20 +52,27 @@ def _worker(rank, world, port, two_phase, q, arena=False):
     ex.pack(grads, vgrad, radii)
     if arena:   # pack() had nothing to copy for the parameter gradients
         assert torch.equal(ex.flat[:ex.stat_off], sentinel[:ex.stat_off])
-    ex.exchange()
-    out, gnorm, vis, rmax = ex.unpack()
+    if use_async:   # double-buffered form: the next step's buffer becomes current while this one is in flight
+        k = ex.exchange_async()
+        assert ex.cur != k and ex.arena("means3D", (P, 3)).data_ptr() != ex.flats[k].data_ptr()
+        ex.flat.fill_(7.0)          # "next step" scribbling over the other buffer must not disturb the one in flight
+        ex.wait(k)
+        out, gnorm, vis, rmax = ex.unpack(k)
+    else:
+        ex.exchange()
+        out, gnorm, vis, rmax = ex.unpack()
     q.put((rank, {k: v.clone().numpy() for k, v in out.items()}, gnorm.clone().numpy(), vis.clone().numpy(),
            rmax.clone().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(two_phase, arena=False):
+def _run(two_phase, arena=False, use_async=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, two_phase, q, arena)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, two_phase, q, arena, use_async)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
@@ -92,3 +99,83 @@ def test_exchange_single_all_reduce():
 
 def test_exchange_with_gradient_arena():
     _run(two_phase=True, arena=True)
+
+
+def test_exchange_async_double_buffered():
+    _run(two_phase=True, arena=True, use_async=True)
+
+
+# ---- camera-sharded statistics (SURVEY.md 8e tier 2) ------------------------------------------------------------------
+def _cv_partial(cams):
+    """numpy model of the per-camera recurrence of calculate_colours_variance (reduced_3dgs.cu:154-198, with the
+    reference's mean_old aliasing) over the given cameras: cams = list of (w[P], colour[P,3], dist[P,D])."""
+    Pn, D = cams[0][1].shape[0], cams[0][2].shape[1]
+    acc, wsum = np.zeros((Pn, D), np.float64), np.zeros((Pn, 1), np.float64)
+    mean, S = np.zeros((Pn, 1, 3), np.float64), np.zeros((Pn, 1, 3), np.float64)
+    for w, col, dist_ in cams:
+        w = w.reshape(-1, 1)
+        wsum = wsum + w
+        acc = acc + w * dist_
+        coeff = np.where(wsum > 0, w / np.maximum(wsum, 1e-300), 0.0).reshape(-1, 1, 1)
+        mean = mean + coeff * (col.reshape(-1, 1, 3) - mean)
+        S = S + w.reshape(-1, 1, 1) * (col.reshape(-1, 1, 3) - mean) ** 2
+    return acc, wsum, mean, S
+
+
+def _cv_cameras(seed, n):
+    rng = np.random.default_rng(seed)
+    return [(rng.uniform(0.05, 1.0, 300), rng.uniform(0, 1, (300, 3)), rng.uniform(0, 0.3, (300, 3))) for _ in range(n)]
+
+
+def _tier2_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reduced-3dgs_amd"))
+    from multiview import merge_colour_variance, min_over_ranks
+    cams = _cv_cameras(5, 12)
+    mine = cams[rank::world]                       # cameras sharded round-robin over the ranks
+    part = tuple(torch.from_numpy(x).float() for x in _cv_partial(mine))
+    dists, var, mean = merge_colour_variance(part)
+    rng = np.random.default_rng(40 + rank)
+    px = torch.from_numpy(rng.uniform(0.5, 3.0, 300).astype(np.float32))
+    px[rng.random(300) < 0.3] = 10000.0            # unseen by this rank's cameras
+    mn = min_over_ranks(px.clone())
+    q.put((rank, dists.numpy(), var.numpy(), mean.numpy(), px.numpy(), mn.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_camera_sharded_colour_variance_merge_and_pixel_size_min():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tier2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cams = _cv_cameras(5, 12)
+    acc, wsum, mean, S = _cv_partial(cams)          # all cameras on one rank, in order
+    # exact references: weighted mean and the un-aliased weighted variance
+    W = sum(c[0] for c in cams).reshape(-1, 1)
+    mu = sum(c[0].reshape(-1, 1) * c[1] for c in cams) / W
+    M2 = sum(c[0].reshape(-1, 1) * (c[1] - mu) ** 2 for c in cams)
+    for rank, dists, var, mean_m, px, mn in results:
+        np.testing.assert_allclose(dists, acc / wsum, rtol=1e-5, atol=1e-6)            # plain sums
+        np.testing.assert_allclose(mean_m[:, 0], mu, rtol=1e-5, atol=1e-6)               # weighted mean: exact merge
+        np.testing.assert_allclose(mean_m, mean, rtol=1e-5, atol=1e-6)
+        # variance: the merge is exact on the textbook recurrence; with the reference's aliasing both the sequential
+        # and the sharded numbers sit a little below the true weighted variance, by an order-dependent amount
+        seq = (S / wsum.reshape(-1, 1, 1))[:, 0]
+        true = M2 / W
+        assert np.all(var[:, 0] <= true * (1 + 1e-5) + 1e-7)
+        assert np.abs(var[:, 0] - seq).max() <= 0.25 * true.max()
+        assert np.abs(var[:, 0] - true).mean() <= np.abs(seq - true).mean() * 3 + 1e-6
+    np.testing.assert_array_equal(results[0][5], results[1][5])                          # replicas agree bit for bit
+    np.testing.assert_array_equal(results[0][5], np.minimum(results[0][4], results[1][4]))
+    np.testing.assert_array_equal(results[0][2], results[1][2])

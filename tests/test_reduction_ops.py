@@ -316,3 +316,24 @@ def test_gpu_pack_view_stats_and_exchange_pack():
     for k in shapes:
         assert torch.equal(out[k], grads[k])
     assert torch.allclose(gnorm, want, rtol=1e-6, atol=0) and torch.equal(visible, vis.float()) and torch.equal(rmax, radii)
+
+
+@pytest.mark.gpu
+def test_gpu_reduce_shards_sum_and_max():
+    """Local half of the view-parallel exchange (r3dgs_reduce_shards): fp32 SUM below sum_len, int32 MAX above, for a
+    shard that straddles the boundary -- against torch, bit for bit (same rank order of the additions)."""
+    from diff_gaussian_rasterization import _C
+    world, shard = 8, 1000
+    g = torch.Generator().manual_seed(3)
+    for begin, sum_len in ((0, 5000), (3 * shard, 3 * shard + 417), (5 * shard, 4000)):
+        recv = torch.randn(world, shard, generator=g)
+        n_sum = min(max(sum_len - begin, 0), shard)
+        ints = torch.randint(0, 500, (world, shard - n_sum), generator=g, dtype=torch.int32)
+        recv[:, n_sum:] = ints.view(torch.float32)
+        out = torch.empty(shard, device="cuda")
+        _C.reduce_shards(recv.cuda().contiguous().view(-1), world, begin, sum_len, out)
+        acc = recv[0, :n_sum].clone()
+        for w in range(1, world):
+            acc += recv[w, :n_sum]
+        assert torch.equal(out[:n_sum].cpu(), acc)
+        assert torch.equal(out[n_sum:].cpu().view(torch.int32), ints.amax(0))
