@@ -322,6 +322,7 @@ def test_gpu_pack_view_stats_and_exchange_pack():
 def test_gpu_reduce_shards_sum_and_max():
     """Local half of the view-parallel exchange (r3dgs_reduce_shards): fp32 SUM below sum_len, int32 MAX above, for a
     shard that straddles the boundary -- against torch, bit for bit (same rank order of the additions)."""
+    import torch
     from diff_gaussian_rasterization import _C
     world, shard = 8, 1000
     g = torch.Generator().manual_seed(3)
