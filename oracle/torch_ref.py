@@ -3,8 +3,10 @@
 TEST INFRASTRUCTURE ONLY.  Purpose: an independent, differentiable statement of the
 forward maths whose fp64 autograd gradients pin the C oracle's
 hand-written backward (oracle/raster_oracle.c, which follows DGR/cuda_rasterizer/backward.cu).
-It evaluates every (pixel, Gaussian) pair densely -- O(N*P) memory -- so keep P <= ~2000 and
-images <= ~64x64.  It is also the "PyTorch CPU autograd reference render" BASELINE.md names.
+The default path evaluates every (pixel, Gaussian) pair densely -- O(N*P) memory -- so keep P <= ~2000 and
+images <= ~64x64 there; `tiled=True` blends tile by tile against each tile's own Gaussians (same arithmetic), which
+is what makes it usable as the "PyTorch CPU autograd reference render" BASELINE.json configs[0] names
+(10k Gaussians, 400x400: about a second per pass) -- bench.py times that as `cpu_baseline`.
 
 Reference quirks reproduced on purpose (so that autograd == the reference's analytic backward):
   * alpha = min(0.99, o*G) is straight-through in the backward (backward.cu:537,576);
@@ -46,7 +48,7 @@ def quat_to_R(q):
 
 def render(means3D, opacity_raw, scales, rotations, sh, degrees, viewmatrix, projmatrix, campos, bg,
            W, H, tan_fovx, tan_fovy, scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None,
-           lambda_sh_sparsity=0.0):
+           lambda_sh_sparsity=0.0, tiled=False):
     """Returns (color[3,H,W], radii[P], sh_sparsity_loss).  All float tensors share one dtype
     (use float64 for gradient ground truth).  `viewmatrix`/`projmatrix` are the transposed
     (row-vector) matrices exactly as the reference passes them."""
@@ -129,30 +131,47 @@ def render(means3D, opacity_raw, scales, rotations, sh, degrees, viewmatrix, pro
     depth32 = t[:, 2].detach().to(torch.float32)
     order = torch.sort(depth32, stable=True).indices
     order = order[vis[order]]
+    geo = dict(mx=mx, my=my, cA=cA, cB=cB, cC=cC, o=o, rgb=rgb, rminx=rminx, rminy=rminy, rmaxx=rmaxx, rmaxy=rmaxy)
+    if tiled:
+        # Tile by tile, each tile against the Gaussians whose rect covers it (what the binning hands the blend kernel):
+        # O(256 * n_tile) work per tile instead of O(N * P), which makes BASELINE.json configs[0] (10k Gaussians,
+        # 400x400) tractable on a CPU.  Same arithmetic as the dense path.
+        out = torch.empty(H, W, 3, dtype=dt)
+        ro_x0, ro_x1, ro_y0, ro_y1 = rminx[order], rmaxx[order], rminy[order], rmaxy[order]
+        for ty in range(gy):
+            rows = (ro_y0 <= ty) & (ro_y1 > ty)
+            for tx in range(gx):
+                g = order[rows & (ro_x0 <= tx) & (ro_x1 > tx)]
+                y0, y1, x0, x1 = ty * TILE, min(H, (ty + 1) * TILE), tx * TILE, min(W, (tx + 1) * TILE)
+                ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
+                out[y0:y1, x0:x1] = _blend(xs.reshape(-1), ys.reshape(-1), g, geo, bg, dt).reshape(y1 - y0, x1 - x0, 3)
+        return out.permute(2, 0, 1), radii, sparsity
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    px, py = xs.reshape(-1).to(dt), ys.reshape(-1).to(dt)
-    tx_pix, ty_pix = (xs.reshape(-1) // TILE), (ys.reshape(-1) // TILE)
-    g = order
-    in_rect = ((tx_pix[:, None] >= rminx[g][None, :]) & (tx_pix[:, None] < rmaxx[g][None, :]) &
-               (ty_pix[:, None] >= rminy[g][None, :]) & (ty_pix[:, None] < rmaxy[g][None, :]))
-    dx = mx[g][None, :] - px[:, None]
-    dy = my[g][None, :] - py[:, None]
-    power = -0.5 * (cA[g][None, :] * dx * dx + cC[g][None, :] * dy * dy) - cB[g][None, :] * dx * dy
+    out = _blend(xs.reshape(-1), ys.reshape(-1), order, geo, bg, dt)
+    return out.t().reshape(3, H, W), radii, sparsity
+
+
+def _blend(xs, ys, g, geo, bg, dt):
+    """Front-to-back alpha blend of the pixels (xs, ys) over the depth-ordered Gaussians g -> [n_pix, 3]."""
+    px, py = xs.to(dt), ys.to(dt)
+    tx_pix, ty_pix = xs // TILE, ys // TILE
+    in_rect = ((tx_pix[:, None] >= geo["rminx"][g][None, :]) & (tx_pix[:, None] < geo["rmaxx"][g][None, :]) &
+               (ty_pix[:, None] >= geo["rminy"][g][None, :]) & (ty_pix[:, None] < geo["rmaxy"][g][None, :]))
+    dx = geo["mx"][g][None, :] - px[:, None]
+    dy = geo["my"][g][None, :] - py[:, None]
+    power = -0.5 * (geo["cA"][g][None, :] * dx * dx + geo["cC"][g][None, :] * dy * dy) - geo["cB"][g][None, :] * dx * dy
     G = torch.exp(torch.clamp(power, max=0.0))
-    araw = o[g][None, :] * G
+    araw = geo["o"][g][None, :] * G
     alpha = araw + (torch.clamp(araw, max=0.99) - araw).detach()  # straight-through min(0.99, .)
     valid = in_rect & (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
     a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
     one_m = 1.0 - a_eff
     Tincl = torch.cumprod(one_m, dim=1)
-    Texcl = torch.cat([torch.ones(Tincl.shape[0], 1, dtype=dt), Tincl[:, :-1]], 1)
     stop = (torch.cumsum((valid & (Tincl.detach() < 1e-4)).to(torch.int64), dim=1) > 0)
     a_fin = torch.where(stop, torch.zeros_like(a_eff), a_eff)
     Tincl2 = torch.cumprod(1.0 - a_fin, dim=1)
     Texcl2 = torch.cat([torch.ones(Tincl2.shape[0], 1, dtype=dt), Tincl2[:, :-1]], 1)
     w = a_fin * Texcl2
-    C = w @ rgb[g]
+    C = w @ geo["rgb"][g]
     Tend = Tincl2[:, -1] if Tincl2.shape[1] else torch.ones(px.shape[0], dtype=dt)
-    out = C + Tend[:, None] * bg.to(dt)[None, :]
-    del Texcl
-    return out.t().reshape(3, H, W), radii, sparsity
+    return C + Tend[:, None] * bg.to(dt)[None, :]

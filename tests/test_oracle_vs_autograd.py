@@ -167,3 +167,36 @@ def test_empty_and_all_culled_inputs():
                       g["sh"], g["degrees"], cam.camera_center)
     assert out["num_rendered"] == 0 and (out["radii"] == 0).all()
     np.testing.assert_array_equal(out["color"], np.broadcast_to(bg[:, None, None], (3, 32, 32)))
+
+
+def test_tiled_torch_reference_equals_dense_and_matches_oracle():
+    """oracle/torch_ref.py render(tiled=True) -- the configs[0] "PyTorch CPU autograd reference render" bench.py times as
+    cpu_baseline -- is the dense statement evaluated tile by tile: identical image and gradients, and the C oracle's
+    image within fp32 rounding."""
+    W, H, P = 70, 45, 400
+    cam = ss.make_camera(W, H, 60.0, 3)
+    g = ss.make_gaussians(P, cam, seed=9, degree_mode="mixed", scale_mu=0.12, scale_sigma=0.5)
+    bg = np.array([0.2, 0.1, 0.4], np.float32)
+    dl = torch.tensor(ss.upstream_grad(W, H, seed=4) * (W * H), dtype=DT)
+
+    def run(tiled):
+        leaves = dict(m3=T(g["means3D"]), op=T(g["opacity"]), sc=T(g["scales"]), rot=T(g["rotations"]), sh=T(g["sh"]))
+        for v in leaves.values():
+            v.requires_grad_()
+        color, radii, _ = tr.render(leaves["m3"], leaves["op"], leaves["sc"], leaves["rot"], leaves["sh"],
+                                    torch.tensor(g["degrees"]), T(cam.world_view_transform), T(cam.full_proj_transform),
+                                    T(cam.camera_center), T(bg), W, H, cam.tanfovx, cam.tanfovy, tiled=tiled)
+        (color * dl).sum().backward()
+        return color.detach(), radii, {k: v.grad.clone() for k, v in leaves.items()}
+
+    c0, r0, g0 = run(False)
+    c1, r1, g1 = run(True)
+    assert torch.equal(r0, r1)
+    assert float((c0 - c1).abs().max()) < 1e-12
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-10 * (float(g0[k].abs().max()) + 1e-30), k
+    ref = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
+                      cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"],
+                      g["degrees"], cam.camera_center, want_ambig=True)
+    ok = ref["ambig"].reshape(-1) == 0
+    assert np.abs(c1.numpy().reshape(3, -1) - ref["color"].reshape(3, -1))[:, ok].max() < 2e-5
