@@ -64,7 +64,7 @@ STAGE_KERNELS = {
                      ("r3::radix_scatter_kernel<unsigned int, 7>", 2, False),
                      ("r3::radix_hist_kernel<unsigned int>", 1, False),
                      ("r3::tile_ranges_kernel<unsigned int>", 1, True)],
-    "blend_fwd": [("r3::blend_fwd_kernel<2, false>", 1, True)],
+    "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
     "blend_bwd": [("r3::blend_bwd_kernel<4>", 1, True), ("r3::pair_reduce_kernel", 1, False)],
     "preprocess_bwd": [("r3::preprocess_bwd_kernel", 1, False)],
 }

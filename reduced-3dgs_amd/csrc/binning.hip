@@ -184,8 +184,12 @@ __device__ __forceinline__ uint32_t upper_bound_wave(const uint32_t* __restrict_
     return m ? lo + (uint32_t)__builtin_ctzll(m) : hi;
 }
 
+// One logical block = kEmitPerBlock consecutive output slots.  The pair-sized kernels are launched with about as many
+// workgroups as the pair count of recent passes needs (FwdPlan::grid_pairs) and stride over the logical blocks: sizing
+// the grid by the reservation left a third of the workgroups with nothing to do but three dependent loads to find that
+// out (+10 us on the backward's segmented sum alone).
 template <class Word>
-__global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restrict__ ap)
+__device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, uint32_t blk)
 {
     __shared__ uint32_t s_hist[kMaxRadixBins];   // first radix digit of the tile sort, counted while emitting
     __shared__ uint32_t s_end[kEmitSlice];
@@ -193,14 +197,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
     __shared__ ushort4 s_rect[kEmitSlice];
     __shared__ uint32_t s_j[2];
     __shared__ uint32_t s_start0;
-    const EmitArgs a = *ap;
-    const uint32_t R = a.hdr->num_pairs;
     const int bins = 1 << a.digit_bits;
-    // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
-    // by a fill of its own on the stream
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.n_tiles; t += gridDim.x * 256u) a.ranges[t] = make_uint2(0u, 0u);
-    const uint32_t pos0 = blockIdx.x * (uint32_t)kEmitPerBlock;
-    if (pos0 >= R) return;   // the grid covers the reservation
+    const uint32_t pos0 = blk * (uint32_t)kEmitPerBlock;
     if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
     const uint32_t* __restrict__ offsets = a.offsets;
     const uint32_t pos1 = min(R, pos0 + (uint32_t)kEmitPerBlock);  // exclusive
@@ -252,7 +250,21 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < bins) a.radix_rows[(size_t)threadIdx.x * a.row_stride + blockIdx.x] = s_hist[threadIdx.x];
+    if ((int)threadIdx.x < bins) a.radix_rows[(size_t)threadIdx.x * a.row_stride + blk] = s_hist[threadIdx.x];
+}
+
+template <class Word>
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restrict__ ap)
+{
+    const EmitArgs a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    // the tile ranges start out as (0, 0) (rasterizer_impl.cu:475 memset): cleared here, ahead of the sort, instead of
+    // by a fill of its own on the stream
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.n_tiles; t += gridDim.x * 256u) a.ranges[t] = make_uint2(0u, 0u);
+    for (uint32_t blk = blockIdx.x; blk * (uint32_t)kEmitPerBlock < R; blk += gridDim.x) {
+        emit_pairs_block<Word>(a, R, blk);
+        __syncthreads();
+    }
 }
 
 // ---- tile sort of the packed pair words: LSD radix -------------------------------------------------------------------
@@ -263,13 +275,10 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
 // running per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the passes give the tile-major
 // order with the emission (depth) order preserved inside a tile.
 template <class Word>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const RadixArgs* __restrict__ ap)
+__device__ __forceinline__ void radix_hist_block(const RadixArgs& a, uint32_t R, uint32_t blk)
 {
     __shared__ uint32_t s_hist[kMaxRadixBins];
-    const RadixArgs a = *ap;
-    const uint32_t R = a.hdr->num_pairs;
-    const uint32_t base = blockIdx.x * (uint32_t)kRadixBlock;
-    if (base >= R) return;
+    const uint32_t base = blk * (uint32_t)kRadixBlock;
     const int bins = 1 << a.digit_bits;
     if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -280,7 +289,18 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const RadixArgs* __rest
         if (i < R) atomicAdd(&s_hist[(uint32_t)(in[i] >> a.shift) & (uint32_t)(bins - 1)], 1u);
     }
     __syncthreads();
-    if ((int)threadIdx.x < bins) a.rows[(size_t)threadIdx.x * a.row_stride + blockIdx.x] = s_hist[threadIdx.x];
+    if ((int)threadIdx.x < bins) a.rows[(size_t)threadIdx.x * a.row_stride + blk] = s_hist[threadIdx.x];
+}
+
+template <class Word>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const RadixArgs* __restrict__ ap)
+{
+    const RadixArgs a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    for (uint32_t blk = blockIdx.x; blk * (uint32_t)kRadixBlock < R; blk += gridDim.x) {
+        radix_hist_block<Word>(a, R, blk);
+        __syncthreads();
+    }
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-workgroup counts, and the digit total
@@ -310,15 +330,12 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(const RadixArgs* 
 // (Materialising point_list[pos] = order[rank] here in the last pass was measured: the dependent gather lengthens this
 // kernel by 19 us and saves 13 us in tile_ranges_kernel, so it stays there.)
 template <class Word, int BITS>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __restrict__ ap)
+__device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t R, uint32_t blk_id)
 {
     constexpr int kWaves = 4, kRounds = kRadixBlock / 256, kBins = 1 << BITS;
     __shared__ uint32_t s_wcount[kWaves][kBins];   // running per-wave digit counts
     __shared__ uint32_t s_start[kBins];            // exclusive scan of the digit totals
     __shared__ uint32_t s_off[kWaves][kBins];      // digit start + workgroup base + waves below
-    const RadixArgs a = *ap;
-    const uint32_t R = a.hdr->num_pairs;
-    if (blockIdx.x * (uint32_t)kRadixBlock >= R) return;
     const Word* __restrict__ in = reinterpret_cast<const Word*>(a.in);
     Word* __restrict__ out = reinterpret_cast<Word*>(a.out);
     const int shift = a.shift;
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __r
         }
     }
     __syncthreads();
-    const uint32_t blk = blockIdx.x * (uint32_t)kRadixBlock + (uint32_t)w * (kRadixBlock / kWaves);
+    const uint32_t blk = blk_id * (uint32_t)kRadixBlock + (uint32_t)w * (kRadixBlock / kWaves);
     Word key[kRounds];
     uint32_t lrank[kRounds];
 #pragma unroll
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __r
     }
     __syncthreads();
     for (int d = threadIdx.x; d < kBins; d += 256) {
-        uint32_t run = s_start[d] + a.base[(size_t)d * a.row_stride + blockIdx.x];
+        uint32_t run = s_start[d] + a.base[(size_t)d * a.row_stride + blk_id];
 #pragma unroll
         for (int k = 0; k < kWaves; k++) {
             s_off[k][d] = run;
@@ -384,6 +401,17 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __r
     }
 }
 
+template <class Word, int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __restrict__ ap)
+{
+    const RadixArgs a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    for (uint32_t blk = blockIdx.x; blk * (uint32_t)kRadixBlock < R; blk += gridDim.x) {
+        radix_scatter_block<Word, BITS>(a, R, blk);
+        __syncthreads();
+    }
+}
+
 // rasterizer_impl.cu:124-146 identifyTileRanges on the sorted words; the Gaussian ids (the low bits of the words)
 // are split off into point_list here too.
 template <class Word>
@@ -391,8 +419,9 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __re
 {
     const RangesArgs a = *ap;
     const int R = (int)a.hdr->num_pairs;
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
-    if (i0 >= R) return;
+  for (int blk = (int)blockIdx.x; blk * 1024 < R; blk += (int)gridDim.x) {
+    const int i0 = (blk * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
+    if (i0 >= R) continue;
     const Word* __restrict__ sorted = reinterpret_cast<const Word*>(a.sorted);
     unsigned char* __restrict__ pair_flag = a.pair_flag;
     uint32_t* __restrict__ point_list = a.point_list;
@@ -428,13 +457,14 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __re
         if (i == R - 1) ranges[cur].y = R;
         prev = cur;
     }
+  }
 }
 
 template <class Word>
 static void issue_tile_binning_t(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
 {
     const PairLayout& l = p.layout;
-    const uint32_t nbk = (p.reserve + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // == row_stride
+    const uint32_t nbk = (p.grid_pairs + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // <= row_stride; blocks stride
     const int bins = 1 << l.digit_bits;
     hipLaunchKernelGGL(emit_pairs_kernel<Word>, dim3(nbk), dim3(256), 0, s, &a->emit);
     for (int k = 0; k < l.passes; k++) {
@@ -446,7 +476,7 @@ static void issue_tile_binning_t(const FwdPlan& p, const FwdPassArgs* a, hipStre
         else
             hipLaunchKernelGGL((radix_scatter_kernel<Word, 8>), dim3(nbk), dim3(256), 0, s, ra);
     }
-    hipLaunchKernelGGL(tile_ranges_kernel<Word>, dim3((p.reserve + 1023u) / 1024u), dim3(256), 0, s, &a->ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel<Word>, dim3((p.grid_pairs + 1023u) / 1024u), dim3(256), 0, s, &a->ranges);
 }
 
 void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)

@@ -482,6 +482,7 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     p.gx = (c.width + kTile - 1) / kTile;
     p.gy = (c.height + kTile - 1) / kTile;
     p.reserve = reserve;
+    p.grid_pairs = grid_pairs_for(reserve);
     p.layout = pair_layout(c.P, (size_t)p.gx * p.gy);
     p.nb = depth_bucket_count((size_t)c.P);
     p.ragged = (c.coeffsNum != nullptr && !c.colors_precomp) ? 1 : 0;
@@ -694,6 +695,7 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     const uint32_t R = info->num_rendered;
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
     plan.reserve = R ? R : 1u;
+    plan.grid_pairs = plan.reserve;   // exact size: one block per chunk
     char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide), binning_user);
     if (!bptr) throw Error("binning allocator returned NULL");
     BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide);
@@ -1020,6 +1022,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         // R: the pair capacity the forward carved the binning blob with (num_rendered of an exact-size forward, the
         // reservation of a reserved one); the pair count itself is read from the device header
         plan.reserve = R > 0 ? (uint32_t)R : 1u;
+        plan.grid_pairs = grid_pairs_for(plan.reserve);
         plan.has_pairs = binning_buffer != nullptr ? 1 : 0;
         const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));

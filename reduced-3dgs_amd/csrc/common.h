@@ -271,6 +271,16 @@ size_t required_bytes(A... a)
 // temp-storage query of the generic (rocPRIM) depth sort (binning.hip); needs a visible GPU
 size_t depth_sort_temp_bytes(size_t P);
 
+// Launch size of the pair-sized kernels for a binning blob of `reserve` pairs: the reservation is ~1.5x the largest
+// recent pair count plus a constant (capi.hip reserve_hint), the grids cover that count with a little headroom and
+// their blocks stride over whatever lies beyond.  A function of `reserve` alone, so forward, backward and the graph
+// cache agree on it.
+inline uint32_t grid_pairs_for(uint32_t reserve)
+{
+    const uint64_t g = (uint64_t)reserve * 7 / 10;
+    return (uint32_t)(g < 1024 ? (reserve < 1024 ? reserve : 1024) : g);
+}
+
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
@@ -502,6 +512,8 @@ static_assert(sizeof(FwdPassArgs) <= 3072 && sizeof(BwdPassArgs) <= 3072, "pass 
 struct FwdPlan {
     int P, M, W, H, gx, gy;
     uint32_t reserve;      // pair capacity the binning blob was carved with (>= 1)
+    uint32_t grid_pairs;   // pairs the pair-sized grids are launched for (their blocks stride beyond it): the pair count
+                           // the reservation was derived from, without its slack
     PairLayout layout;
     int nb;                // depth buckets
     int ragged, counters;  // ragged SH addressing; counter mode (calculate_mean_transmittance)
@@ -513,7 +525,7 @@ struct FwdPlan {
 };
 struct BwdPlan {
     int P, M, W, H, gx, gy;
-    uint32_t reserve;
+    uint32_t reserve, grid_pairs;
     PairLayout layout;
     int bwd_ppl;
     int has_pairs;         // 0: the forward ran with an empty reservation (P > 0, no binning blob)

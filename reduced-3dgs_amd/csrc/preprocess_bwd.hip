@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
 {
     const PairReduceArgs a = *ap;
     const uint32_t R = a.hdr->num_pairs;
-    if (blockIdx.x * 256u >= R) return;   // the grid covers the reservation, not the actual pair count
+  for (uint32_t blk = blockIdx.x; blk * 256u < R; blk += gridDim.x) {   // logical blocks strided over the grid (common.h)
     const float* __restrict__ pair_grad = a.pair_grad;
     unsigned char* __restrict__ pair_flag = a.pair_flag;
     const uint32_t* __restrict__ pair_gid = a.pair_rank;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
     const uint32_t* __restrict__ tiles = a.tiles;
     float* __restrict__ acc = a.acc;
     float* __restrict__ wave_part = a.wave_part;
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t e = blk * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = e < R;
     float v[kPairGrad];
@@ -72,16 +72,29 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
             v[8] = pair_grad[(size_t)e * kPairStride + 8];
         }
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {  // inclusive segmented scan over equal-key runs
-        const uint32_t ku = (uint32_t)__shfl_up((int)key, d);
-        const bool take = lane >= d && ku == key;
-#pragma unroll
-        for (int k = 0; k < kPairGrad; k++) {
-            const float vu = __shfl_up(v[k], d);
-            if (take) v[k] += vu;
-        }
+    // Inclusive segmented scan over equal-key runs, on DPP (VALU) moves only: Kogge-Stone inside each row of 16 lanes
+    // (row_shr 1, 2, 4, 8), then the classic row_bcast:15 / row_bcast:31 pair carries the row totals across -- valid
+    // for a SEGMENTED scan because runs are contiguous: a lane shares the key of the broadcast lane iff its run reaches
+    // back to it.  The first version went through ds_bpermute (60 LDS-pipe instructions per wave: 61% issue stall).
+    // A lane without a source keeps `old`: ~key for the key (never equal), so it takes nothing.
+#define R3_SEG_STEP(CTRL, RMASK)                                                                                          \
+    {                                                                                                                     \
+        const uint32_t ku = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, CTRL, RMASK, 0xf, false);          \
+        const bool take = ku == key;                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < kPairGrad; k++)                                                             \
+        {                                                                                                                 \
+            const float vu = __builtin_bit_cast(                                                                          \
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), CTRL, RMASK, 0xf, false));           \
+            if (take) v[k] += vu;                                                                                         \
+        }                                                                                                                 \
     }
+    R3_SEG_STEP(0x111, 0xf)   // row_shr:1
+    R3_SEG_STEP(0x112, 0xf)   // row_shr:2
+    R3_SEG_STEP(0x114, 0xf)   // row_shr:4
+    R3_SEG_STEP(0x118, 0xf)   // row_shr:8
+    R3_SEG_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1 and 3
+    R3_SEG_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2 and 3
+#undef R3_SEG_STEP
     const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
     if (valid && (lane == 63 || knext != key)) {  // last lane of a run: holds the run's sum inside this group
         const uint32_t gid = order ? order[key] : key;
@@ -102,12 +115,13 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
             }
         }
     }
+  }
 }
 
 void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
 {
     if (!p.has_pairs) return;
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.reserve + 255u) / 256u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.grid_pairs + 255u) / 256u), dim3(256), 0, s, a);
 }
 
 __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
@@ -130,7 +144,32 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     const bool wave_vis = __ballot(vis) != 0ull;
     if (has_sh && wave_vis) {
         const float* src = a.in.shs + span_first;
-        for (int e = lane; e < span_len; e += 64) lds[bskew(e)] = src[e];
+        if (((span_first | span_len) & 3) == 0) {   // 16-B aligned span (always for M = 16): dwordx4 loads, six in
+            const float4* src4 = reinterpret_cast<const float4*>(src);   // flight before the first LDS store (twelve, as in
+            const int n4 = span_len >> 2;                                // the forward's colour kernel, cost a wave of occupancy)
+            constexpr int kBatch = 6;
+            for (int base = 0; base < n4; base += 64 * kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const int e4 = base + k * 64 + lane;
+                    v[k] = e4 < n4 ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    const int e4 = base + k * 64 + lane;
+                    if (e4 < n4) {
+                        const int e = e4 << 2;
+                        lds[bskew(e)] = v[k].x;
+                        lds[bskew(e + 1)] = v[k].y;
+                        lds[bskew(e + 2)] = v[k].z;
+                        lds[bskew(e + 3)] = v[k].w;
+                    }
+                }
+            }
+        } else {
+            for (int e = lane; e < span_len; e += 64) lds[bskew(e)] = src[e];
+        }
     }
     __syncthreads();
 
@@ -207,7 +246,18 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     __syncthreads();
     if (has_sh) {
         float* dst = a.out.dL_dsh + span_first;
-        if (wave_vis) {
+        if (((span_first | span_len) & 3) == 0) {   // dwordx4 stores of the gradient rows (or of zeros)
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            const int n4 = span_len >> 2;
+            if (wave_vis) {
+                for (int e4 = lane; e4 < n4; e4 += 64) {
+                    const int e = e4 << 2;
+                    dst4[e4] = make_float4(lds[bskew(e)], lds[bskew(e + 1)], lds[bskew(e + 2)], lds[bskew(e + 3)]);
+                }
+            } else {
+                for (int e4 = lane; e4 < n4; e4 += 64) dst4[e4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (wave_vis) {
             for (int e = lane; e < span_len; e += 64) dst[e] = lds[bskew(e)];
         } else {
             for (int e = lane; e < span_len; e += 64) dst[e] = 0.f;

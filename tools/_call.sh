@@ -1,7 +1,6 @@
 set -u
 export PYTHONPATH=$PWD:$PWD/reduced-3dgs_amd TMPDIR=/tmp
-ROOT=$PWD
-for wl in garden_like_2M_1600x1062 train_like_6M_1920x1080; do
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$wl -o r -- python $ROOT/bench.py --workload $wl --steps 6 --warmup 2 --cameras 2 --no-cpu-baseline ) > gpurun_out/prof_$wl.log 2>&1; echo "prof $wl rc=$?"
-f=$(find gpurun_out/prof_$wl -name "*kernel_stats.csv" | head -1); head -24 "$f" | cut -d, -f1,2,4 | cut -c1-150
-done
+SMOKE=1 TESTS=1 BENCH=1 PROF=1 T_TEST=900 STEPS=20 PMC="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES;SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS;FETCH_SIZE;WRITE_SIZE" bash tools/gpu_round.sh > gpurun_out/round.log 2>&1
+python tools/pmc_summary.py > gpurun_out/pmc_summary.log 2>&1
+echo "=== dry run 2 ranks"; timeout 300 python tools/dryrun_2rank.py 2>&1 | tail -3 | cut -c1-1500
+tail -30 gpurun_out/round.log | cut -c1-400
