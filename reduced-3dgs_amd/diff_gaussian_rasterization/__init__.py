@@ -9,10 +9,12 @@ function `_RasterizeGaussians` (:21-167), plus the `_C` operator module.
 Put `reduced-3dgs_amd/` on PYTHONPATH (before or instead of the CUDA submodule) to switch a reference
 checkout over.  Behavioural notes:
   * the reference hard-codes debug=True in the forward call (:85), i.e. a device synchronisation after
-    every stage; here `raster_settings.debug` is honoured (False => fully asynchronous except for the one
-    structural read-back of num_rendered);
-  * gradients of one forward are deterministic up to the order of one float atomic per
-    (tile, Gaussian, component) -- the reference issues one per (pixel, Gaussian, component).
+    every stage; here `raster_settings.debug` is honoured.  debug=False (what render() passes) takes the
+    asynchronous path: nothing waits for num_rendered, a pass is one hipGraph launch, and `ctx.num_rendered`
+    is an int-like `_C.NumRendered` that is only fetched from the device if somebody looks at it;
+    debug=True takes the exact-size path with a synchronisation after every stage;
+  * gradients are bit-reproducible: the backward has no float atomics (the reference issues one per
+    (pixel, Gaussian, component), so its low bits depend on scheduling).
 """
 from typing import NamedTuple
 
