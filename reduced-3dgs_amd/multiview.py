@@ -127,7 +127,13 @@ class ViewParallelExchange:
         if self.world == 1:
             return
         if self.two_phase:
-            dist.all_to_all_single(self.recv, flat)
+            try:
+                dist.all_to_all_single(self.recv, flat)
+            except (RuntimeError, NotImplementedError) as e:   # a backend without all-to-all: plain all-reduces from now on
+                import warnings
+                warnings.warn(f"view-parallel exchange: all_to_all_single unavailable ({e}); using all_reduce")
+                self.two_phase = False
+                return self._run(k)
             self._combine()
             dist.all_gather_into_tensor(flat, self.mine)
         else:
