@@ -53,70 +53,15 @@ void run_generic_depth_sort(int P, GeomState& g, hipStream_t s)
 }
 
 // ---- per-view header ----------------------------------------------------------------------------------------------
-// Sum / max of the preprocess workgroups' partials by one workgroup of 1024 threads (s_red: 16 x 4 words).
-__device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
-{
-    PrePartial acc = {0u, 0u, 0u, 0u};
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint4 v = reinterpret_cast<const uint4*>(parts)[i];
-        acc.visible += v.x;
-        acc.num_rendered += v.y;
-        acc.depth_max = max(acc.depth_max, v.z);
-        acc.depth_inv_min = max(acc.depth_inv_min, v.w);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        acc.visible += (uint32_t)__shfl_xor((int)acc.visible, off);
-        acc.num_rendered += (uint32_t)__shfl_xor((int)acc.num_rendered, off);
-        acc.depth_max = max(acc.depth_max, (uint32_t)__shfl_xor((int)acc.depth_max, off));
-        acc.depth_inv_min = max(acc.depth_inv_min, (uint32_t)__shfl_xor((int)acc.depth_inv_min, off));
-    }
-    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_red[w][0] = acc.visible;
-        s_red[w][1] = acc.num_rendered;
-        s_red[w][2] = acc.depth_max;
-        s_red[w][3] = acc.depth_inv_min;
-    }
-    __syncthreads();
-    PrePartial out = {0u, 0u, 0u, 0u};
-    for (int k = 0; k < nw; k++) {
-        out.visible += s_red[k][0];
-        out.num_rendered += s_red[k][1];
-        out.depth_max = max(out.depth_max, s_red[k][2]);
-        out.depth_inv_min = max(out.depth_inv_min, s_red[k][3]);
-    }
-    __syncthreads();
-    return out;
-}
-
-// One workgroup turns the preprocess partials into the device header every later kernel reads (visible count,
-// num_rendered, the pair count clamped to the reservation, depth range) and publishes num_rendered / visible in the
-// pass's host-mapped PassInfo slot: the host never has to wait for it, and when it wants it (exact-size path, lazy
-// statistics) it polls plain memory.
+// One workgroup turns the preprocess partials into the device header (depth_sort.h write_header).  Used by the
+// exact-size path, whose host waits for num_rendered between the geometry kernel and everything else; the asynchronous
+// path lets the histogram workgroups do it (DepthArgs::fuse_header).
 __global__ __launch_bounds__(1024) void header_reduce_kernel(const HeaderArgs* __restrict__ ap)
 {
     __shared__ uint32_t s_red[16][4];
     const HeaderArgs a = *ap;
     const PrePartial all = reduce_partials(a.parts, a.n_parts, s_red);
-    if (threadIdx.x == 0) {
-        GeomHeader* hdr = a.hdr;
-        hdr->visible = all.visible;
-        hdr->num_rendered = all.num_rendered;
-        hdr->depth_max = all.depth_max;
-        hdr->depth_inv_min = all.depth_inv_min;
-        hdr->num_pairs = min(all.num_rendered, a.reserve);
-        hdr->reserve = a.reserve;
-        hdr->sort_overflow = 0u;
-        volatile PassInfo* info = a.info;
-        if (info) {
-            info->num_rendered = all.num_rendered;
-            info->visible = all.visible;
-            info->reserve = a.reserve;
-            info->sort_overflow = 0u;
-            __threadfence_system();
-            info->seq = a.ticket;
-        }
-    }
+    if (threadIdx.x == 0) write_header(a, all);
 }
 
 void issue_header_reduce(const HeaderArgs* a, hipStream_t s)

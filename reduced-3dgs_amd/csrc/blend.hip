@@ -294,10 +294,13 @@ constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 // 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
 // (0.5174 vs 0.5170 ms): occupancy is not what limits this kernel.
 template <int PPL>
-__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(const BlendBwdArgs* __restrict__ ap)
+__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
-    const BlendBwdArgs a = *ap;
+    // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from
+    // the kernarg segment
+    if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, 64);
+    const BlendBwdArgs a = v.blend;
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -419,12 +422,11 @@ __global__ __launch_bounds__(64, 5) void blend_bwd_kernel(const BlendBwdArgs* __
     }
 }
 
-void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s)
+void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
 {
-    if (!p.has_pairs) return;
     // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
-    const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == a->nblocks
-    hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, a);
+    const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == v.blend.nblocks
+    hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, dst, v);
 }
 
 }  // namespace r3

@@ -284,6 +284,7 @@ struct GraphCtx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipGraphNode_t node0 = nullptr;
+    hipKernelNodeParams node0_params = {};
     uint64_t last_use = 0;
 };
 std::mutex g_ctx_mu;
@@ -334,15 +335,18 @@ struct NoHooks {
     void end(int, const char*, hipStream_t) {}
 };
 
-// phases: 1 = geometry + header (everything num_rendered depends on), 2 = the rest
+// phases: 1 = geometry (+ header: everything num_rendered depends on), 2 = the rest.  The geometry kernel installs the
+// pass block `args` at `d` for the kernels behind it; a caller that issues phase 2 on its own (exact-size path) writes
+// the completed block with write_args first.
 template <class Hooks>
-void issue_forward(const FwdPlan& p, const FwdPassArgs* d, hipStream_t s, int phases, Hooks& h, GeomState* g_host)
+void issue_forward(const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& args, hipStream_t s, int phases, Hooks& h,
+                   GeomState* g_host)
 {
     if (phases & 1) {
         h.begin(kPre, s);
-        issue_preprocess_geom(p, &d->pre, s);
+        issue_preprocess_geom(p, d, args, s);
         h.end(kPre, "preprocess", s);
-        issue_header_reduce(&d->header, s);
+        if (!args.depth.fuse_header) issue_header_reduce(&d->header, s);
     }
     if (phases & 2) {
         h.begin(kDepthSort, s);
@@ -365,14 +369,22 @@ void issue_forward(const FwdPlan& p, const FwdPassArgs* d, hipStream_t s, int ph
     }
 }
 
+template <class Block>
+void launch_write_args(Block* dst, const Block& v, hipStream_t s);
+
+// The backward blend installs the pass block; without pairs (empty reservation) it does not run and write_args does.
 template <class Hooks>
-void issue_backward(const BwdPlan& p, const BwdPassArgs* d, hipStream_t s, Hooks& h)
+void issue_backward(const BwdPlan& p, BwdPassArgs* d, const BwdPassArgs& args, hipStream_t s, Hooks& h)
 {
     h.begin(kBlendBwd, s);
     // the pair flags are all zero here: the forward's tile_ranges kernel clears them and pair_reduce puts every
     // flag it consumed back to zero, so neither pass pays for a fill of its own
-    issue_blend_backward(p, &d->blend, s);
-    issue_pair_reduce(p, &d->reduce, s);
+    if (p.has_pairs) {
+        issue_blend_backward(p, d, args, s);
+        issue_pair_reduce(p, &d->reduce, s);
+    } else {
+        launch_write_args(d, args, s);
+    }
     h.end(kBlendBwd, "blend backward", s);
     h.begin(kPreBwd, s);
     issue_preprocess_backward(p, &d->pre, s);
@@ -385,7 +397,10 @@ void launch_write_args(Block* dst, const Block& v, hipStream_t s)
     hipLaunchKernelGGL(write_args_kernel<Block>, dim3(1), dim3(256), 0, s, dst, v);
 }
 
-// Replays (capturing it first if this shape is new) the launch chain of a pass as one graph launch on `s`.
+// Replays (capturing it first if this shape is new) the launch chain of a pass as one graph launch on `s`.  Node 0 of
+// the chain is the kernel that receives (Block* dst, Block by value) and installs the block; on replay only its
+// arguments are refreshed (hipGraphExecKernelNodeSetParams copies them at the call, so a host running many passes
+// ahead cannot disturb launches that are still queued -- checked in tools/launch_bench2.hip with the GPU kept busy).
 template <class Block, class Plan, class IssueFn>
 void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStream_t s, IssueFn&& issue)
 {
@@ -397,8 +412,7 @@ void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStr
             hipStream_t cap = capture_stream(key.dev);
             R3_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
             try {
-                launch_write_args(static_cast<Block*>(c.d_args), args, cap);
-                issue(plan, static_cast<const Block*>(c.d_args), cap);
+                issue(plan, static_cast<Block*>(c.d_args), args, cap);
             } catch (...) {
                 hipGraph_t dead = nullptr;
                 (void)hipStreamEndCapture(cap, &dead);
@@ -410,6 +424,7 @@ void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStr
             R3_HIP(hipGraphGetRootNodes(c.graph, nullptr, &n_root));
             if (n_root != 1) throw Error("captured pass graph is not a linear chain");
             R3_HIP(hipGraphGetRootNodes(c.graph, &c.node0, &n_root));
+            R3_HIP(hipGraphKernelNodeGetParams(c.node0, &c.node0_params));
             R3_HIP(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
         } catch (...) {
             if (c.graph) (void)hipGraphDestroy(c.graph);
@@ -424,12 +439,7 @@ void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStr
     Block* dst = static_cast<Block*>(ctx.d_args);
     Block copy = args;
     void* params[2] = {&dst, &copy};
-    hipKernelNodeParams kp;
-    memset(&kp, 0, sizeof(kp));
-    kp.func = reinterpret_cast<void*>(write_args_kernel<Block>);
-    kp.gridDim = dim3(1);
-    kp.blockDim = dim3(256);
-    kp.sharedMemBytes = 0;
+    hipKernelNodeParams kp = ctx.node0_params;   // function, grid, block as captured
     kp.kernelParams = params;
     kp.extra = nullptr;
     R3_HIP(hipGraphExecKernelNodeSetParams(ctx.exec, ctx.node0, &kp));   // by-value block: copied at this call
@@ -500,7 +510,7 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
 }
 
 void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const GeomState& g, const BinState* b,
-                   const ImageState& img, PassInfo* info_dev, uint64_t ticket)
+                   const ImageState& img, PassInfo* info_dev, uint64_t ticket, bool fuse_header)
 {
     memset(&a, 0, sizeof(a));
     int* radii = c.radii ? c.radii : g.radii_internal;
@@ -548,6 +558,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     d.nb = p.nb;
     d.rows = (int)depth_hist_rows((size_t)c.P);
     d.per_block = (int)depth_hist_per_block((size_t)c.P);
+    d.fuse_header = fuse_header ? 1 : 0;
     d.key = g.depth_key;
     d.tiles = g.tiles;
     d.hdr = g.header;
@@ -687,9 +698,8 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     }
     StageRun hooks{c.debug != 0};
     FwdPassArgs args;
-    fill_fwd_args(args, plan, c, geom, nullptr, img, info_dev, ticket);
-    launch_write_args(d_args, args, s);
-    issue_forward(plan, d_args, s, 1, hooks, &geom);
+    fill_fwd_args(args, plan, c, geom, nullptr, img, info_dev, ticket, false);
+    issue_forward(plan, d_args, args, s, 1, hooks, &geom);
     // the one structural wait of this entry point (the reference's cudaMemcpy at rasterizer_impl.cu:446)
     const volatile PassInfo* info = wait_info(dev, ticket);
     const uint32_t R = info->num_rendered;
@@ -699,9 +709,9 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide), binning_user);
     if (!bptr) throw Error("binning allocator returned NULL");
     BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide);
-    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket);
-    launch_write_args(d_args, args, s);
-    issue_forward(plan, d_args, s, 2, hooks, &geom);
+    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, false);
+    launch_write_args(d_args, args, s);   // the completed block (binning pointers, pair capacity)
+    issue_forward(plan, d_args, args, s, 2, hooks, &geom);
     return (int)R;
 }
 
@@ -724,7 +734,8 @@ long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_
     PassInfo* info_dev = nullptr;
     const uint64_t ticket = new_ticket(dev, c, plan.reserve, &info_dev);
     FwdPassArgs args;
-    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket);
+    // the generic (rocPRIM) depth sort has no histogram kernel to carry the header reduction
+    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, !plan.generic_depth_sort);
     const bool direct = !graphs_enabled() || c.debug || plan.generic_depth_sort || (g_prof.mask.load() & kFwdStages);
     if (direct) {
         FwdPassArgs* d_args;
@@ -733,13 +744,12 @@ long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_
             d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
         }
         StageRun hooks{c.debug != 0};
-        launch_write_args(d_args, args, s);
-        issue_forward(plan, d_args, s, 3, hooks, &geom);
+        issue_forward(plan, d_args, args, s, 3, hooks, &geom);
     } else {
         const CtxKey key{dev, 0, s, c.P, c.M, c.width, c.height, plan.reserve, fwd_flags(plan, c)};
-        launch_graph(key, plan, args, s, [](const FwdPlan& p, const FwdPassArgs* d, hipStream_t cs) {
+        launch_graph(key, plan, args, s, [](const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& v, hipStream_t cs) {
             NoHooks nh;
-            issue_forward(p, d, cs, 3, nh, nullptr);
+            issue_forward(p, d, v, cs, 3, nh, nullptr);
         });
     }
     return (long long)ticket;
@@ -1104,14 +1114,13 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
                 d_args = static_cast<BwdPassArgs*>(direct_block(dev, 1, s, sizeof(BwdPassArgs)));
             }
             StageRun hooks{debug != 0};
-            launch_write_args(d_args, a, s);
-            issue_backward(plan, d_args, s, hooks);
+            issue_backward(plan, d_args, a, s, hooks);
         } else {
             const uint32_t flags = (uint32_t)plan.bwd_ppl | ((uint32_t)plan.has_pairs << 3) | ((uint32_t)plan.layout.wide << 4);
             const CtxKey key{dev, 1, s, P, M, width, height, plan.reserve, flags};
-            launch_graph(key, plan, a, s, [](const BwdPlan& p, const BwdPassArgs* d, hipStream_t cs) {
+            launch_graph(key, plan, a, s, [](const BwdPlan& p, BwdPassArgs* d, const BwdPassArgs& v, hipStream_t cs) {
                 NoHooks nh;
-                issue_backward(p, d, cs, nh);
+                issue_backward(p, d, v, cs, nh);
             });
         }
         return 0;

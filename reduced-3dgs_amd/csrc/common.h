@@ -394,6 +394,8 @@ struct HeaderArgs {       // binning.hip header_reduce_kernel
 };
 struct DepthArgs {        // depth_sort.h bucketed depth sort
     int P, nb, rows, per_block;
+    int fuse_header;      // 1: the histogram workgroups reduce the preprocess partials themselves and workgroup 0 writes
+                          // the header / PassInfo (no header_reduce launch in front: asynchronous path)
     const uint32_t* key;
     const uint32_t* tiles;
     GeomHeader* hdr;
@@ -537,7 +539,9 @@ struct BwdPlan {
 enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
 
 // ---- per-stage issue functions (one per translation unit).  `a` points INTO the device pass block. ----------------
-void issue_preprocess_geom(const FwdPlan& p, const PreArgs* a, hipStream_t s);
+// The first kernel of a pass also installs the pass block: it receives the block BY VALUE (its workgroups read their own
+// arguments straight from the kernarg segment) and workgroup 0 copies it to `dst` for the kernels that follow.
+void issue_preprocess_geom(const FwdPlan& p, FwdPassArgs* dst, const FwdPassArgs& v, hipStream_t s);
 void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
@@ -551,7 +555,7 @@ void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const G
                         hipStream_t s);
 
 void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s);
-void issue_blend_backward(const BwdPlan& p, const BlendBwdArgs* a, hipStream_t s);
+void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s);   // installs the block too
 void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s);
 void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_t s);
 
@@ -561,5 +565,22 @@ void launch_colour_variance_accumulate(int P, const int* D, int M, int max_sh_de
                                        float* variance, float* accum, hipStream_t s);
 
 int env_int(const char* env, int dflt, int lo, int hi);   // capi.hip
+
+#if defined(__HIPCC__)
+// Copies the pass block, which the calling kernel received as its SECOND by-value argument after a `Block* dst`, word by
+// word out of the kernarg segment to *dst (taking the parameter's address instead would spill it to scratch first).
+// Call from one workgroup; `nthreads` threads take part.
+template <class Block>
+__device__ __forceinline__ void install_block_from_kernarg(Block* dst, int tid, int nthreads)
+{
+    static_assert(alignof(Block) == 8 && sizeof(Block) % 4 == 0, "kernarg layout: [dst (8 B)][block]");
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t __attribute__((address_space(4))) * KernargWords;
+    KernargWords src = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(Block*) / 4;
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t k = (uint32_t)tid; k < sizeof(Block) / 4; k += (uint32_t)nthreads) d[k] = src[k];
+#endif
+}
+#endif
 
 }  // namespace r3

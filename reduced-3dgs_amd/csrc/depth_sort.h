@@ -95,13 +95,86 @@ inline size_t depth_hist_lds(int nb) { return (size_t)(nb + 1) * sizeof(unsigned
 inline size_t depth_scatter_lds(int nb) { return (size_t)2 * (nb + 2) * sizeof(uint32_t) + 256 * sizeof(unsigned long long); }
 constexpr size_t kBucketSortLds = (size_t)kBucketCap * 8 + 256 * 4 + (256 + 256 + 4 * 256 + 4) * 4;
 
-// (1) workgroup `wg` of depth_hist_rows(P): histogram of its per_block Gaussians, kHistBatch at a time
-__device__ inline void depth_hist_role(const DepthArgs& a, char* smem, int wg)
+// Sum / max of the preprocess workgroups' partials by one workgroup (s_red: 16 x 4 words).
+__device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
 {
+    PrePartial acc = {0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(parts)[i];
+        acc.visible += v.x;
+        acc.num_rendered += v.y;
+        acc.depth_max = max(acc.depth_max, v.z);
+        acc.depth_inv_min = max(acc.depth_inv_min, v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.visible += (uint32_t)__shfl_xor((int)acc.visible, off);
+        acc.num_rendered += (uint32_t)__shfl_xor((int)acc.num_rendered, off);
+        acc.depth_max = max(acc.depth_max, (uint32_t)__shfl_xor((int)acc.depth_max, off));
+        acc.depth_inv_min = max(acc.depth_inv_min, (uint32_t)__shfl_xor((int)acc.depth_inv_min, off));
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[w][0] = acc.visible;
+        s_red[w][1] = acc.num_rendered;
+        s_red[w][2] = acc.depth_max;
+        s_red[w][3] = acc.depth_inv_min;
+    }
+    __syncthreads();
+    PrePartial out = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < nw; k++) {
+        out.visible += s_red[k][0];
+        out.num_rendered += s_red[k][1];
+        out.depth_max = max(out.depth_max, s_red[k][2]);
+        out.depth_inv_min = max(out.depth_inv_min, s_red[k][3]);
+    }
+    __syncthreads();
+    return out;
+}
+
+// The device header every later kernel reads (visible count, num_rendered, the pair count clamped to the reservation,
+// depth range), and num_rendered / visible published in the pass's host-mapped PassInfo slot: the host never has to
+// wait for it, and when it wants it (exact-size path, lazy statistics) it polls plain memory.  One thread.
+__device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
+{
+    GeomHeader* hdr = a.hdr;
+    hdr->visible = all.visible;
+    hdr->num_rendered = all.num_rendered;
+    hdr->depth_max = all.depth_max;
+    hdr->depth_inv_min = all.depth_inv_min;
+    hdr->num_pairs = min(all.num_rendered, a.reserve);
+    hdr->reserve = a.reserve;
+    hdr->sort_overflow = 0u;
+    volatile PassInfo* info = a.info;
+    if (info) {
+        info->num_rendered = all.num_rendered;
+        info->visible = all.visible;
+        info->reserve = a.reserve;
+        info->sort_overflow = 0u;
+        __threadfence_system();
+        info->seq = a.ticket;
+    }
+}
+
+// (1) workgroup `wg` of depth_hist_rows(P): histogram of its per_block Gaussians, kHistBatch at a time.  With
+// a.fuse_header every histogram workgroup first reduces the preprocess partials itself (2 k x 16 B out of L2) and
+// workgroup 0 writes the header: the one-workgroup header kernel and its launch gap leave the chain.
+__device__ inline void depth_hist_role(const DepthArgs& a, const HeaderArgs& h, char* smem, int wg)
+{
+    __shared__ uint32_t s_red[16][4];
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);   // [nb + 1]
     const int P = a.P, nb = a.nb;
     for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;
-    const DepthRange rng = make_depth_range(a.hdr->depth_max, a.hdr->depth_inv_min, nb);
+    uint32_t dmax, dinv;
+    if (a.fuse_header) {
+        const PrePartial all = reduce_partials(h.parts, h.n_parts, s_red);
+        if (wg == 0 && threadIdx.x == 0) write_header(h, all);
+        dmax = all.depth_max;
+        dinv = all.depth_inv_min;
+    } else {
+        dmax = a.hdr->depth_max;
+        dinv = a.hdr->depth_inv_min;
+    }
+    const DepthRange rng = make_depth_range(dmax, dinv, nb);
     __syncthreads();
     for (int base = wg * a.per_block; base < min(P, (wg + 1) * a.per_block); base += kHistBatch) {
         uint32_t kv[kHistPerThread], tv[kHistPerThread];

@@ -53,9 +53,11 @@ __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const i
 // cull, projection, conic, radius, tile rect, depth key, per-view counters.  Reads 44 B per Gaussian.  Its
 // outputs are everything the depth sort / binning needs, so the SH -> RGB kernel below can run on a side
 // stream underneath the (launch-latency-bound) sort.
-__global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(const PreArgs* __restrict__ ap)
+__global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs* dst, FwdPassArgs v)
 {
-    const PreArgs a = *ap;   // pass block in device memory: wave-uniform (scalar) loads of the fields used, once
+    // first kernel of the forward: it gets the pass block by value, installs it for the kernels behind it ...
+    if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, kPreBlock);
+    const PreArgs a = v.pre;   // ... and reads its own arguments from the kernarg segment (scalar loads)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P;
     const int i = blockIdx.x * kPreBlock + tid;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kPreBlock) void depth_sort_color_kernel(const FwdPa
     if (wg < n_sort) {
         const DepthArgs d = pa->depth;
         if (STEP == 0)
-            depth_hist_role(d, smem, wg);
+            depth_hist_role(d, pa->header, smem, wg);
         else if (STEP == 1)
             depth_scatter_role(d, smem, wg);
         else
@@ -279,10 +281,10 @@ __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(const Dep
     depth_colscan_role(d, (int)blockIdx.x);
 }
 
-void issue_preprocess_geom(const FwdPlan& p, const PreArgs* a, hipStream_t s)
+void issue_preprocess_geom(const FwdPlan& p, FwdPassArgs* dst, const FwdPassArgs& v, hipStream_t s)
 {
     const int blocks = (p.P + kPreBlock - 1) / kPreBlock;
-    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, a);
+    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, dst, v);
 }
 
 void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s)
