@@ -623,3 +623,38 @@ def test_num_rendered_is_lazy_and_queryable(C_):
     torch.cuda.synchronize()
     assert nr.ready() and int(nr) == int(first[0]) and f"{nr}" == str(int(first[0]))
     assert list(range(10))[:nr] == list(range(10))[:int(nr)]            # usable as an index
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=1, W=64, H=48, f=50.0, scale_mu=0.5),
+    dict(P=63, W=67, H=35, f=50.0, scale_mu=0.2),
+    dict(P=257, W=130, H=70, f=80.0, scale_mu=0.2),
+    dict(P=2500, W=96, H=80, f=70.0, scale_mu=1.2),          # ~2000-entry tile lists, R = 12 P
+    dict(P=12_345, W=333, H=222, f=260.0, scale_mu=0.03),
+    dict(P=3000, W=4096, H=2304, f=3000.0, scale_mu=0.03),   # 16 tile bits: 8-bit digits
+    dict(P=70_000, W=1000, H=40, f=500.0, scale_mu=0.01),    # one row of tiles + a partial one
+], ids=["p1", "p63_odd", "p257", "long_lists", "p12345_odd", "uhd", "strip"])
+def test_reserved_path_fuzz_of_shapes(C_, kw):
+    """Odd shapes through BOTH issue paths: the exact-size one (direct launches, num_rendered read back) and the
+    reserved one (pair reservation, one graph launch, grids strided over the pair count) must agree bit for bit in
+    image, radii, sorted list and every gradient -- also when the second pass is a replay of a captured graph."""
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], 13)
+    g = ss.make_gaussians(P, cam, seed=17, degree_mode="mixed", scale_mu=kw["scale_mu"], scale_sigma=0.4,
+                          behind_frac=0.0 if P < 10 else 0.02)
+    bg = np.array([0.7, 0.1, 0.3], np.float32)
+    dl = ss.upstream_grad(W, H, seed=8) * (W * H)
+    fargs, fex = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    bex = hip_backward(C_, fargs, fex, dl, 0.04)
+    ex = C_.export_binning(P, fex[0], H, W, fex[3], fex[4], fex[5])
+    for rep in range(3):   # first: graph captured; then replays
+        out = C_._forward_common(None, *fargs)
+        nr = out[0]
+        assert nr.ticket > 0 and not nr.truncated and int(nr) == int(fex[0])
+        assert torch.equal(out[1], fex[1]) and torch.equal(out[2], fex[2])
+        ex2 = C_.export_binning(P, nr, H, W, out[3], out[4], out[5])
+        for k in ("keys", "point_list", "ranges", "n_contrib", "final_T", "tiles_touched"):
+            assert torch.equal(ex2[k], ex[k]), k
+        b2 = hip_backward(C_, fargs, out, dl, 0.04)
+        for a, b in zip(bex, b2):
+            assert torch.equal(a, b)
