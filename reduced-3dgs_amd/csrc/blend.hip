@@ -146,6 +146,9 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
+#ifndef R3_FWD_PAIRED
+#define R3_FWD_PAIRED 1   // 0.176 -> 0.171 ms
+#endif
 template <int PPL, bool COUNTERS>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __restrict__ ap)
 {
@@ -220,6 +223,41 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 nxc = g[2];
             }
         }
+#if R3_FWD_PAIRED
+        // Two surviving entries per trip: their alphas (the exp and the quadratic form, ~70 % of a step) do not depend on
+        // the pixel state, so they are evaluated side by side before the sequential compositing of first one, then the
+        // other -- twice the independent work between dependent instructions, half the scalar loop overhead.
+        while (!COUNTERS && anymask) {
+            const int j1 = __builtin_ctzll(anymask);
+            anymask &= anymask - 1ull;
+            const bool two = anymask != 0ull;
+            const int j2 = two ? __builtin_ctzll(anymask) : j1;
+            if (two) anymask &= anymask - 1ull;
+            const Splat s1 = load_splat(s_rec[j1]);
+            const Splat s2 = load_splat(s_rec[j2]);
+            float a1[PPL], a2[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                a1[q] = fwd_alpha(s1, pxf[q], pyf[q]);
+                a2[q] = fwd_alpha(s2, pxf[q], pyf[q]);
+            }
+            const uint32_t p1 = base - range.x + (uint32_t)j1 + 1u, p2 = base - range.x + (uint32_t)j2 + 1u;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                if (((qmask[q] >> j1) & 1ull) && (live & (1u << q))) {
+                    float Tb;
+                    if (fwd_apply(s1, a1[q], p1, pix[q], &Tb) == 2) live &= ~(1u << q);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                if (two && ((qmask[q] >> j2) & 1ull) && (live & (1u << q))) {
+                    float Tb;
+                    if (fwd_apply(s2, a2[q], p2, pix[q], &Tb) == 2) live &= ~(1u << q);
+                }
+            }
+        }
+#endif
         while (anymask) {  // surviving entries, front to back
             const int j = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
@@ -293,8 +331,11 @@ constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
 
 // 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
 // (0.5174 vs 0.5170 ms): occupancy is not what limits this kernel.
+#ifndef R3_BWD_OCC
+#define R3_BWD_OCC 5
+#endif
 template <int PPL>
-__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
+__global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
     // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from

@@ -80,15 +80,27 @@ struct FwdPix {
     uint32_t last;  // 1-based list position of the last blended entry (n_contrib)
 };
 
-// One list entry against one pixel.  Returns 0: skipped, 1: blended, 2: pixel saturated (done).
-// `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance the entry saw.
-R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
+// alpha of one list entry at one pixel (forward.cu:534-546); 0 where the reference skips on power > 0
+R3_HD float fwd_alpha(const Splat& s, float pxf, float pyf)
 {
     const float dx = s.x - pxf, dy = s.y - pyf;
     const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
     // the reference's two skips (power > 0, alpha < 1/255) as ONE divergence point: a select instead of a branch
-    // for the first (it can only fire for a degenerate conic), then a single test
-    const float alpha = power > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP(power));
+    // for the first (it can only fire for a degenerate conic), then a single test in fwd_apply
+    return power > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP(power));
+}
+
+R3_HD int fwd_apply(const Splat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before);
+
+// One list entry against one pixel.  Returns 0: skipped, 1: blended, 2: pixel saturated (done).
+// `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance the entry saw.
+R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
+{
+    return fwd_apply(s, fwd_alpha(s, pxf, pyf), pos1, p, T_before);
+}
+
+R3_HD int fwd_apply(const Splat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before)
+{
     if (alpha < 1.0f / 255.0f) return 0;
     const float test_T = p.T * (1.0f - alpha);
     if (test_T < 0.0001f) return 2;

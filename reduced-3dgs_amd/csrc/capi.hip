@@ -426,6 +426,7 @@ void launch_graph(const CtxKey& key, const Plan& plan, const Block& args, hipStr
             R3_HIP(hipGraphGetRootNodes(c.graph, &c.node0, &n_root));
             R3_HIP(hipGraphKernelNodeGetParams(c.node0, &c.node0_params));
             R3_HIP(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+            c.last_use = ++g_use_clock;   // before the eviction below: the newest entry must not be its victim
         } catch (...) {
             if (c.graph) (void)hipGraphDestroy(c.graph);
             if (c.d_args) (void)hipFree(c.d_args);

@@ -14,6 +14,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libr3dgs_hip.so")
+if os.environ.get("R3DGS_LIB"):   # A/B builds (tools/build_variant.py): a path, or the tag of libr3dgs_hip_<tag>.so
+    _v = os.environ["R3DGS_LIB"]
+    _LIB_PATH = _v if os.sep in _v else os.path.join(os.path.dirname(_HERE), f"libr3dgs_hip_{_v}.so")
 if not os.path.exists(_LIB_PATH):
     raise ImportError(f"{_LIB_PATH} not found: build it with `python reduced-3dgs_amd/build.py` "
                       "(the rasterizer has no CPU or PyTorch fallback)")

@@ -658,3 +658,24 @@ def test_reserved_path_fuzz_of_shapes(C_, kw):
         b2 = hip_backward(C_, fargs, out, dl, 0.04)
         for a, b in zip(bex, b2):
             assert torch.equal(a, b)
+
+
+def test_graph_cache_eviction_keeps_results_right(C_):
+    """A training run changes P at every densification: more shapes than the library caches graphs for (48).  Forward +
+    backward of 40 different Gaussian counts through the reserved path, each checked against the exact-size path."""
+    W, H = 176, 112
+    cam = ss.make_camera(W, H, 130.0, 21)
+    bg = np.array([0.2, 0.2, 0.6], np.float32)
+    dl = ss.upstream_grad(W, H, seed=12) * (W * H)
+    gall = ss.make_gaussians(4000, cam, seed=23, degree_mode="mixed", scale_mu=0.04)
+    for n in range(40):
+        P = 2000 + 37 * n
+        g = {k: np.ascontiguousarray(v[:P]) for k, v in gall.items()}
+        fargs, fex = hip_forward(C_, bg, g, cam, H, W, exact=True)
+        out = C_._forward_common(None, *fargs)
+        assert out[0].ticket > 0 and not out[0].truncated
+        assert torch.equal(out[1], fex[1]) and torch.equal(out[2], fex[2])
+        bex = hip_backward(C_, fargs, fex, dl, 0.0)
+        b2 = hip_backward(C_, fargs, out, dl, 0.0)
+        for a, b in zip(bex, b2):
+            assert torch.equal(a, b), (n, P)
