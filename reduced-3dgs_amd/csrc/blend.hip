@@ -100,42 +100,56 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
-// Transposing wave reduction of the 9 gradient components.  A plain butterfly costs 6 cross-lane adds per
-// component (54, and the two cross-row steps need an extra move each).  Here the first two steps exchange
-// DIFFERENT components between partner lanes (keep one, send the other), halving the live values each time:
-// 9 -> 5 -> 3 registers, which are then summed over the remaining lane bits.  Afterwards lane l holds the wave
-// totals of component (l & 3) in w0, component 4 + (l & 3) in w1 and component 8 in w8
-// (component order: mx, my, cA, cB, cC, op, r, g, b).  38 instead of ~72 VALU/DS instructions per entry.
-__device__ __forceinline__ float dpp_get(float v, const int ctrl_is_quad_1032)
+// Transposing wave reduction of the 9 gradient components (order: mx, my, cA, cB, cC, op, r, g, b).  A plain butterfly
+// costs 6 cross-lane adds per component (54, and the two cross-row steps need an extra move each).  Here every step
+// over a lane bit exchanges DIFFERENT components between partner lanes (keep one, send the other), halving the live
+// registers: 9 -> 5 -> 3 -> 2 -> 1, and only that one register crosses the 16-lane rows (2 ds_bpermute).  The two
+// steps that start with the most registers go over lane bits 2 and 3 (row_ror:4 / row_ror:8), because a DPP bank mask
+// selects exactly those bits (bank = 4 consecutive lanes of a row): two bank-masked v_add_f32_dpp into the same
+// destination do "keep mine, add the partner's" without a v_cndmask.  The compiler cannot be asked for a bank-masked
+// DPP add (it only folds full-mask moves), so those 14 instructions are inline assembly; the leading s_nop is the
+// VALU-write -> DPP-read wait states the hazard recogniser cannot see INTO an asm block (it does pad behind one).
+// Afterwards every lane with (lane & 2) == 0 holds the wave total of component reduce9_component(lane), every other
+// lane component 8.  25 VALU + 2 DS per entry (was 38 + 6).
+__device__ __forceinline__ int reduce9_component(int lane)
 {
-    return ctrl_is_quad_1032
-               ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true))
-               : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+    return (lane & 2) ? 8 : 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
 }
 
-__device__ __forceinline__ float rows_and_halves_sum(float v)
+__device__ __forceinline__ float wave_reduce9(const SplatGrad& g, int lane)
 {
-    R3_DPP_ADD(v, 0x124, 0xf);  // row_ror:4  (lane & 3 preserved)
-    R3_DPP_ADD(v, 0x128, 0xf);  // row_ror:8
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
-__device__ __forceinline__ void wave_reduce9(const SplatGrad& g, int lane, float& w0, float& w1, float& w8)
-{
-    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
-#define R3_PAIR(odd, a, b, quad1032) (((odd) ? (b) : (a)) + dpp_get((odd) ? (a) : (b), quad1032))
-    const float u0 = R3_PAIR(o1, g.mx, g.my, 1), u1 = R3_PAIR(o1, g.cA, g.cB, 1);
-    const float u2 = R3_PAIR(o1, g.cC, g.op, 1), u3 = R3_PAIR(o1, g.r, g.g, 1);
-    float t8 = g.b + dpp_get(g.b, 1);
-    w0 = R3_PAIR(o2, u0, u1, 0);
-    w1 = R3_PAIR(o2, u2, u3, 0);
-    t8 += dpp_get(t8, 0);
-#undef R3_PAIR
-    w0 = rows_and_halves_sum(w0);
-    w1 = rows_and_halves_sum(w1);
-    w8 = rows_and_halves_sum(t8);
+    float u0, u1, u2, u3, t8, w0, w1;
+    asm("s_nop 1\n\t"
+        // lane bit 2: banks 0 and 2 keep the first of a pair, banks 1 and 3 the second
+        "v_add_f32_dpp %[u0], %[mx], %[mx] row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[u0], %[my], %[my] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[u1], %[ca], %[ca] row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[u1], %[cb], %[cb] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[u2], %[cc], %[cc] row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[u2], %[op], %[op] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[u3], %[cr], %[cr] row_ror:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[u3], %[cg], %[cg] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[t8], %[bl], %[bl] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        // lane bit 3: banks 0 and 1 keep the first, banks 2 and 3 the second
+        "v_add_f32_dpp %[w0], %[u0], %[u0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[w0], %[u1], %[u1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[w1], %[u2], %[u2] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[w1], %[u3], %[u3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[t8], %[t8], %[t8] row_ror:8 row_mask:0xf bank_mask:0xf"
+        : [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), [t8] "=&v"(t8), [w0] "=&v"(w0), [w1] "=&v"(w1)
+        : [mx] "v"(g.mx), [my] "v"(g.my), [ca] "v"(g.cA), [cb] "v"(g.cB), [cc] "v"(g.cC), [op] "v"(g.op), [cr] "v"(g.r),
+          [cg] "v"(g.g), [bl] "v"(g.b));
+    // now, summed over the 4 lanes of the row with the same lane & 3:  w0 = component 2 * bit3 + bit2,  w1 = 4 + that,  t8 = b
+    R3_DPP_ADD(w0, 0xb1, 0xf);   // quad_perm [1,0,3,2]
+    R3_DPP_ADD(w1, 0xb1, 0xf);
+    R3_DPP_ADD(t8, 0xb1, 0xf);
+    float z = (lane & 1) ? w1 : w0;
+    R3_DPP_ADD(z, 0x4e, 0xf);    // quad_perm [2,3,0,1]
+    R3_DPP_ADD(t8, 0x4e, 0xf);
+    z = (lane & 2) ? t8 : z;
+    z += __shfl_xor(z, 16);
+    z += __shfl_xor(z, 32);
+    return z;
 }
 
 template <int PPL>
@@ -327,7 +341,7 @@ void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-constexpr int kGradStride = 10;  // 9 sums + "contributed" flag per list entry
+constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the flush reads without bank conflicts)
 
 // 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
 // (0.5174 vs 0.5170 ms): occupancy is not what limits this kernel.
@@ -391,6 +405,11 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         nxb = g[1];
         nxc = g[2];
     }
+    // lanes that park the reduced sums of an entry: lane -> component as wave_reduce9 leaves them
+    const bool writer = lane < 16 && ((lane & 2) == 0 || lane == 2);
+    float* const s_grad_slot = s_grad + reduce9_component(lane);
+    SplatGrad sg;   // zero whenever an entry starts: cleared after every reduction, untouched by entries without a hit
+    sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
     for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
         __syncthreads();
         s_rec[lane].a = nxa;
@@ -413,36 +432,37 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             nxb = g[1];
             nxc = g[2];
         }
-        s_grad[lane * kGradStride + 9] = 0.f;
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
+        unsigned long long contributed = 0ull;   // wave-uniform: entries of this chunk that got sums
         while (anymask) {  // surviving entries, back to front: highest set bit first
             const int j = 63 - __builtin_clzll(anymask);
             anymask &= ~(1ull << j);
             const Splat s = load_splat(s_rec[j]);
             const uint32_t pos = (uint32_t)(cbase + j);
-            SplatGrad sg;
-            sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
-            bool any = false;
+            unsigned long long hit = 0ull;
 #pragma unroll
             for (int q = 0; q < PPL; q++)
-                if ((qmask[q] >> j) & 1ull) any |= bwd_step(s, pxf[q], pyf[q], pos, pix[q], sg);
-            if (__ballot(any) != 0ull) {
-                float* d = s_grad + j * kGradStride;
-                float w0, w1, w8;
-                wave_reduce9(sg, lane, w0, w1, w8);
-                if (lane < 4) {
-                    d[lane] = w0;
-                    d[4 + lane] = w1;
+                if ((qmask[q] >> j) & 1ull) {
+                    BwdEval e;
+                    const bool valid = bwd_test(s, pxf[q], pyf[q], pos, pix[q], e);
+                    // ballot of ONE compare is that compare's SGPR pair; of the conjunction it is a v_cndmask + v_cmp.
+                    // `hit` only gates the reduction, so it may over-approximate: power > 0 (a degenerate conic) is
+                    // left out, such an entry then reduces and stores the zeros it accumulated.
+                    hit |= __builtin_amdgcn_ballot_w64(e.in_list) & __builtin_amdgcn_ballot_w64(e.visible);
+                    if (valid) bwd_accumulate(s, e, pix[q], sg);
                 }
-                if (lane == 0) {
-                    d[8] = w8;
-                    d[9] = 1.f;
-                }
+            if (hit != 0ull) {
+                const float z = wave_reduce9(sg, lane);
+                int joff = j * kGradStride;
+                asm("" : "+s"(joff));   // stays a scalar multiply + v_add (else: one quarter-rate v_mad_u64_u32)
+                if (writer) s_grad_slot[joff] = z;
+                contributed |= 1ull << j;
+                sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
             }
         }
         __syncthreads();
-        if (lane < n && s_grad[lane * kGradStride + 9] != 0.f) {
+        if (lane < n && ((contributed >> lane) & 1ull)) {
             // park the entry's sums in ITS slot of the per-pair slab: slot = first pair of the Gaussian + row-major
             // index of this tile inside the Gaussian's tile rect (exactly the emission order of binning.hip).
             // Plain stores, one owner per slot -- the per-Gaussian kernel adds a Gaussian's slots up in order, so

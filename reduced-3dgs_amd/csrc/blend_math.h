@@ -144,18 +144,33 @@ struct SplatGrad {
     float mx, my, cA, cB, cC, op, r, g, b;
 };
 
-// One list entry (0-based position `pos`) against one pixel; accumulates into `a`.
-// Returns true when the entry contributed.  dmean2D is accumulated WITHOUT the 0.5*W / 0.5*H
-// viewport factors (backward.cu:498-499); the caller applies them once after the reduction.
-R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
+// One list entry (0-based position `pos`) against one pixel, in two halves so that the kernel can ballot the decision
+// before it branches on it.  bwd_test: the reference's three skips -- entry behind this pixel's last contributor
+// (backward.cu:524-526), power > 0, alpha < 1/255 -- evaluated together: one divergence point instead of three.
+struct BwdEval {
+    float dx, dy, G, alpha;
+    bool in_list, in_bound, visible;   // the three decisions, kept apart: a kernel can ballot each compare for free
+    R3_HD bool valid() const { return in_list && in_bound && visible; }
+};
+
+R3_HD bool bwd_test(const Splat& s, float pxf, float pyf, uint32_t pos, const BwdPix& p, BwdEval& e)
 {
-    const float dx = s.x - pxf, dy = s.y - pyf;
-    const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
-    const float G = R3_EXP(power);
-    const float alpha = fminf(0.99f, s.op * G);
-    // the reference's three skips -- entry behind this pixel's last contributor (backward.cu:524-526), power > 0,
-    // alpha < 1/255 -- evaluated together: one divergence point instead of three
-    if (!(pos < p.last && power <= 0.0f && alpha >= 1.0f / 255.0f)) return false;
+    e.dx = s.x - pxf;
+    e.dy = s.y - pyf;
+    const float power = -0.5f * (s.cA * e.dx * e.dx + s.cC * e.dy * e.dy) - s.cB * e.dx * e.dy;
+    e.G = R3_EXP(power);
+    e.alpha = fminf(0.99f, s.op * e.G);
+    e.in_list = pos < p.last;
+    e.in_bound = power <= 0.0f;
+    e.visible = e.alpha >= 1.0f / 255.0f;
+    return e.valid();
+}
+
+// accumulates into `a`.  dmean2D is accumulated WITHOUT the 0.5*W / 0.5*H viewport factors (backward.cu:498-499); the
+// caller applies them once after the reduction.
+R3_HD void bwd_accumulate(const Splat& s, const BwdEval& e, BwdPix& p, SplatGrad& a)
+{
+    const float dx = e.dx, dy = e.dy, G = e.G, alpha = e.alpha;
     const float ra = R3_RCP(1.0f - alpha);
     p.T = p.T * ra;  // T recovered by division (backward.cu:541)
     const float dch = alpha * p.T;
@@ -176,6 +191,14 @@ R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& 
     a.cB += hx * dy;
     a.cC += hy * dy;
     a.op += G * dL_dalpha;
+}
+
+// Returns true when the entry contributed.
+R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
+{
+    BwdEval e;
+    if (!bwd_test(s, pxf, pyf, pos, p, e)) return false;
+    bwd_accumulate(s, e, p, a);
     return true;
 }
 
