@@ -34,20 +34,20 @@ namespace r3 {
 
 constexpr int kChunk = 64;
 
-struct LdsRec {  // 48 B, same field order as GRec's first 9 floats
-    float4 a;    // x, y, cA, cB
-    float4 b;    // cC, op, r, g
+struct LdsRec {  // 48 B: a staged list entry, conic pre-scaled (QSplat); c.yzw = GRec's rect_min, width_clamp, pair_start
+    float4 a;    // x, y, qa, qb
+    float4 b;    // qc, op, r, g
     float4 c;    // b, -, -, -
 };
 
-__device__ __forceinline__ Splat load_splat(const LdsRec& r)
+__device__ __forceinline__ QSplat load_splat(const LdsRec& r)
 {
-    Splat s;
+    QSplat s;
     s.x = r.a.x;
     s.y = r.a.y;
-    s.cA = r.a.z;
-    s.cB = r.a.w;
-    s.cC = r.b.x;
+    s.qa = r.a.z;
+    s.qb = r.a.w;
+    s.qc = r.b.x;
     s.op = r.b.y;
     s.r = r.b.z;
     s.g = r.b.w;
@@ -68,6 +68,14 @@ __device__ __forceinline__ Splat splat_from_regs(const float4& a, const float4& 
     s.g = b.w;
     s.b = c.x;
     return s;
+}
+
+// lane j parks the entry it gathered (registers a, b, c = the GRec) with the conic pre-scaled
+__device__ __forceinline__ void stage_entry(LdsRec& dst, const float4& a, const float4& b, const float4& c)
+{
+    dst.a = make_float4(a.x, a.y, (-0.5f * kLog2e) * a.z, -kLog2e * a.w);
+    dst.b = make_float4((-0.5f * kLog2e) * b.x, b.y, b.z, b.w);
+    dst.c = c;
 }
 
 // consecutive logical ids on one XCD: hardware places workgroup b on XCD b % 8 (speed only, never correctness)
@@ -100,7 +108,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
-// Transposing wave reduction of the 9 gradient components (order: mx, my, cA, cB, cC, op, r, g, b).  A plain butterfly
+// Transposing wave reduction of the 9 per-entry sums (SplatSums, in its field order: components 0..8).  A plain butterfly
 // costs 6 cross-lane adds per component (54, and the two cross-row steps need an extra move each).  Here every step
 // over a lane bit exchanges DIFFERENT components between partner lanes (keep one, send the other), halving the live
 // registers: 9 -> 5 -> 3 -> 2 -> 1, and only that one register crosses the 16-lane rows (2 ds_bpermute).  The two
@@ -116,7 +124,7 @@ __device__ __forceinline__ int reduce9_component(int lane)
     return (lane & 2) ? 8 : 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
 }
 
-__device__ __forceinline__ float wave_reduce9(const SplatGrad& g, int lane)
+__device__ __forceinline__ float wave_reduce9(const SplatSums& g, int lane)
 {
     float u0, u1, u2, u3, t8, w0, w1;
     asm("s_nop 1\n\t"
@@ -137,7 +145,7 @@ __device__ __forceinline__ float wave_reduce9(const SplatGrad& g, int lane)
         "v_add_f32_dpp %[w1], %[u3], %[u3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
         "v_add_f32_dpp %[t8], %[t8], %[t8] row_ror:8 row_mask:0xf bank_mask:0xf"
         : [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), [t8] "=&v"(t8), [w0] "=&v"(w0), [w1] "=&v"(w1)
-        : [mx] "v"(g.mx), [my] "v"(g.my), [ca] "v"(g.cA), [cb] "v"(g.cB), [cc] "v"(g.cC), [op] "v"(g.op), [cr] "v"(g.r),
+        : [mx] "v"(g.sx), [my] "v"(g.sy), [ca] "v"(g.sxx), [cb] "v"(g.sxy), [cc] "v"(g.syy), [op] "v"(g.sm), [cr] "v"(g.r),
           [cg] "v"(g.g), [bl] "v"(g.b));
     // now, summed over the 4 lanes of the row with the same lane & 3:  w0 = component 2 * bit3 + bit2,  w1 = 4 + that,  t8 = b
     R3_DPP_ADD(w0, 0xb1, 0xf);   // quad_perm [1,0,3,2]
@@ -211,9 +219,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
         if (__ballot(live != 0) == 0ull) break;  // every pixel of the region saturated
         __syncthreads();
-        s_rec[lane].a = nxa;
-        s_rec[lane].b = nxb;
-        s_rec[lane].c = nxc;
+        stage_entry(s_rec[lane], nxa, nxb, nxc);
         if (COUNTERS) s_id[lane] = nxid;
         // region pre-test: lane j decides for entry j which of this wave's quadrants it can reach at all
         unsigned long long qmask[PPL], anymask = 0ull;
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
             const bool two = anymask != 0ull;
             const int j2 = two ? __builtin_ctzll(anymask) : j1;
             if (two) anymask &= anymask - 1ull;
-            const Splat s1 = load_splat(s_rec[j1]);
-            const Splat s2 = load_splat(s_rec[j2]);
+            const QSplat s1 = load_splat(s_rec[j1]);
+            const QSplat s2 = load_splat(s_rec[j2]);
             float a1[PPL], a2[PPL];
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         while (anymask) {  // surviving entries, front to back
             const int j = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
-            const Splat s = load_splat(s_rec[j]);
+            const QSplat s = load_splat(s_rec[j]);
             const uint32_t pos1 = base - range.x + (uint32_t)j + 1u;
             int cnt = 0;
             float tsum = 0.f;
@@ -389,8 +395,16 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         }
         lmax = max(lmax, p.last);
     }
-    // deepest contributor of the whole region: nothing behind it matters to any pixel here
+    // deepest contributor of each quadrant and of the whole region: nothing behind it matters to any pixel there
+    uint32_t qlast[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        uint32_t m = pix[q].last;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        qlast[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    }
     for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off));
+    lmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)lmax);
     if (lmax == 0) return;
 
     const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
@@ -408,13 +422,11 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     // lanes that park the reduced sums of an entry: lane -> component as wave_reduce9 leaves them
     const bool writer = lane < 16 && ((lane & 2) == 0 || lane == 2);
     float* const s_grad_slot = s_grad + reduce9_component(lane);
-    SplatGrad sg;   // zero whenever an entry starts: cleared after every reduction, untouched by entries without a hit
-    sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
+    SplatSums sg;   // zero whenever an entry starts: cleared after every reduction, untouched by entries without a hit
+    sg.sx = sg.sy = sg.sxx = sg.sxy = sg.syy = sg.sm = sg.r = sg.g = sg.b = 0.f;
     for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
         __syncthreads();
-        s_rec[lane].a = nxa;
-        s_rec[lane].b = nxb;
-        s_rec[lane].c = nxc;
+        stage_entry(s_rec[lane], nxa, nxb, nxc);
         unsigned long long qmask[PPL], anymask = 0ull;
         {
             const Splat mine = splat_from_regs(nxa, nxb, nxc);
@@ -422,6 +434,9 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
                 qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
+                // entries behind the quadrant's deepest contributor (scalar arithmetic)
+                const uint32_t left = qlast[q] > (uint32_t)cbase ? qlast[q] - (uint32_t)cbase : 0u;
+                if (left < (uint32_t)kChunk) qmask[q] &= (1ull << left) - 1ull;
                 anymask |= qmask[q];
             }
         }
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         while (anymask) {  // surviving entries, back to front: highest set bit first
             const int j = 63 - __builtin_clzll(anymask);
             anymask &= ~(1ull << j);
-            const Splat s = load_splat(s_rec[j]);
+            const QSplat s = load_splat(s_rec[j]);
             const uint32_t pos = (uint32_t)(cbase + j);
             unsigned long long hit = 0ull;
 #pragma unroll
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
                 asm("" : "+s"(joff));   // stays a scalar multiply + v_add (else: one quarter-rate v_mad_u64_u32)
                 if (writer) s_grad_slot[joff] = z;
                 contributed |= 1ull << j;
-                sg.mx = sg.my = sg.cA = sg.cB = sg.cC = sg.op = sg.r = sg.g = sg.b = 0.f;
+                sg.sx = sg.sy = sg.sxx = sg.sxy = sg.syy = sg.sm = sg.r = sg.g = sg.b = 0.f;
             }
         }
         __syncthreads();
@@ -474,10 +489,21 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
                                   ((uint32_t)tile_x - (rect_min & 0xffffu));
             float4* dst = reinterpret_cast<float4*>(a.pair_grad + (size_t)slot * kPairStride);   // 48-B row, 3 x 16 B
             const float* src = s_grad + lane * kGradStride;
-            // viewport factors of backward.cu:498-499, applied once
-            dst[0] = make_float4(src[0] * half_w, src[1] * half_h, src[2], src[3]);
-            dst[1] = make_float4(src[4], src[5], src[6], src[7]);
-            dst[2] = make_float4(src[8], 0.f, 0.f, 0.f);
+            SplatSums u;
+            u.sx = src[0];
+            u.sy = src[1];
+            u.sxx = src[2];
+            u.sxy = src[3];
+            u.syy = src[4];
+            u.sm = src[5];
+            u.r = src[6];
+            u.g = src[7];
+            u.b = src[8];
+            // moments -> gradients, once per (tile, entry); viewport factors of backward.cu:498-499 applied here
+            const SplatGrad g = splat_grad_of(load_splat(s_rec[lane]), u);
+            dst[0] = make_float4(g.mx * half_w, g.my * half_h, g.cA, g.cB);
+            dst[1] = make_float4(g.cC, g.op, g.r, g.g);
+            dst[2] = make_float4(g.b, 0.f, 0.f, 0.f);
             a.pair_flag[slot] = 1;
         }
     }

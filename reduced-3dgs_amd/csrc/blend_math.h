@@ -19,11 +19,11 @@ namespace r3 {
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define R3_EXP(x) __expf(x)
+#define R3_EXP2(x) __builtin_amdgcn_exp2f(x)  // v_exp_f32
 #define R3_LOG(x) __logf(x)
 #define R3_RCP(x) __builtin_amdgcn_rcpf(x)  // v_rcp_f32, 1 ulp
 #else
-#define R3_EXP(x) expf(x)
+#define R3_EXP2(x) exp2f(x)
 #define R3_LOG(x) logf(x)
 #define R3_RCP(x) (1.0f / (x))
 #endif
@@ -75,31 +75,53 @@ R3_HD bool region_may_contribute(const Splat& s, float X0, float X1, float Y0, f
     return !(qmin > tau + 2e-3f * fabsf(tau) + 2e-3f);  // NaN anywhere => keep
 }
 
+// The same 9 floats with the conic pre-scaled so that  log2(G) = qa*dx^2 + qb*dx*dy + qc*dy^2  (G = exp(power) of
+// forward.cu:534-537): the -0.5 and the log2(e) in front of v_exp_f32 are paid once per list entry by the lane that
+// stages it (3 multiplies per 64-entry chunk) instead of once per (pixel, entry).  Forward and backward evaluate the
+// falloff through the one function below, with explicit FMAs, so both take the same per-pixel decisions.
+struct QSplat {
+    float x, y, qa, qb, qc, op, r, g, b;
+};
+
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+R3_HD QSplat scale_splat(const Splat& s)
+{
+    QSplat q;
+    q.x = s.x;
+    q.y = s.y;
+    q.qa = (-0.5f * kLog2e) * s.cA;
+    q.qb = -kLog2e * s.cB;
+    q.qc = (-0.5f * kLog2e) * s.cC;
+    q.op = s.op;
+    q.r = s.r;
+    q.g = s.g;
+    q.b = s.b;
+    return q;
+}
+
+R3_HD float log2_falloff(const QSplat& s, float dx, float dy)
+{
+    return fmaf(s.qb * dx, dy, fmaf(s.qc * dy, dy, (s.qa * dx) * dx));
+}
+
 struct FwdPix {
     float T, C0, C1, C2;
     uint32_t last;  // 1-based list position of the last blended entry (n_contrib)
 };
 
 // alpha of one list entry at one pixel (forward.cu:534-546); 0 where the reference skips on power > 0
-R3_HD float fwd_alpha(const Splat& s, float pxf, float pyf)
+R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf)
 {
-    const float dx = s.x - pxf, dy = s.y - pyf;
-    const float power = -0.5f * (s.cA * dx * dx + s.cC * dy * dy) - s.cB * dx * dy;
+    const float p2 = log2_falloff(s, s.x - pxf, s.y - pyf);
     // the reference's two skips (power > 0, alpha < 1/255) as ONE divergence point: a select instead of a branch
     // for the first (it can only fire for a degenerate conic), then a single test in fwd_apply
-    return power > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP(power));
+    return p2 > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP2(p2));
 }
 
-R3_HD int fwd_apply(const Splat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before);
-
-// One list entry against one pixel.  Returns 0: skipped, 1: blended, 2: pixel saturated (done).
-// `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance the entry saw.
-R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
-{
-    return fwd_apply(s, fwd_alpha(s, pxf, pyf), pos1, p, T_before);
-}
-
-R3_HD int fwd_apply(const Splat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before)
+// Blends an entry of opacity-weighted falloff `alpha` into pixel `p`.  Returns 0: skipped, 1: blended, 2: pixel
+// saturated (done).  `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance it saw.
+R3_HD int fwd_apply(const QSplat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before)
 {
     if (alpha < 1.0f / 255.0f) return 0;
     const float test_T = p.T * (1.0f - alpha);
@@ -114,12 +136,23 @@ R3_HD int fwd_apply(const Splat& s, float alpha, uint32_t pos1, FwdPix& p, float
     return 1;
 }
 
+// One list entry against one pixel (forward.cu:528-570).
+R3_HD int fwd_step(const QSplat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
+{
+    return fwd_apply(s, fwd_alpha(s, pxf, pyf), pos1, p, T_before);
+}
+
+R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
+{
+    return fwd_step(scale_splat(s), pxf, pyf, pos1, p, T_before);
+}
+
 // per-pixel state of the back-to-front walk.  The reference keeps accum_rec[3] and last_color[3] per
 // pixel (backward.cu:487-494) and forms  dL_dalpha = sum_ch (c_ch - accum_rec_ch) * g_ch.  Both recurrences
 // are linear, so only their projections on the pixel's upstream gradient g are needed:
-//   A   = accum_rec . g      A   <- la * cgp + (1 - la) * A
+//   A   = accum_rec . g      A   <- A + la * (cgp - A)
 //   cgp = last_color . g     cgp <- c . g
-// which is the same arithmetic up to association (5 fewer registers per pixel, ~9 fewer VALU per step).
+// which is the same arithmetic up to association (5 fewer registers per pixel, ~10 fewer VALU per step).
 struct BwdPix {
     float T;           // transmittance in front of the current entry (recovered by division)
     float tb;          // -T_final * (bg . g): background term numerator (backward.cu:569-572)
@@ -139,10 +172,36 @@ R3_HD void bwd_pix_init(BwdPix& p, float T_final, uint32_t last, float g0, float
     p.last = last;
 }
 
-// per-Gaussian partial gradient of one lane (summed over its pixels, then over the wave)
+// per-Gaussian partial gradient (2D stage): dmean2D WITHOUT the 0.5*W / 0.5*H viewport factors of backward.cu:498-499
 struct SplatGrad {
     float mx, my, cA, cB, cC, op, r, g, b;
 };
+
+// What a lane accumulates per list entry over its pixels and the wave then reduces.  The entry's conic and opacity are
+// the same for every pixel, so the five geometry gradients of backward.cu:553-566 are kept as the moments
+//   m = G * dL_dalpha,   sm = sum m,  (sx, sy) = sum m * d,  (sxx, sxy, syy) = sum m * d d^T
+// and turned into dL_dmean2D / dL_dconic / dL_dopacity ONCE per (tile, entry) after the reduction (splat_grad_of):
+// 9 VALU per (pixel, entry) instead of 15.
+struct SplatSums {
+    float sx, sy, sxx, sxy, syy, sm, r, g, b;
+};
+
+R3_HD SplatGrad splat_grad_of(const QSplat& s, const SplatSums& u)
+{
+    SplatGrad g;
+    const float k = s.op * kLn2;   // conic = -ln2 * (2 qa, qb, 2 qc)
+    g.mx = k * (2.f * s.qa * u.sx + s.qb * u.sy);
+    g.my = k * (2.f * s.qc * u.sy + s.qb * u.sx);
+    const float h = -0.5f * s.op;
+    g.cA = h * u.sxx;
+    g.cB = h * u.sxy;
+    g.cC = h * u.syy;
+    g.op = u.sm;
+    g.r = u.r;
+    g.g = u.g;
+    g.b = u.b;
+    return g;
+}
 
 // One list entry (0-based position `pos`) against one pixel, in two halves so that the kernel can ballot the decision
 // before it branches on it.  bwd_test: the reference's three skips -- entry behind this pixel's last contributor
@@ -153,52 +212,61 @@ struct BwdEval {
     R3_HD bool valid() const { return in_list && in_bound && visible; }
 };
 
-R3_HD bool bwd_test(const Splat& s, float pxf, float pyf, uint32_t pos, const BwdPix& p, BwdEval& e)
+R3_HD bool bwd_test(const QSplat& s, float pxf, float pyf, uint32_t pos, const BwdPix& p, BwdEval& e)
 {
     e.dx = s.x - pxf;
     e.dy = s.y - pyf;
-    const float power = -0.5f * (s.cA * e.dx * e.dx + s.cC * e.dy * e.dy) - s.cB * e.dx * e.dy;
-    e.G = R3_EXP(power);
+    const float p2 = log2_falloff(s, e.dx, e.dy);
+    e.G = R3_EXP2(p2);
     e.alpha = fminf(0.99f, s.op * e.G);
     e.in_list = pos < p.last;
-    e.in_bound = power <= 0.0f;
+    e.in_bound = p2 <= 0.0f;
     e.visible = e.alpha >= 1.0f / 255.0f;
     return e.valid();
 }
 
-// accumulates into `a`.  dmean2D is accumulated WITHOUT the 0.5*W / 0.5*H viewport factors (backward.cu:498-499); the
-// caller applies them once after the reduction.
-R3_HD void bwd_accumulate(const Splat& s, const BwdEval& e, BwdPix& p, SplatGrad& a)
+R3_HD void bwd_accumulate(const QSplat& s, const BwdEval& e, BwdPix& p, SplatSums& a)
 {
-    const float dx = e.dx, dy = e.dy, G = e.G, alpha = e.alpha;
-    const float ra = R3_RCP(1.0f - alpha);
+    const float ra = R3_RCP(1.0f - e.alpha);
     p.T = p.T * ra;  // T recovered by division (backward.cu:541)
-    const float dch = alpha * p.T;
+    const float dch = e.alpha * p.T;
     a.r += dch * p.g0;
     a.g += dch * p.g1;
     a.b += dch * p.g2;
-    p.A = p.la * p.cgp + (1.f - p.la) * p.A;
+    p.A = fmaf(p.la, p.cgp - p.A, p.A);
     const float cg = s.r * p.g0 + s.g * p.g1 + s.b * p.g2;
     p.cgp = cg;
-    p.la = alpha;
+    p.la = e.alpha;
     const float dL_dalpha = (cg - p.A) * p.T + p.tb * ra;
-    const float dL_dG = s.op * dL_dalpha;
-    const float gdx = G * dx, gdy = G * dy;
-    a.mx += dL_dG * (-gdx * s.cA - gdy * s.cB);
-    a.my += dL_dG * (-gdy * s.cC - gdx * s.cB);
-    const float hx = -0.5f * dL_dG * gdx, hy = -0.5f * dL_dG * gdy;
-    a.cA += hx * dx;
-    a.cB += hx * dy;
-    a.cC += hy * dy;
-    a.op += G * dL_dalpha;
+    const float m = e.G * dL_dalpha;
+    a.sm += m;
+    const float mdx = m * e.dx, mdy = m * e.dy;
+    a.sx += mdx;
+    a.sy += mdy;
+    a.sxx += mdx * e.dx;
+    a.sxy += mdx * e.dy;
+    a.syy += mdy * e.dy;
 }
 
-// Returns true when the entry contributed.
-R3_HD bool bwd_step(const Splat& s, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
+// Whole step for one (pixel, entry) pair, adding into `a`; returns true when the entry contributed.
+R3_HD bool bwd_step(const Splat& s0, float pxf, float pyf, uint32_t pos, BwdPix& p, SplatGrad& a)
 {
+    const QSplat s = scale_splat(s0);
     BwdEval e;
     if (!bwd_test(s, pxf, pyf, pos, p, e)) return false;
-    bwd_accumulate(s, e, p, a);
+    SplatSums u;
+    u.sx = u.sy = u.sxx = u.sxy = u.syy = u.sm = u.r = u.g = u.b = 0.f;
+    bwd_accumulate(s, e, p, u);
+    const SplatGrad g = splat_grad_of(s, u);
+    a.mx += g.mx;
+    a.my += g.my;
+    a.cA += g.cA;
+    a.cB += g.cB;
+    a.cC += g.cC;
+    a.op += g.op;
+    a.r += g.r;
+    a.g += g.g;
+    a.b += g.b;
     return true;
 }
 
