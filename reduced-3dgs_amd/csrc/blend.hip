@@ -168,6 +168,18 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
+#ifndef R3_FWD_SCALAR_RANGE
+#define R3_FWD_SCALAR_RANGE 0   // readfirstlane of the tile's range: forward 0.174 -> 0.185 ms (measured), so it stays a VGPR
+#endif
+#ifndef R3_BWD_SCALAR_RANGE
+#define R3_BWD_SCALAR_RANGE 1
+#endif
+#ifndef R3_ID_AHEAD
+#define R3_ID_AHEAD 1
+#endif
+#ifndef R3_FWD_EARLY_RGB
+#define R3_FWD_EARLY_RGB 0
+#endif
 #ifndef R3_FWD_PAIRED
 #define R3_FWD_PAIRED 1   // 0.176 -> 0.171 ms
 #endif
@@ -183,12 +195,15 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
-    const uint2 range = a.ranges[tile];
+    uint2 range = a.ranges[tile];
+#if R3_FWD_SCALAR_RANGE
+    range.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);   // wave-uniform: the chunk loop's arithmetic is scalar
+    range.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.y);
+#endif
 
     float pxf[PPL], pyf[PPL], qx0[PPL], qy0[PPL];
     FwdPix pix[PPL];
     bool inside[PPL];
-    uint32_t live = 0;  // bit q set while pixel q still blends
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
         int px, py;
@@ -199,10 +214,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         pxf[q] = (float)px;
         pyf[q] = (float)py;
         inside[q] = px < a.W && py < a.H;
-        pix[q].T = 1.0f;
-        pix[q].C0 = pix[q].C1 = pix[q].C2 = 0.f;
-        pix[q].last = 0;
-        if (inside[q]) live |= 1u << q;
+        fwd_pix_init(pix[q], inside[q]);
     }
 
     // software pipeline: the records of chunk k+1 are gathered into registers while chunk k is blended
@@ -216,8 +228,18 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         nxb = g[1];
         nxc = g[2];
     }
+#if R3_ID_AHEAD
+    // the list ids run one more chunk ahead than the records they index: one memory round trip per chunk, not two
+    uint32_t nnid = 0;
+    if (range.x + kChunk + lane < range.y) nnid = a.point_list[range.x + kChunk + lane];
+#endif
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
-        if (__ballot(live != 0) == 0ull) break;  // every pixel of the region saturated
+        {
+            bool live = false;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) live |= fwd_pix_live(pix[q]);
+            if (__ballot(live) == 0ull) break;  // every pixel of the region saturated
+        }
         __syncthreads();
         stage_entry(s_rec[lane], nxa, nxb, nxc);
         if (COUNTERS) s_id[lane] = nxid;
@@ -231,17 +253,32 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
                 anymask |= qmask[q];
             }
+            if (a.quad_masks) {   // kept for the backward, which walks the same chunks
+                unsigned long long* dst =
+                    a.quad_masks + quad_mask_slot(range.x, (base - range.x) >> 6, tile) * 4 + (uint32_t)(part * PPL);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < PPL; q++) dst[q] = qmask[q];
+                }
+            }
         }
         __syncthreads();
         {
             const uint32_t idx = base + kChunk + lane;
             if (idx < range.y) {
+#if R3_ID_AHEAD
+                nxid = nnid;
+#else
                 nxid = a.point_list[idx];
+#endif
                 const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
                 nxa = g[0];
                 nxb = g[1];
                 nxc = g[2];
             }
+#if R3_ID_AHEAD
+            if (idx + kChunk < range.y) nnid = a.point_list[idx + kChunk];
+#endif
         }
 #if R3_FWD_PAIRED
         // Two surviving entries per trip: their alphas (the exp and the quadratic form, ~70 % of a step) do not depend on
@@ -261,19 +298,23 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 a1[q] = fwd_alpha(s1, pxf[q], pyf[q]);
                 a2[q] = fwd_alpha(s2, pxf[q], pyf[q]);
             }
+#if R3_FWD_EARLY_RGB
+            // the colours are read with the rest of the record, not inside the blend branch behind an LDS round trip
+            asm volatile("" ::"v"(s1.r), "v"(s1.g), "v"(s1.b), "v"(s2.r), "v"(s2.g), "v"(s2.b));
+#endif
             const uint32_t p1 = base - range.x + (uint32_t)j1 + 1u, p2 = base - range.x + (uint32_t)j2 + 1u;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                if (((qmask[q] >> j1) & 1ull) && (live & (1u << q))) {
+                if (PPL == 1 || ((qmask[q] >> j1) & 1ull)) {   // one quadrant per wave: anymask IS its mask
                     float Tb;
-                    if (fwd_apply(s1, a1[q], p1, pix[q], &Tb) == 2) live &= ~(1u << q);
+                    fwd_apply(s1, a1[q], p1, pix[q], &Tb);
                 }
             }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                if (two && ((qmask[q] >> j2) & 1ull) && (live & (1u << q))) {
+                if (two && (PPL == 1 || ((qmask[q] >> j2) & 1ull))) {
                     float Tb;
-                    if (fwd_apply(s2, a2[q], p2, pix[q], &Tb) == 2) live &= ~(1u << q);
+                    fwd_apply(s2, a2[q], p2, pix[q], &Tb);
                 }
             }
         }
@@ -287,10 +328,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
             float tsum = 0.f;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                if (((qmask[q] >> j) & 1ull) && (live & (1u << q))) {
+                if ((qmask[q] >> j) & 1ull) {
                     float Tb;
                     const int r = fwd_step(s, pxf[q], pyf[q], pos1, pix[q], &Tb);
-                    if (r == 2) live &= ~(1u << q);
                     if (COUNTERS && r == 1) {
                         cnt++;
                         tsum += Tb;
@@ -315,11 +355,12 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     for (int q = 0; q < PPL; q++) {
         if (inside[q]) {
             const size_t p = (size_t)a.W * (size_t)pyf[q] + (size_t)pxf[q];
-            a.final_T[p] = pix[q].T;
+            const float T = fwd_pix_T(pix[q]);
+            a.final_T[p] = T;
             a.n_contrib[p] = pix[q].last;
-            a.out_color[p] = pix[q].C0 + pix[q].T * bg0;
-            a.out_color[plane + p] = pix[q].C1 + pix[q].T * bg1;
-            a.out_color[2 * plane + p] = pix[q].C2 + pix[q].T * bg2;
+            a.out_color[p] = pix[q].C0 + T * bg0;
+            a.out_color[plane + p] = pix[q].C1 + T * bg1;
+            a.out_color[2 * plane + p] = pix[q].C2 + T * bg2;
         }
     }
 }
@@ -354,7 +395,8 @@ constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the 
 #ifndef R3_BWD_OCC
 #define R3_BWD_OCC 5
 #endif
-template <int PPL>
+// REUSE: the region pre-test masks are the forward's (BinState::quad_masks) instead of being recomputed per chunk
+template <int PPL, bool REUSE>
 __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
@@ -369,7 +411,11 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
-    const uint2 range = a.ranges[tile];
+    uint2 range = a.ranges[tile];
+#if R3_BWD_SCALAR_RANGE
+    range.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);   // wave-uniform: kept in SGPRs
+    range.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.y);
+#endif
     const size_t plane = (size_t)a.W * a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
@@ -419,6 +465,14 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         nxb = g[1];
         nxc = g[2];
     }
+    // the forward's masks of a chunk travel with its records: lane q < 4 fetches quadrant q's word one chunk ahead
+#if R3_ID_AHEAD
+    uint32_t nnid = 0;
+    if (cfirst >= kChunk) nnid = a.point_list[range.x + (uint32_t)(cfirst - kChunk) + (uint32_t)lane];
+#endif
+    const unsigned long long* const masks0 = REUSE ? a.quad_masks + quad_mask_slot(range.x, 0u, tile) * 4 : nullptr;
+    unsigned long long nxm = 0ull;
+    if (REUSE && lane < 4) nxm = masks0[(size_t)(cfirst >> 6) * 4 + lane];
     // lanes that park the reduced sums of an entry: lane -> component as wave_reduce9 leaves them
     const bool writer = lane < 16 && ((lane & 2) == 0 || lane == 2);
     float* const s_grad_slot = s_grad + reduce9_component(lane);
@@ -433,7 +487,13 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             const bool have = (uint32_t)cbase + (uint32_t)lane < lmax;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
+                if (REUSE) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nxm, q);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nxm >> 32), q);
+                    qmask[q] = ((unsigned long long)hi << 32) | lo;
+                } else {
+                    qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
+                }
                 // entries behind the quadrant's deepest contributor (scalar arithmetic)
                 const uint32_t left = qlast[q] > (uint32_t)cbase ? qlast[q] - (uint32_t)cbase : 0u;
                 if (left < (uint32_t)kChunk) qmask[q] &= (1ull << left) - 1ull;
@@ -441,11 +501,17 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             }
         }
         if (cbase >= kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
+#if R3_ID_AHEAD
+            nxid = nnid;
+            if (cbase >= 2 * kChunk) nnid = a.point_list[range.x + (uint32_t)(cbase - 2 * kChunk) + (uint32_t)lane];
+#else
             nxid = a.point_list[range.x + (uint32_t)(cbase - kChunk) + (uint32_t)lane];
+#endif
             const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
             nxa = g[0];
             nxb = g[1];
             nxc = g[2];
+            if (REUSE && lane < 4) nxm = masks0[(size_t)((cbase - kChunk) >> 6) * 4 + lane];
         }
         __syncthreads();
         const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
@@ -513,7 +579,10 @@ void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs&
 {
     // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
     const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == v.blend.nblocks
-    hipLaunchKernelGGL((blend_bwd_kernel<4>), dim3(nblocks), dim3(64), 0, s, dst, v);
+    if (v.blend.quad_masks)
+        hipLaunchKernelGGL((blend_bwd_kernel<4, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
+    else
+        hipLaunchKernelGGL((blend_bwd_kernel<4, false>), dim3(nblocks), dim3(64), 0, s, dst, v);
 }
 
 }  // namespace r3

@@ -17,14 +17,24 @@ namespace r3 {
 #ifndef R3_HD
 #define R3_HD __host__ __device__ __forceinline__
 #endif
+#ifndef R3_FAST_LOG
+#define R3_FAST_LOG 1
+#endif
+#ifndef R3_FWD_NOIFCVT
+#define R3_FWD_NOIFCVT 1
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define R3_EXP2(x) __builtin_amdgcn_exp2f(x)  // v_exp_f32
-#define R3_LOG(x) __logf(x)
+#if R3_FAST_LOG
+#define R3_LOG2(x) __builtin_amdgcn_logf(x)  // v_log_f32
+#else
+#define R3_LOG2(x) __log2f(x)
+#endif
 #define R3_RCP(x) __builtin_amdgcn_rcpf(x)  // v_rcp_f32, 1 ulp
 #else
 #define R3_EXP2(x) exp2f(x)
-#define R3_LOG(x) logf(x)
+#define R3_LOG2(x) log2f(x)
 #define R3_RCP(x) (1.0f / (x))
 #endif
 
@@ -70,7 +80,7 @@ R3_HD float region_qmin(float x, float y, float A, float B, float C, float X0, f
 R3_HD bool region_may_contribute(const Splat& s, float X0, float X1, float Y0, float Y1)
 {
     if (!(s.cA > 0.f) || !(s.cC > 0.f)) return true;  // degenerate conic: never skip
-    const float tau = R3_LOG(255.0f * s.op);           // alpha >= 1/255  <=>  q <= tau
+    const float tau = 0.6931471805599453f * R3_LOG2(255.0f * s.op);   // alpha >= 1/255  <=>  q <= tau
     const float qmin = region_qmin(s.x, s.y, s.cA, s.cB, s.cC, X0, X1, Y0, Y1);
     return !(qmin > tau + 2e-3f * fabsf(tau) + 2e-3f);  // NaN anywhere => keep
 }
@@ -106,9 +116,22 @@ R3_HD float log2_falloff(const QSplat& s, float dx, float dy)
 }
 
 struct FwdPix {
-    float T, C0, C1, C2;
+    float T;        // transmittance; its SIGN is the reference's `done` flag (forward.cu:548-552): once the pixel is
+                    // saturated -- or if it lies outside the image -- T is kept negated, and T * (1 - alpha) < 0.0001
+                    // then rejects every later entry without a separate test
+    float C0, C1, C2;
     uint32_t last;  // 1-based list position of the last blended entry (n_contrib)
 };
+
+R3_HD void fwd_pix_init(FwdPix& p, bool inside)
+{
+    p.T = inside ? 1.0f : -1.0f;
+    p.C0 = p.C1 = p.C2 = 0.f;
+    p.last = 0;
+}
+
+R3_HD bool fwd_pix_live(const FwdPix& p) { return p.T > 0.0f; }
+R3_HD float fwd_pix_T(const FwdPix& p) { return fabsf(p.T); }
 
 // alpha of one list entry at one pixel (forward.cu:534-546); 0 where the reference skips on power > 0
 R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf)
@@ -124,8 +147,14 @@ R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf)
 R3_HD int fwd_apply(const QSplat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before)
 {
     if (alpha < 1.0f / 255.0f) return 0;
-    const float test_T = p.T * (1.0f - alpha);
-    if (test_T < 0.0001f) return 2;
+    const float test_T = fmaf(-alpha, p.T, p.T);   // T * (1 - alpha), forward.cu:547
+    if (test_T < 0.0001f) {
+        p.T = -fabsf(p.T);
+        return 2;
+    }
+#if R3_FWD_NOIFCVT
+    asm volatile("");   // keeps the rare saturation case a branch: if-converted it costs 6 v_cndmask per blended entry
+#endif
     const float w = alpha * p.T;
     p.C0 += s.r * w;
     p.C1 += s.g * w;

@@ -45,6 +45,11 @@ int env_int(const char* env, int dflt, int lo, int hi)
     const int p = atoi(v);
     return (p >= lo && p <= hi) ? p : dflt;
 }
+bool keep_quad_masks()   // R3DGS_KEEP_QUAD_MASKS=0: the backward repeats the forward's region pre-test (A/B runs)
+{
+    static const bool keep = env_int("R3DGS_KEEP_QUAD_MASKS", 1, 0, 1) != 0;
+    return keep;
+}
 int depth_bucket_load()
 {
     static const int load = env_int("R3DGS_DEPTH_BUCKET_LOAD", 128, 32, 2048);   // 64 / 128 / 256 / 512 measured: 0.106 / 0.084 / 0.099 / 0.139 ms
@@ -635,6 +640,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     f.n_contrib = img.n_contrib;
     f.touched = p.counters ? c.out_touched_pixels : nullptr;
     f.transmittance = p.counters ? c.out_transmittance : nullptr;
+    f.quad_masks = b && keep_quad_masks() ? b->quad_masks : nullptr;
 }
 
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
@@ -707,9 +713,9 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
     plan.reserve = R ? R : 1u;
     plan.grid_pairs = plan.reserve;   // exact size: one block per chunk
-    char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide), binning_user);
+    char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy), binning_user);
     if (!bptr) throw Error("binning allocator returned NULL");
-    BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide);
+    BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
     fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, false);
     launch_write_args(d_args, args, s);   // the completed block (binning pointers, pair capacity)
     issue_forward(plan, d_args, args, s, 2, hooks, &geom);
@@ -731,7 +737,7 @@ long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_
     const size_t depth_temp = cached_depth_temp((size_t)c.P);
     GeomState geom = GeomState::carve(geom_buffer, (size_t)c.P, depth_temp);
     ImageState img = ImageState::carve(image_buffer, (size_t)c.width * c.height, (size_t)plan.gx * plan.gy);
-    BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide);
+    BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
     PassInfo* info_dev = nullptr;
     const uint64_t ticket = new_ticket(dev, c, plan.reserve, &info_dev);
     FwdPassArgs args;
@@ -850,7 +856,7 @@ size_t r3dgs_binning_bytes(int P, int width, int height, int reserve)
         g_last_error.clear();
         const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
         const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
-        return r3::required_bytes<r3::BinState>((size_t)(reserve > 0 ? reserve : 1), l.wide);
+        return r3::required_bytes<r3::BinState>((size_t)(reserve > 0 ? reserve : 1), l.wide, (size_t)gx * gy);
     } catch (const std::exception& e) {
         g_last_error = e.what();
         return 0;
@@ -866,13 +872,13 @@ int r3dgs_binning_capacity(int P, int width, int height, size_t bytes)
     return guarded([&]() {
         const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
         const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
-        if (r3::required_bytes<r3::BinState>((size_t)1, l.wide) > bytes) return 0;
+        if (r3::required_bytes<r3::BinState>((size_t)1, l.wide, (size_t)gx * gy) > bytes) return 0;
         // largest R whose layout fits: every array size is monotone in R, so any R with the same total has the same
         // offsets -- the capacity recovered from a blob's size reproduces the carve the forward used
         long long lo = 1, hi = 0x7fffffffLL;
         while (lo < hi) {
             const long long mid = (lo + hi + 1) / 2;
-            if (r3::required_bytes<r3::BinState>((size_t)mid, l.wide) <= bytes)
+            if (r3::required_bytes<r3::BinState>((size_t)mid, l.wide, (size_t)gx * gy) <= bytes)
                 lo = mid;
             else
                 hi = mid - 1;
@@ -1038,7 +1044,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)plan.gx * plan.gy);
-        BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide);
+        BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
         if (!radii) radii = geom.radii_internal;
 
         BwdPassArgs a;
@@ -1057,6 +1063,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         bb.bg = background;
         bb.pair_grad = bin.pair_grad;
         bb.pair_flag = bin.pair_flag;
+        bb.quad_masks = binning_buffer && keep_quad_masks() ? bin.quad_masks : nullptr;
         PairReduceArgs& pr = a.reduce;
         pr.hdr = geom.header;
         pr.pair_grad = bin.pair_grad;
@@ -1202,7 +1209,7 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
         if (count > R) throw Error("count exceeds the blob's pair capacity");
         if (count > 0 && binning_buffer) {
             const PairLayout l = pair_layout(P, Tn);
-            BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide);
+            BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide, Tn);
             if (keys) launch_export_keys(P, count, Tn, bin, geom, keys, s);
             if (point_list)
                 R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, s));

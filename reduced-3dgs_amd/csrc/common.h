@@ -218,8 +218,11 @@ struct BinState {
     uint32_t* radix_rows;  // [bins][R/kRadixBlock + 1] per-workgroup digit counts, digit-major
     uint32_t* radix_base;  // same shape: first slot of each workgroup inside each digit
     uint32_t* radix_total; // [kMaxRadixPasses][kMaxRadixBins] digit totals of the passes
+    unsigned long long* quad_masks;  // [R/64 + Tn + 2][4] region pre-test of the forward blend, kept for the backward:
+                                     // bit j of [slot][q] = entry j of a 64-entry chunk of a tile's list may reach 8x8
+                                     // quadrant q; slot = quad_mask_slot(first pair of the tile, chunk, tile)
     char* end;
-    static BinState carve(char* base, size_t R, int wide)
+    static BinState carve(char* base, size_t R, int wide, size_t Tn)
     {
         Carver c(base);
         BinState b;
@@ -241,10 +244,19 @@ struct BinState {
         b.radix_rows = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
         b.radix_base = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
+        b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
         b.end = c.p;
         return b;
     }
 };
+
+// Slot of chunk `chunk` (64 entries) of the list of tile `tile`, whose first pair is `first`: lists are contiguous and in
+// tile order, so floor(first / 64) + chunk grows by at least (chunks of the tile) - 1 from a tile to the next; adding the
+// tile id makes the slots of different tiles disjoint without a prefix sum over the tiles' chunk counts.
+R3_HD size_t quad_mask_slot(uint32_t first, uint32_t chunk, uint32_t tile)
+{
+    return (size_t)(first >> 6) + chunk + tile;
+}
 
 struct ImageState {
     float* final_T;       // [N]
@@ -456,6 +468,7 @@ struct BlendFwdArgs {     // blend.hip
     uint32_t* n_contrib;
     int* touched;
     float* transmittance;
+    unsigned long long* quad_masks;   // BinState::quad_masks (null: not kept)
 };
 struct BlendBwdArgs {     // blend.hip
     const uint2* ranges;
@@ -469,6 +482,7 @@ struct BlendBwdArgs {     // blend.hip
     const float* bg;
     float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
     unsigned char* pair_flag;  // [R] set for rows written in this pass
+    const unsigned long long* quad_masks;   // BinState::quad_masks as the forward left them (null: recompute)
 };
 struct PairReduceArgs {   // preprocess_bwd.hip
     const GeomHeader* hdr;

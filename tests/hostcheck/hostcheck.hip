@@ -101,9 +101,7 @@ void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_li
             const int tile = (py / kTile) * gx + px / kTile;
             const float qx0 = (float)((px / 8) * 8), qy0 = (float)((py / 8) * 8);
             FwdPix p;
-            p.T = 1.f;
-            p.C0 = p.C1 = p.C2 = 0.f;
-            p.last = 0;
+            fwd_pix_init(p, true);
             for (unsigned k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
                 float Tb;
                 const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
@@ -118,11 +116,12 @@ void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_li
                 if (fwd_step(s, (float)px, (float)py, k - ranges[2 * tile] + 1, p, &Tb) == 2) break;
             }
             const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
-            final_T[pix] = p.T;
+            const float T = fwd_pix_T(p);
+            final_T[pix] = T;
             n_contrib[pix] = p.last;
-            out_color[pix] = p.C0 + p.T * bg[0];
-            out_color[plane + pix] = p.C1 + p.T * bg[1];
-            out_color[2 * plane + pix] = p.C2 + p.T * bg[2];
+            out_color[pix] = p.C0 + T * bg[0];
+            out_color[plane + pix] = p.C1 + T * bg[1];
+            out_color[2 * plane + pix] = p.C2 + T * bg[2];
         }
 }
 
@@ -201,9 +200,7 @@ long hc_region_fuzz(long n, unsigned seed, long* n_skip, long* n_keep_empty)
         for (int py = 0; py < 8 && !any; py++)
             for (int px = 0; px < 8; px++) {
                 FwdPix p;
-                p.T = 1.f;
-                p.C0 = p.C1 = p.C2 = 0.f;
-                p.last = 0;
+                fwd_pix_init(p, true);
                 float Tb;
                 if (fwd_step(s, X0 + px, Y0 + py, 1, p, &Tb) != 0) {
                     any = true;
