@@ -32,6 +32,20 @@
 
 namespace r3 {
 
+// A pointer read out of a pass block in memory is a generic pointer to the compiler: every access through it is a FLAT
+// instruction, which also counts on lgkmcnt -- so each wait for an LDS read would wait for the global gather in flight.
+// The blocks only ever hold device-global addresses.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R3_GLOBAL __attribute__((address_space(1)))
+#else
+#define R3_GLOBAL   // host pass: the kernels are only parsed
+#endif
+template <class T>
+__device__ __forceinline__ R3_GLOBAL T* global_ptr(T* p)
+{
+    return (R3_GLOBAL T*)p;
+}
+
 constexpr int kChunk = 64;
 
 struct LdsRec {  // 48 B: a staged list entry, conic pre-scaled (QSplat); c.yzw = GRec's rect_min, width_clamp, pair_start
@@ -70,12 +84,24 @@ __device__ __forceinline__ Splat splat_from_regs(const float4& a, const float4& 
     return s;
 }
 
-// lane j parks the entry it gathered (registers a, b, c = the GRec) with the conic pre-scaled
+// Lane j parks the entry it gathered (registers a, b, c = the GRec) with the conic pre-scaled.  Six narrow stores, each
+// either straight out of the gather's destination registers or of freshly computed values: built as three float4
+// the compiler shuffles the loaded components into new register tuples right behind the gather -- and waits for the
+// gather there, which serialises the prefetch of chunk k+1 with the blending of chunk k.
 __device__ __forceinline__ void stage_entry(LdsRec& dst, const float4& a, const float4& b, const float4& c)
 {
-    dst.a = make_float4(a.x, a.y, (-0.5f * kLog2e) * a.z, -kLog2e * a.w);
-    dst.b = make_float4((-0.5f * kLog2e) * b.x, b.y, b.z, b.w);
-    dst.c = c;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    // volatile: or the stores are merged back into float4; explicitly LDS: volatile accesses are not address-space inferred
+#define R3_LDS_V(T) volatile T __attribute__((address_space(3)))*
+    R3_LDS_V(float) d = (R3_LDS_V(float))reinterpret_cast<float*>(&dst);
+    *(R3_LDS_V(v2f))d = v2f{a.x, a.y};
+    *(R3_LDS_V(v2f))(d + 2) = v2f{(-0.5f * kLog2e) * a.z, -kLog2e * a.w};
+    d[4] = (-0.5f * kLog2e) * b.x;
+    d[5] = b.y;
+    *(R3_LDS_V(v2f))(d + 6) = v2f{b.z, b.w};
+    *(R3_LDS_V(v4f))(d + 8) = v4f{c.x, c.y, c.z, c.w};
+#undef R3_LDS_V
 }
 
 // consecutive logical ids on one XCD: hardware places workgroup b on XCD b % 8 (speed only, never correctness)
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
-    uint2 range = a.ranges[tile];
+    uint2 range = global_ptr(a.ranges)[tile];
 #if R3_FWD_SCALAR_RANGE
     range.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);   // wave-uniform: the chunk loop's arithmetic is scalar
     range.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.y);
@@ -222,8 +248,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     uint32_t nxid = 0;
     nxa = nxb = nxc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (range.x + lane < range.y) {
-        nxid = a.point_list[range.x + lane];
-        const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+        nxid = global_ptr(a.point_list)[range.x + lane];
+        const auto* g = (const R3_GLOBAL float4*)global_ptr(a.rec + nxid);
         nxa = g[0];
         nxb = g[1];
         nxc = g[2];
@@ -231,7 +257,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
 #if R3_ID_AHEAD
     // the list ids run one more chunk ahead than the records they index: one memory round trip per chunk, not two
     uint32_t nnid = 0;
-    if (range.x + kChunk + lane < range.y) nnid = a.point_list[range.x + kChunk + lane];
+    if (range.x + kChunk + lane < range.y) nnid = global_ptr(a.point_list)[range.x + kChunk + lane];
 #endif
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
         {
@@ -254,8 +280,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 anymask |= qmask[q];
             }
             if (a.quad_masks) {   // kept for the backward, which walks the same chunks
-                unsigned long long* dst =
-                    a.quad_masks + quad_mask_slot(range.x, (base - range.x) >> 6, tile) * 4 + (uint32_t)(part * PPL);
+                auto* dst =
+                    global_ptr(a.quad_masks) + quad_mask_slot(range.x, (base - range.x) >> 6, tile) * 4 + (uint32_t)(part * PPL);
                 if (lane == 0) {
 #pragma unroll
                     for (int q = 0; q < PPL; q++) dst[q] = qmask[q];
@@ -269,15 +295,15 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
 #if R3_ID_AHEAD
                 nxid = nnid;
 #else
-                nxid = a.point_list[idx];
+                nxid = global_ptr(a.point_list)[idx];
 #endif
-                const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
+                const auto* g = (const R3_GLOBAL float4*)global_ptr(a.rec + nxid);
                 nxa = g[0];
                 nxb = g[1];
                 nxc = g[2];
             }
 #if R3_ID_AHEAD
-            if (idx + kChunk < range.y) nnid = a.point_list[idx + kChunk];
+            if (idx + kChunk < range.y) nnid = global_ptr(a.point_list)[idx + kChunk];
 #endif
         }
 #if R3_FWD_PAIRED
@@ -350,17 +376,17 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         }
     }
     const size_t plane = (size_t)a.W * a.H;
-    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+    const float bg0 = global_ptr(a.bg)[0], bg1 = global_ptr(a.bg)[1], bg2 = global_ptr(a.bg)[2];
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
         if (inside[q]) {
             const size_t p = (size_t)a.W * (size_t)pyf[q] + (size_t)pxf[q];
             const float T = fwd_pix_T(pix[q]);
-            a.final_T[p] = T;
-            a.n_contrib[p] = pix[q].last;
-            a.out_color[p] = pix[q].C0 + T * bg0;
-            a.out_color[plane + p] = pix[q].C1 + T * bg1;
-            a.out_color[2 * plane + p] = pix[q].C2 + T * bg2;
+            global_ptr(a.final_T)[p] = T;
+            global_ptr(a.n_contrib)[p] = pix[q].last;
+            global_ptr(a.out_color)[p] = pix[q].C0 + T * bg0;
+            global_ptr(a.out_color)[plane + p] = pix[q].C1 + T * bg1;
+            global_ptr(a.out_color)[2 * plane + p] = pix[q].C2 + T * bg2;
         }
     }
 }

@@ -5,4 +5,3 @@ cat gpurun_out/summary.log; tail -3 gpurun_out/pytest_gpu.log
 grep -o '"value": [0-9.]*' gpurun_out/bench.log | head -1
 grep -o '"stages": {.*"stages_note"' gpurun_out/bench.log | cut -c1-900
 head -4 gpurun_out/prof/r_kernel_stats.csv | cut -c1-150
-bash tools/other_workloads.sh > gpurun_out/other.log 2>&1; tail -8 gpurun_out/other.log | cut -c1-1200
