@@ -47,7 +47,12 @@ def _newest(paths):
 
 
 def build(force=False, verbose=True):
-    objdir = os.path.join(HERE, "build")
+    global OUT
+    # whole-library A/B builds: R3DGS_BUILD_TAG=<tag> R3DGS_EXTRA_FLAGS="-D..." -> libr3dgs_hip_<tag>.so (own object directory)
+    tag, extra_all = os.environ.get("R3DGS_BUILD_TAG"), os.environ.get("R3DGS_EXTRA_FLAGS", "").split()
+    if tag:
+        OUT = os.path.join(HERE, f"libr3dgs_hip_{tag}.so")
+    objdir = os.path.join(HERE, "build" + (f"_{tag}" if tag else ""))
     os.makedirs(objdir, exist_ok=True)
     hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)])
     jobs = []
@@ -55,7 +60,7 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append(([HIPCC] + COMMON + extra + ["-c", s, "-o", o], src))
+            jobs.append(([HIPCC] + COMMON + extra + extra_all + ["-c", s, "-o", o], src))
     def run(job):
         cmd, name = job
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -72,14 +72,20 @@ void issue_header_reduce(const HeaderArgs* a, hipStream_t s)
 // ---- packed pair words -------------------------------------------------------------------------------------------
 PairLayout pair_layout(int P, size_t n_tiles)
 {
-    static const bool force_wide = [] {   // R3DGS_TILE_SORT=wide: 64-bit words for every shape (A/B runs, tests)
+    static const int forced = [] {   // R3DGS_TILE_SORT=wide | split: that layout for every shape it can hold (A/B runs, tests)
         const char* v = getenv("R3DGS_TILE_SORT");
-        return v && std::string(v) == "wide";
+        return !v ? 0 : std::string(v) == "wide" ? 1 : std::string(v) == "split" ? 2 : 0;
     }();
     PairLayout l;
     l.tile_bits = (int)higher_msb((uint32_t)n_tiles);
     const int rb = (int)higher_msb((uint32_t)P);
-    l.wide = (force_wide || l.tile_bits + rb > 32) ? 1 : 0;
+    const bool fits16 = n_tiles <= 65536;
+    if (forced == 1 || (forced == 2 && !fits16))
+        l.wide = 1;
+    else if (forced == 2)
+        l.wide = 2;
+    else
+        l.wide = l.tile_bits + rb > 32 ? (fits16 ? 2 : 1) : 0;
     l.rank_bits = l.wide ? 32 : rb;
     l.digit_bits = l.tile_bits <= 14 ? 7 : 8;
     l.passes = (l.tile_bits + l.digit_bits - 1) / l.digit_bits;
@@ -88,11 +94,41 @@ PairLayout pair_layout(int P, size_t n_tiles)
     return l;
 }
 
-template <class Word>
-__device__ __forceinline__ uint32_t word_tile(Word w, int rank_bits)
-{
-    return (uint32_t)(w >> rank_bits);
-}
+#ifndef R3_RADIX_STAGED
+#define R3_RADIX_STAGED 1
+#endif
+
+// How the pair words live in memory.  In registers a word is always  tile << rank_bits | Gaussian id.
+struct IoNarrow {   // one 32-bit array
+    typedef uint32_t Reg;
+    static constexpr bool kIdsApart = false;
+    static __device__ __forceinline__ Reg load(const char* buf, uint32_t, uint32_t i) { return reinterpret_cast<const uint32_t*>(buf)[i]; }
+    static __device__ __forceinline__ void store(char* buf, uint32_t*, uint32_t, uint32_t i, Reg w) { reinterpret_cast<uint32_t*>(buf)[i] = w; }
+    static __device__ __forceinline__ uint32_t tile_at(const char* buf, uint32_t cap, uint32_t i, int rank_bits) { return load(buf, cap, i) >> rank_bits; }
+};
+struct IoWide {     // one 64-bit array, rank_bits = 32
+    typedef unsigned long long Reg;
+    static constexpr bool kIdsApart = false;
+    static __device__ __forceinline__ Reg load(const char* buf, uint32_t, uint32_t i) { return reinterpret_cast<const Reg*>(buf)[i]; }
+    static __device__ __forceinline__ void store(char* buf, uint32_t*, uint32_t, uint32_t i, Reg w) { reinterpret_cast<Reg*>(buf)[i] = w; }
+    static __device__ __forceinline__ uint32_t tile_at(const char* buf, uint32_t cap, uint32_t i, int) { return (uint32_t)(load(buf, cap, i) >> 32); }
+};
+struct IoSplit {    // [cap] 32-bit ids, then [cap] 16-bit tile keys; rank_bits = 32.  6 bytes per pair and pass instead of 8,
+                    // the last pass drops its ids straight into point_list, and the emitted ids ARE the backward's run keys
+    typedef unsigned long long Reg;
+    static constexpr bool kIdsApart = true;
+    static __device__ __forceinline__ const unsigned short* keys(const char* buf, uint32_t cap) { return reinterpret_cast<const unsigned short*>(buf + 4 * (size_t)cap); }
+    static __device__ __forceinline__ Reg load(const char* buf, uint32_t cap, uint32_t i)
+    {
+        return ((Reg)keys(buf, cap)[i] << 32) | reinterpret_cast<const uint32_t*>(buf)[i];
+    }
+    static __device__ __forceinline__ void store(char* buf, uint32_t* ids_out, uint32_t cap, uint32_t i, Reg w)
+    {
+        reinterpret_cast<unsigned short*>(buf + 4 * (size_t)cap)[i] = (unsigned short)(w >> 32);
+        (ids_out ? ids_out : reinterpret_cast<uint32_t*>(buf))[i] = (uint32_t)w;
+    }
+    static __device__ __forceinline__ uint32_t tile_at(const char* buf, uint32_t cap, uint32_t i, int) { return keys(buf, cap)[i]; }
+};
 
 // Pair emission, balanced over OUTPUT positions.  The reference loops one thread over all tiles of its
 // Gaussian (rasterizer_impl.cu:106-117); in depth order the nearest -- largest -- splats sit next to each
@@ -133,7 +169,7 @@ __device__ __forceinline__ uint32_t upper_bound_wave(const uint32_t* __restrict_
 // workgroups as the pair count of recent passes needs (FwdPlan::grid_pairs) and stride over the logical blocks: sizing
 // the grid by the reservation left a third of the workgroups with nothing to do but three dependent loads to find that
 // out (+10 us on the backward's segmented sum alone).
-template <class Word>
+template <class IO>
 __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, uint32_t blk)
 {
     __shared__ uint32_t s_hist[kMaxRadixBins];   // first radix digit of the tile sort, counted while emitting
@@ -169,7 +205,7 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     const uint32_t start0 = s_start0;
     // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value)
     for (uint32_t k = threadIdx.x; k < n; k += 256) a.rec[s_id[k]].pair_start = k == 0 ? start0 : s_end[k - 1];
-    Word* __restrict__ out = reinterpret_cast<Word*>(a.words_out);
+    typedef typename IO::Reg Word;
     const int rank_bits = a.rank_bits;
 #pragma unroll
     for (int e = 0; e < kEmitPerBlock / 256; e++) {
@@ -189,8 +225,8 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
             const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
             const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
             const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)a.gx + (uint32_t)r.x + tx;
-            out[pos] = ((Word)tile << rank_bits) | (Word)s_id[lo];   // one word: tile | Gaussian id
-            if (sizeof(Word) == 8) a.pair_rank[pos] = s_id[lo];
+            IO::store(a.words_out, nullptr, a.cap, pos, ((Word)tile << rank_bits) | (Word)s_id[lo]);   // tile | Gaussian id
+            if (a.pair_rank) a.pair_rank[pos] = s_id[lo];
             atomicAdd(&s_hist[tile & (uint32_t)(bins - 1)], 1u);
         }
     }
@@ -198,7 +234,7 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     if ((int)threadIdx.x < bins) a.radix_rows[(size_t)threadIdx.x * a.row_stride + blk] = s_hist[threadIdx.x];
 }
 
-template <class Word>
+template <class IO>
 __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restrict__ ap)
 {
     const EmitArgs a = *ap;
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
     // by a fill of its own on the stream
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.n_tiles; t += gridDim.x * 256u) a.ranges[t] = make_uint2(0u, 0u);
     for (uint32_t blk = blockIdx.x; blk * (uint32_t)kEmitPerBlock < R; blk += gridDim.x) {
-        emit_pairs_block<Word>(a, R, blk);
+        emit_pairs_block<IO>(a, R, blk);
         __syncthreads();
     }
 }
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
 // of counts, and a scatter that ranks its 1024 keys stably -- wave-level match by one ballot per digit bit per round,
 // running per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the passes give the tile-major
 // order with the emission (depth) order preserved inside a tile.
-template <class Word>
+template <class IO>
 __device__ __forceinline__ void radix_hist_block(const RadixArgs& a, uint32_t R, uint32_t blk)
 {
     __shared__ uint32_t s_hist[kMaxRadixBins];
@@ -227,23 +263,22 @@ __device__ __forceinline__ void radix_hist_block(const RadixArgs& a, uint32_t R,
     const int bins = 1 << a.digit_bits;
     if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    const Word* __restrict__ in = reinterpret_cast<const Word*>(a.in);
 #pragma unroll
     for (int k = 0; k < kRadixBlock / 256; k++) {
         const uint32_t i = base + k * 256u + threadIdx.x;
-        if (i < R) atomicAdd(&s_hist[(uint32_t)(in[i] >> a.shift) & (uint32_t)(bins - 1)], 1u);
+        if (i < R) atomicAdd(&s_hist[(IO::tile_at(a.in, a.cap, i, a.rank_bits) >> a.tile_shift) & (uint32_t)(bins - 1)], 1u);
     }
     __syncthreads();
     if ((int)threadIdx.x < bins) a.rows[(size_t)threadIdx.x * a.row_stride + blk] = s_hist[threadIdx.x];
 }
 
-template <class Word>
+template <class IO>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const RadixArgs* __restrict__ ap)
 {
     const RadixArgs a = *ap;
     const uint32_t R = a.hdr->num_pairs;
     for (uint32_t blk = blockIdx.x; blk * (uint32_t)kRadixBlock < R; blk += gridDim.x) {
-        radix_hist_block<Word>(a, R, blk);
+        radix_hist_block<IO>(a, R, blk);
         __syncthreads();
     }
 }
@@ -274,15 +309,18 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(const RadixArgs* 
 
 // (Materialising point_list[pos] = order[rank] here in the last pass was measured: the dependent gather lengthens this
 // kernel by 19 us and saves 13 us in tile_ranges_kernel, so it stays there.)
-template <class Word, int BITS>
+template <class IO, int BITS>
 __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t R, uint32_t blk_id)
 {
     constexpr int kWaves = 4, kRounds = kRadixBlock / 256, kBins = 1 << BITS;
     __shared__ uint32_t s_wcount[kWaves][kBins];   // running per-wave digit counts
     __shared__ uint32_t s_start[kBins];            // exclusive scan of the digit totals
     __shared__ uint32_t s_off[kWaves][kBins];      // digit start + workgroup base + waves below
-    const Word* __restrict__ in = reinterpret_cast<const Word*>(a.in);
-    Word* __restrict__ out = reinterpret_cast<Word*>(a.out);
+#if R3_RADIX_STAGED
+    __shared__ uint32_t s_delta[kBins];
+    __shared__ typename IO::Reg s_keys[kRadixBlock];
+#endif
+    typedef typename IO::Reg Word;
     const int shift = a.shift;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < kWaves * kBins; t += 256) (&s_wcount[0][0])[t] = 0;
@@ -313,7 +351,7 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
         const uint32_t i = blk + r * 64u + lane;
-        key[r] = i < R ? in[i] : (Word)0;
+        key[r] = i < R ? IO::load(a.in, a.cap, i) : (Word)0;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -328,6 +366,59 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+#if R3_RADIX_STAGED
+    // The keys leave through LDS in digit-major order: consecutive lanes then store to consecutive addresses inside a
+    // digit's run (kRadixBlock / kBins keys long on average), instead of every lane to a slot of its own.
+    if (w == 0) {   // exclusive scan of the workgroup's digit totals -> where each digit's run starts in the staging array
+        constexpr int kPer = kBins / 64;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int d = kPer * lane + k;
+            v[k] = s_wcount[0][d] + s_wcount[1][d] + s_wcount[2][d] + s_wcount[3][d];
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += up;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int d = kPer * lane + k;
+            // global slot of staging slot i of digit d = i + s_delta[d] (wrapping arithmetic)
+            s_delta[d] = s_start[d] + a.base[(size_t)d * a.row_stride + blk_id] - run;
+            uint32_t r2 = run;
+#pragma unroll
+            for (int q = 0; q < kWaves; q++) {
+                s_off[q][d] = r2;
+                r2 += s_wcount[q][d];
+            }
+            run += v[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        if (blk + r * 64u + lane < R) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(kBins - 1);
+            s_keys[s_off[w][d] + lrank[r]] = key[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t base0 = blk_id * (uint32_t)kRadixBlock;
+    const uint32_t nvalid = min((uint32_t)kRadixBlock, R - base0);
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const uint32_t i = (uint32_t)r * 256u + threadIdx.x;
+        if (i < nvalid) {
+            const Word k = s_keys[i];
+            const uint32_t d = (uint32_t)(k >> shift) & (uint32_t)(kBins - 1);
+            IO::store(a.out, a.ids_out, a.cap, i + s_delta[d], k);
+        }
+    }
+#else
     for (int d = threadIdx.x; d < kBins; d += 256) {
         uint32_t run = s_start[d] + a.base[(size_t)d * a.row_stride + blk_id];
 #pragma unroll
@@ -341,33 +432,34 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
     for (int r = 0; r < kRounds; r++) {
         if (blk + r * 64u + lane < R) {
             const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(kBins - 1);
-            out[s_off[w][d] + lrank[r]] = key[r];
+            IO::store(a.out, a.ids_out, a.cap, s_off[w][d] + lrank[r], key[r]);
         }
     }
+#endif
 }
 
-template <class Word, int BITS>
+template <class IO, int BITS>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const RadixArgs* __restrict__ ap)
 {
     const RadixArgs a = *ap;
     const uint32_t R = a.hdr->num_pairs;
     for (uint32_t blk = blockIdx.x; blk * (uint32_t)kRadixBlock < R; blk += gridDim.x) {
-        radix_scatter_block<Word, BITS>(a, R, blk);
+        radix_scatter_block<IO, BITS>(a, R, blk);
         __syncthreads();
     }
 }
 
 // rasterizer_impl.cu:124-146 identifyTileRanges on the sorted words; the Gaussian ids (the low bits of the words)
 // are split off into point_list here too.
-template <class Word>
+template <class IO>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __restrict__ ap)
 {
+    typedef typename IO::Reg Word;
     const RangesArgs a = *ap;
     const int R = (int)a.hdr->num_pairs;
   for (int blk = (int)blockIdx.x; blk * 1024 < R; blk += (int)gridDim.x) {
     const int i0 = (blk * 256 + threadIdx.x) * 4;   // four consecutive entries per thread (arrays 256-B aligned)
     if (i0 >= R) continue;
-    const Word* __restrict__ sorted = reinterpret_cast<const Word*>(a.sorted);
     unsigned char* __restrict__ pair_flag = a.pair_flag;
     uint32_t* __restrict__ point_list = a.point_list;
     uint2* ranges = a.ranges;
@@ -377,21 +469,27 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __re
         *reinterpret_cast<uint32_t*>(pair_flag + i0) = 0u;
     else
         for (int k = i0; k < R; k++) pair_flag[k] = 0;
-    Word key[4];
     const int n = min(4, R - i0);
-    for (int k = 0; k < 4; k++) key[k] = k < n ? sorted[i0 + k] : (Word)0;
-    uint32_t prev = i0 ? word_tile(sorted[i0 - 1], rank_bits) : 0xFFFFFFFFu;
-    {
+    uint32_t tile[4];
+    if (IO::kIdsApart) {   // the last pass wrote the ids into point_list itself; only the 16-bit keys are read here
+        for (int k = 0; k < 4; k++) tile[k] = k < n ? IO::tile_at(a.sorted, a.cap, (uint32_t)(i0 + k), rank_bits) : 0u;
+    } else {
+        Word key[4];
+        for (int k = 0; k < 4; k++) key[k] = k < n ? IO::load(a.sorted, a.cap, (uint32_t)(i0 + k)) : (Word)0;
         const Word mask = (((Word)1) << rank_bits) - 1;
         uint32_t id[4];
-        for (int k = 0; k < 4; k++) id[k] = (uint32_t)(key[k] & mask);
+        for (int k = 0; k < 4; k++) {
+            id[k] = (uint32_t)(key[k] & mask);
+            tile[k] = (uint32_t)(key[k] >> rank_bits);
+        }
         if (n == 4)
             *reinterpret_cast<uint4*>(point_list + i0) = make_uint4(id[0], id[1], id[2], id[3]);
         else
             for (int k = 0; k < n; k++) point_list[i0 + k] = id[k];
     }
+    uint32_t prev = i0 ? IO::tile_at(a.sorted, a.cap, (uint32_t)(i0 - 1), rank_bits) : 0xFFFFFFFFu;
     for (int k = 0; k < n; k++) {
-        const uint32_t cur = word_tile(key[k], rank_bits);
+        const uint32_t cur = tile[k];
         const int i = i0 + k;
         if (i == 0)
             ranges[cur].x = 0;
@@ -405,63 +503,70 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const RangesArgs* __re
   }
 }
 
-template <class Word>
+template <class IO>
 static void issue_tile_binning_t(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
 {
     const PairLayout& l = p.layout;
     const uint32_t nbk = (p.grid_pairs + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // <= row_stride; blocks stride
     const int bins = 1 << l.digit_bits;
-    hipLaunchKernelGGL(emit_pairs_kernel<Word>, dim3(nbk), dim3(256), 0, s, &a->emit);
+    hipLaunchKernelGGL(emit_pairs_kernel<IO>, dim3(nbk), dim3(256), 0, s, &a->emit);
     for (int k = 0; k < l.passes; k++) {
         const RadixArgs* ra = &a->radix[k];
-        if (k > 0) hipLaunchKernelGGL(radix_hist_kernel<Word>, dim3(nbk), dim3(256), 0, s, ra);
+        if (k > 0) hipLaunchKernelGGL(radix_hist_kernel<IO>, dim3(nbk), dim3(256), 0, s, ra);
         hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(bins), dim3(256), 0, s, ra);
         if (l.digit_bits == 7)
-            hipLaunchKernelGGL((radix_scatter_kernel<Word, 7>), dim3(nbk), dim3(256), 0, s, ra);
+            hipLaunchKernelGGL((radix_scatter_kernel<IO, 7>), dim3(nbk), dim3(256), 0, s, ra);
         else
-            hipLaunchKernelGGL((radix_scatter_kernel<Word, 8>), dim3(nbk), dim3(256), 0, s, ra);
+            hipLaunchKernelGGL((radix_scatter_kernel<IO, 8>), dim3(nbk), dim3(256), 0, s, ra);
     }
-    hipLaunchKernelGGL(tile_ranges_kernel<Word>, dim3((p.grid_pairs + 1023u) / 1024u), dim3(256), 0, s, &a->ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel<IO>, dim3((p.grid_pairs + 1023u) / 1024u), dim3(256), 0, s, &a->ranges);
 }
 
 void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
 {
-    if (p.layout.wide)
-        issue_tile_binning_t<unsigned long long>(p, a, s);
+    if (p.layout.wide == 2)
+        issue_tile_binning_t<IoSplit>(p, a, s);
+    else if (p.layout.wide == 1)
+        issue_tile_binning_t<IoWide>(p, a, s);
     else
-        issue_tile_binning_t<uint32_t>(p, a, s);
+        issue_tile_binning_t<IoNarrow>(p, a, s);
 }
 
 // debug accessor: rebuild the reference's 64-bit keys (tile << 32 | depth bits) of the sorted list
-template <class Word>
-__global__ __launch_bounds__(256) void export_keys_kernel(int R, int rank_bits, const Word* __restrict__ sorted,
+template <class IO>
+__global__ __launch_bounds__(256) void export_keys_kernel(int R, uint32_t cap, int rank_bits, const char* __restrict__ sorted,
                                                           const uint32_t* __restrict__ point_list,
                                                           const uint32_t* __restrict__ depth_key, uint64_t* keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
-    keys[i] = ((uint64_t)word_tile(sorted[i], rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
+    keys[i] = ((uint64_t)IO::tile_at(sorted, cap, (uint32_t)i, rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
 }
 
-// which buffer of the blob holds the sorted words after the passes (see fill of RadixArgs in capi.hip)
+// which buffer of the blob holds the sorted words (split layout: their keys) after the passes (see the fill of RadixArgs
+// in capi.hip)
 const char* sorted_words(const BinState& b, const PairLayout& l)
 {
     if (l.wide) return (l.passes & 1) ? b.words_b : b.words_a;   // a -> b -> a (-> b)
     return (l.passes & 1) ? b.words_b : b.words_c;                // a -> b -> c (-> b)
 }
 
-void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
+void launch_export_keys(int P, int R, int cap, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
                         hipStream_t s)
 {
     if (R <= 0) return;
     const PairLayout l = pair_layout(P, n_tiles);
     const char* sorted = sorted_words(b, l);
-    if (l.wide)
-        hipLaunchKernelGGL(export_keys_kernel<unsigned long long>, dim3((R + 255) / 256), dim3(256), 0, s, R, l.rank_bits,
-                           reinterpret_cast<const unsigned long long*>(sorted), b.point_list, g.depth_key, keys_out);
+    const dim3 grid((R + 255) / 256), block(256);
+    if (l.wide == 2)
+        hipLaunchKernelGGL(export_keys_kernel<IoSplit>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted, b.point_list,
+                           g.depth_key, keys_out);
+    else if (l.wide == 1)
+        hipLaunchKernelGGL(export_keys_kernel<IoWide>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted, b.point_list,
+                           g.depth_key, keys_out);
     else
-        hipLaunchKernelGGL(export_keys_kernel<uint32_t>, dim3((R + 255) / 256), dim3(256), 0, s, R, l.rank_bits,
-                           reinterpret_cast<const uint32_t*>(sorted), b.point_list, g.depth_key, keys_out);
+        hipLaunchKernelGGL(export_keys_kernel<IoNarrow>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted,
+                           b.point_list, g.depth_key, keys_out);
 }
 
 }  // namespace r3

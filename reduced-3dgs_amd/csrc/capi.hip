@@ -594,7 +594,8 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
         e.rank_bits = l.rank_bits;
         e.digit_bits = l.digit_bits;
         e.words_out = b->words_a;
-        e.pair_rank = l.wide ? b->pair_rank : nullptr;
+        e.cap = p.reserve;
+        e.pair_rank = l.wide == 1 ? b->pair_rank : nullptr;
         e.ranges = img.ranges;
         e.n_tiles = (uint32_t)Tn;
         e.radix_rows = b->radix_rows;
@@ -608,8 +609,12 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
             r.hdr = g.header;
             r.in = src;
             r.out = dst;
+            r.ids_out = (l.wide == 2 && k == l.passes - 1) ? b->point_list : nullptr;
+            r.cap = p.reserve;
             r.shift = l.rank_bits + k * l.digit_bits;
             r.digit_bits = l.digit_bits;
+            r.rank_bits = l.rank_bits;
+            r.tile_shift = k * l.digit_bits;
             r.rows = b->radix_rows;
             r.base = b->radix_base;
             r.total = b->radix_total + k * kMaxRadixBins;
@@ -620,6 +625,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
         RangesArgs& t = a.ranges;
         t.hdr = g.header;
         t.sorted = src;
+        t.cap = p.reserve;
         t.rank_bits = l.rank_bits;
         t.order = nullptr;   // the words carry Gaussian ids
         t.point_list = b->point_list;
@@ -646,7 +652,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
 {
     return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
-           ((uint32_t)p.layout.wide << 5) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7);
+           ((uint32_t)p.layout.wide << 8) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7);
 }
 
 int current_device()
@@ -1210,7 +1216,7 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
         if (count > 0 && binning_buffer) {
             const PairLayout l = pair_layout(P, Tn);
             BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide, Tn);
-            if (keys) launch_export_keys(P, count, Tn, bin, geom, keys, s);
+            if (keys) launch_export_keys(P, count, R, Tn, bin, geom, keys, s);
             if (point_list)
                 R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, s));
         }

@@ -193,13 +193,17 @@ inline uint32_t higher_msb(uint32_t n)
 // 32-bit words while tile bits + id bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | id)
 // above -- every real scene.  Two or three stable passes of <= 8-bit digits, 1024 keys per workgroup.
 // Forward and backward derive the same layout from (P, #tiles) alone.
-constexpr int kRadixBlock = 1024;
+#ifndef R3_RADIX_BLOCK
+#define R3_RADIX_BLOCK 2048   // 1024 / 2048 / 4096: tile binning 0.097 / 0.092 / 0.107 ms at 500 k, 0.327 / 0.280 / 0.294 ms at 2 M
+#endif
+constexpr int kRadixBlock = R3_RADIX_BLOCK;
 constexpr int kMaxRadixBins = 256;
 constexpr int kMaxRadixPasses = 3;
 struct PairLayout {
     int tile_bits;   // bits holding the tile id
     int rank_bits;   // shift of the tile id inside the word = bits holding the Gaussian id (32 for wide words)
-    int wide;        // 1: 64-bit words
+    int wide;        // 0: 32-bit words (tile | id);  1: 64-bit words (tile << 32 | id);  2: split -- a 16-bit tile key array
+                     // and a 32-bit id array (6 bytes per pair through the passes instead of 8; needs <= 65536 tiles)
     int passes;      // radix passes over the tile bits
     int digit_bits;  // bits per pass
 };
@@ -230,11 +234,16 @@ struct BinState {
         b.pair_grad = c.take<float>(R * kPairStride);
         b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
         b.pair_flag = c.take<unsigned char>(R);
-        if (wide) {
+        if (wide == 1) {
             b.pair_rank = c.take<uint32_t>(R);
             b.words_a = reinterpret_cast<char*>(c.take<unsigned long long>(R));
             b.words_b = reinterpret_cast<char*>(c.take<unsigned long long>(R));
             b.words_c = nullptr;
+        } else if (wide == 2) {   // per buffer: [R] ids, then [R] 16-bit keys; the emission-order ids of buffer A survive
+            b.words_a = reinterpret_cast<char*>(c.take<unsigned long long>(R));
+            b.words_b = reinterpret_cast<char*>(c.take<unsigned long long>(R));
+            b.words_c = nullptr;
+            b.pair_rank = reinterpret_cast<uint32_t*>(b.words_a);
         } else {
             b.words_a = reinterpret_cast<char*>(c.take<uint32_t>(R));
             b.words_b = reinterpret_cast<char*>(c.take<uint32_t>(R));
@@ -431,7 +440,8 @@ struct EmitArgs {         // binning.hip emit_pairs_kernel
     GRec* rec;
     int rank_bits, digit_bits;
     char* words_out;
-    uint32_t* pair_rank;   // wide words only (else nullptr)
+    uint32_t cap;          // pair capacity of the word buffers (the split layout's key array starts behind cap ids)
+    uint32_t* pair_rank;   // 64-bit words only (else nullptr: it aliases the emitted words / ids)
     uint2* ranges;
     uint32_t n_tiles;
     uint32_t* radix_rows;
@@ -441,7 +451,10 @@ struct RadixArgs {        // binning.hip one LSD pass (hist -> digit scan -> sca
     const GeomHeader* hdr;
     const char* in;
     char* out;
-    int shift, digit_bits;
+    uint32_t* ids_out;     // split layout, last pass: the ids go straight into point_list (else nullptr)
+    uint32_t cap;
+    int shift, digit_bits; // shift = rank_bits + tile_shift: position of the pass's digit inside a register word
+    int rank_bits, tile_shift;
     uint32_t* rows;
     uint32_t* base;
     uint32_t* total;
@@ -450,6 +463,7 @@ struct RadixArgs {        // binning.hip one LSD pass (hist -> digit scan -> sca
 struct RangesArgs {       // binning.hip tile_ranges_kernel
     const GeomHeader* hdr;
     const char* sorted;
+    uint32_t cap;
     int rank_bits;
     const uint32_t* order;
     uint32_t* point_list;
@@ -565,7 +579,7 @@ void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* a, hipStrea
 void run_generic_depth_sort(int P, GeomState& g, hipStream_t s);   // rocPRIM, host pointers: direct issue only
 void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);
 const char* sorted_words(const BinState& b, const PairLayout& l);   // which blob buffer holds the sorted words
-void launch_export_keys(int P, int R, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
+void launch_export_keys(int P, int R, int cap, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
                         hipStream_t s);
 
 void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s);

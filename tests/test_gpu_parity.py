@@ -440,7 +440,8 @@ def test_repeated_backward_and_pair_sort_path(C_):
     """(1) Two backward passes over one forward state (retain_graph): the per-pair "row written" flags are cleared
     by the forward and again by every backward, so the second pass must equal the first bit for bit.
     (2) The 64-bit pair words, used when tile bits + depth-rank bits exceed 32, give the same integer outputs as the
-    32-bit ones: forced here in a child process via R3DGS_TILE_SORT=wide (together with the generic depth sort)."""
+    32-bit ones, and so does the split key / id layout: forced here in child processes via R3DGS_TILE_SORT=wide | split
+    (together with the generic depth sort)."""
     import subprocess
     import sys
     W, H, P = 320, 240, 6000
@@ -472,9 +473,11 @@ def test_repeated_backward_and_pair_sort_path(C_):
         "t.check_forward(_C, fout, ref, 240, 320, 6000)\n"
         "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), t.orc.backward(ref['state'], dl, 0.1), ref['state'], 16)\n"
         "print('pairs-path-ok')\n") % (ROOT, os.path.join(ROOT, "reduced-3dgs_amd"))
-    env = dict(os.environ, R3DGS_TILE_SORT="wide", R3DGS_DEPTH_SORT="generic")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
-    assert "pairs-path-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # wide: 64-bit words; split: 16-bit tile keys + 32-bit ids in two arrays (what scenes of more than 2^19 Gaussians use)
+    for layout, depth in (("wide", "generic"), ("split", "generic"), ("split", "bucket")):
+        env = dict(os.environ, R3DGS_TILE_SORT=layout, R3DGS_DEPTH_SORT=depth)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+        assert "pairs-path-ok" in out.stdout, layout + out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_optimisation_through_the_boundary_fits_target_views(C_):
