@@ -176,11 +176,14 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     __shared__ uint32_t s_end[kEmitSlice];
     __shared__ uint32_t s_id[kEmitSlice];
     __shared__ ushort4 s_rect[kEmitSlice];
+    __shared__ uint32_t s_owner[kEmitPerBlock];
+    __shared__ uint32_t s_wmax[4];
     __shared__ uint32_t s_j[2];
     __shared__ uint32_t s_start0;
     const int bins = 1 << a.digit_bits;
     const uint32_t pos0 = blk * (uint32_t)kEmitPerBlock;
     if ((int)threadIdx.x < bins) s_hist[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kEmitPerBlock; i += 256) s_owner[i] = 0;
     const uint32_t* __restrict__ offsets = a.offsets;
     const uint32_t pos1 = min(R, pos0 + (uint32_t)kEmitPerBlock);  // exclusive
     if (threadIdx.x < 128) {   // wave 0 locates the first slot's Gaussian, wave 1 the last slot's
@@ -203,22 +206,44 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     }
     __syncthreads();
     const uint32_t start0 = s_start0;
-    // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value)
-    for (uint32_t k = threadIdx.x; k < n; k += 256) a.rec[s_id[k]].pair_start = k == 0 ? start0 : s_end[k - 1];
+    // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value), and mark the
+    // slot it starts at with its slice index: a running maximum over the slots then names every slot's Gaussian
+    // (a binary search per slot over the slice's end offsets cost ~11 dependent LDS reads per pair instead)
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+        const uint32_t start = k == 0 ? start0 : s_end[k - 1];
+        a.rec[s_id[k]].pair_start = start;
+        if (start >= pos0) s_owner[start - pos0] = k;   // start < pos1: the slice ends at the last slot's Gaussian
+    }
+    __syncthreads();
+    {
+        constexpr int E = kEmitPerBlock / 256;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t v[E];
+#pragma unroll
+        for (int i = 0; i < E; i++) v[i] = s_owner[threadIdx.x * E + i];
+#pragma unroll
+        for (int i = 1; i < E; i++) v[i] = max(v[i], v[i - 1]);
+        uint32_t incl = v[E - 1];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl = max(incl, up);
+        }
+        if (lane == 63) s_wmax[w] = incl;
+        uint32_t before = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) before = 0;
+        __syncthreads();
+        for (int q = 0; q < w; q++) before = max(before, s_wmax[q]);
+#pragma unroll
+        for (int i = 0; i < E; i++) s_owner[threadIdx.x * E + i] = max(v[i], before);
+    }
+    __syncthreads();
     typedef typename IO::Reg Word;
     const int rank_bits = a.rank_bits;
 #pragma unroll
     for (int e = 0; e < kEmitPerBlock / 256; e++) {
         const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
         if (pos < pos1) {
-            uint32_t lo = 0, hi = n - 1;  // smallest k with s_end[k] > pos; exists because pos < s_end[n-1]
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_end[mid] > pos)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
+            const uint32_t lo = s_owner[pos - pos0];   // the staged Gaussian this slot belongs to
             const uint32_t start = lo == 0 ? start0 : s_end[lo - 1];
             const uint32_t local = pos - start;
             const ushort4 r = s_rect[lo];
