@@ -316,20 +316,23 @@ __global__ __launch_bounds__(256) void radix_digit_scan_kernel(const RadixArgs* 
     const uint32_t nb = (a.hdr->num_pairs + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;   // live workgroups
     const uint32_t* row = a.rows + (size_t)blockIdx.x * a.row_stride;
     uint32_t* out = a.base + (size_t)blockIdx.x * a.row_stride;
-    const uint32_t per = (nb + 255u) / 256u, e0 = threadIdx.x * per;
-    uint32_t mine = 0;
-#pragma unroll 8
-    for (uint32_t k = 0; k < per; k++) mine += e0 + k < nb ? row[e0 + k] : 0u;
-    const uint32_t incl = block256_inclusive_scan(mine, s_sum);
-    uint32_t run = incl - mine;
-#pragma unroll 8
-    for (uint32_t k = 0; k < per; k++)
-        if (e0 + k < nb) {
-            const uint32_t v = row[e0 + k];
-            out[e0 + k] = run;
-            run += v;
-        }
-    if (threadIdx.x == 255) a.total[blockIdx.x] = incl;
+    // 1024 counts per trip, four consecutive ones per thread as one 16-byte access (rows are padded to a multiple of
+    // four counts and 16-byte aligned, capi.hip); counts of workgroups that do not exist read as zero
+    uint32_t run = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024u) {
+        const uint32_t i = c0 + threadIdx.x * 4u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nb) v = *reinterpret_cast<const uint4*>(row + i);
+        if (i + 1 >= nb) v.y = 0u;
+        if (i + 2 >= nb) v.z = 0u;
+        if (i + 3 >= nb) v.w = 0u;
+        const uint32_t mine = v.x + v.y + v.z + v.w;
+        const uint32_t incl = block256_inclusive_scan(mine, s_sum);
+        const uint32_t b0 = run + incl - mine;
+        if (i < nb) *reinterpret_cast<uint4*>(out + i) = make_uint4(b0, b0 + v.x, b0 + v.x + v.y, b0 + v.x + v.y + v.z);
+        run += s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];   // stays valid: the next scan starts with a barrier
+    }
+    if (threadIdx.x == 0) a.total[blockIdx.x] = run;
 }
 
 // (Materialising point_list[pos] = order[rank] here in the last pass was measured: the dependent gather lengthens this

@@ -582,7 +582,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     const PairLayout& l = p.layout;
     const size_t Tn = (size_t)p.gx * p.gy;
     if (b) {
-        const uint32_t stride = (p.reserve + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;
+        const uint32_t stride = radix_row_stride(p.reserve);
         EmitArgs& e = a.emit;
         e.P = c.P;
         e.gx = p.gx;

@@ -209,6 +209,13 @@ struct PairLayout {
 };
 PairLayout pair_layout(int P, size_t n_tiles);   // binning.hip (honours R3DGS_TILE_SORT=wide for A/B runs and tests)
 
+// workgroups of the emission / radix grids for R pairs, padded so that every digit's row of per-workgroup counts starts
+// 16-byte aligned (the digit scan moves four counts per access)
+inline uint32_t radix_row_stride(size_t R)
+{
+    return (uint32_t)(((R + kRadixBlock - 1) / kRadixBlock + 3) & ~(size_t)3);
+}
+
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
@@ -250,8 +257,8 @@ struct BinState {
             b.words_c = reinterpret_cast<char*>(c.take<uint32_t>(R));
             b.pair_rank = reinterpret_cast<uint32_t*>(b.words_a);
         }
-        b.radix_rows = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
-        b.radix_base = c.take<uint32_t>((size_t)kMaxRadixBins * (R / kRadixBlock + 1));
+        b.radix_rows = c.take<uint32_t>((size_t)kMaxRadixBins * radix_row_stride(R));
+        b.radix_base = c.take<uint32_t>((size_t)kMaxRadixBins * radix_row_stride(R));
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
         b.end = c.p;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
             const float4 r0 = src[0], r1 = src[1];
             v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w;
             v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
-            v[8] = pair_grad[(size_t)e * kPairStride + 8];
+            v[8] = src[2].x;
         }
     }
     // Inclusive segmented scan over equal-key runs, on DPP (VALU) moves only: Kogge-Stone inside each row of 16 lanes
@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
         const uint32_t gid = order ? order[key] : key;
         const uint32_t gbase = e & ~63u, start = rec[gid].pair_start, end = start + tiles[gid];
         if (start >= gbase && end <= gbase + 64u) {
-            float* dst = acc + (size_t)gid * kAccStride;
-#pragma unroll
-            for (int k = 0; k < kPairGrad; k++) dst[k] = v[k];
+            float4* dst = reinterpret_cast<float4*>(acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
         } else {
             float* wp = wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
             if (start < gbase) {  // continues a run of the previous group: this group's leading piece
