@@ -57,15 +57,16 @@ def stage_bytes(P, R, N, Tn, Kbar):
 STAGE_KERNELS = {
     "preprocess_fwd": [("r3::preprocess_geom_kernel", 1, False)],
     # the SH -> RGB stream rides in spare workgroups of three of the four depth-sort kernels (preprocess.hip)
-    "depth_sort_scan": [("r3::header_reduce_kernel", 1, True), ("r3::depth_sort_color_kernel<0, false>", 1, True),
+    # (the header reduction is fused into the histogram workgroups on the asynchronous path)
+    "depth_sort_scan": [("r3::depth_sort_color_kernel<0, false>", 1, True),
                         ("r3::depth_colscan_kernel", 1, False), ("r3::depth_sort_color_kernel<1, false>", 1, True),
                         ("r3::depth_sort_color_kernel<2, false>", 1, True)],
-    "tile_binning": [("r3::emit_pairs_kernel<unsigned int>", 1, False), ("r3::radix_digit_scan_kernel", 2, False),
-                     ("r3::radix_scatter_kernel<unsigned int, 7>", 2, False),
-                     ("r3::radix_hist_kernel<unsigned int>", 1, False),
-                     ("r3::tile_ranges_kernel<unsigned int>", 1, True)],
+    "tile_binning": [("r3::emit_pairs_kernel<r3::IoNarrow>", 1, False), ("r3::radix_digit_scan_kernel", 2, False),
+                     ("r3::radix_scatter_kernel<r3::IoNarrow, 7>", 2, False),
+                     ("r3::radix_hist_kernel<r3::IoNarrow>", 1, False),
+                     ("r3::tile_ranges_kernel<r3::IoNarrow>", 1, True)],
     "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
-    "blend_bwd": [("r3::blend_bwd_kernel<4>", 1, True), ("r3::pair_reduce_kernel", 1, False)],
+    "blend_bwd": [("r3::blend_bwd_kernel<4, true>", 1, True), ("r3::pair_reduce_kernel", 1, False)],
     "preprocess_bwd": [("r3::preprocess_bwd_kernel", 1, False)],
 }
 

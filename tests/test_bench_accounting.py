@@ -29,9 +29,9 @@ def test_pmc_traffic_uses_the_committed_counters():
         for name, launches, wide in kernels:
             assert name in pmc, name
     t = bench.pmc_traffic("blend_bwd", "metric_500k_1600x1062")
-    # the x2 FETCH_SIZE correction only for the kernel with 16-B/lane loads
-    want = ((2 * pmc["r3::blend_bwd_kernel<4>"]["FETCH_SIZE"] + pmc["r3::blend_bwd_kernel<4>"]["WRITE_SIZE"]) +
-            (pmc["r3::pair_reduce_kernel"]["FETCH_SIZE"] + pmc["r3::pair_reduce_kernel"]["WRITE_SIZE"])) * 1024
+    # FETCH_SIZE x2 for the kernels whose loads are 16 B / lane (STAGE_KERNELS' wide flag), WRITE_SIZE as reported
+    want = sum(launches * ((2 if wide else 1) * pmc[name]["FETCH_SIZE"] + pmc[name]["WRITE_SIZE"])
+               for name, launches, wide in bench.STAGE_KERNELS["blend_bwd"]) * 1024
     assert t == int(want) and 1e8 < t < 7e8
     assert bench.pmc_traffic("blend_bwd", "some_other_workload") is None
 
