@@ -94,9 +94,6 @@ PairLayout pair_layout(int P, size_t n_tiles)
     return l;
 }
 
-#ifndef R3_RADIX_STAGED
-#define R3_RADIX_STAGED 1
-#endif
 
 // How the pair words live in memory.  In registers a word is always  tile << rank_bits | Gaussian id.
 struct IoNarrow {   // one 32-bit array
@@ -344,10 +341,8 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
     __shared__ uint32_t s_wcount[kWaves][kBins];   // running per-wave digit counts
     __shared__ uint32_t s_start[kBins];            // exclusive scan of the digit totals
     __shared__ uint32_t s_off[kWaves][kBins];      // digit start + workgroup base + waves below
-#if R3_RADIX_STAGED
     __shared__ uint32_t s_delta[kBins];
     __shared__ typename IO::Reg s_keys[kRadixBlock];
-#endif
     typedef typename IO::Reg Word;
     const int shift = a.shift;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -394,7 +389,6 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-#if R3_RADIX_STAGED
     // The keys leave through LDS in digit-major order: consecutive lanes then store to consecutive addresses inside a
     // digit's run (kRadixBlock / kBins keys long on average), instead of every lane to a slot of its own.
     if (w == 0) {   // exclusive scan of the workgroup's digit totals -> where each digit's run starts in the staging array
@@ -446,24 +440,6 @@ __device__ __forceinline__ void radix_scatter_block(const RadixArgs& a, uint32_t
             IO::store(a.out, a.ids_out, a.cap, i + s_delta[d], k);
         }
     }
-#else
-    for (int d = threadIdx.x; d < kBins; d += 256) {
-        uint32_t run = s_start[d] + a.base[(size_t)d * a.row_stride + blk_id];
-#pragma unroll
-        for (int k = 0; k < kWaves; k++) {
-            s_off[k][d] = run;
-            run += s_wcount[k][d];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kRounds; r++) {
-        if (blk + r * 64u + lane < R) {
-            const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(kBins - 1);
-            IO::store(a.out, a.ids_out, a.cap, s_off[w][d] + lrank[r], key[r]);
-        }
-    }
-#endif
 }
 
 template <class IO, int BITS>

@@ -194,21 +194,6 @@ __device__ __forceinline__ void pixel_of(int tile_x, int tile_y, int part, int q
     *py = tile_y * kTile + (b4 >> 1) * 8 + (lane >> 3);
 }
 
-#ifndef R3_FWD_SCALAR_RANGE
-#define R3_FWD_SCALAR_RANGE 0   // readfirstlane of the tile's range: forward 0.174 -> 0.185 ms (measured), so it stays a VGPR
-#endif
-#ifndef R3_BWD_SCALAR_RANGE
-#define R3_BWD_SCALAR_RANGE 1
-#endif
-#ifndef R3_ID_AHEAD
-#define R3_ID_AHEAD 1
-#endif
-#ifndef R3_FWD_EARLY_RGB
-#define R3_FWD_EARLY_RGB 0
-#endif
-#ifndef R3_FWD_PAIRED
-#define R3_FWD_PAIRED 1   // 0.176 -> 0.171 ms
-#endif
 template <int PPL, bool COUNTERS>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __restrict__ ap)
 {
@@ -221,11 +206,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
-    uint2 range = global_ptr(a.ranges)[tile];
-#if R3_FWD_SCALAR_RANGE
-    range.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);   // wave-uniform: the chunk loop's arithmetic is scalar
-    range.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.y);
-#endif
+    // (stays in VGPRs: made wave-uniform by readfirstlane, the scalar loop control cost 0.174 -> 0.185 ms here)
+    const uint2 range = global_ptr(a.ranges)[tile];
 
     float pxf[PPL], pyf[PPL], qx0[PPL], qy0[PPL];
     FwdPix pix[PPL];
@@ -254,11 +236,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         nxb = g[1];
         nxc = g[2];
     }
-#if R3_ID_AHEAD
     // the list ids run one more chunk ahead than the records they index: one memory round trip per chunk, not two
     uint32_t nnid = 0;
     if (range.x + kChunk + lane < range.y) nnid = global_ptr(a.point_list)[range.x + kChunk + lane];
-#endif
     for (uint32_t base = range.x; base < range.y; base += kChunk) {
         {
             bool live = false;
@@ -292,21 +272,14 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         {
             const uint32_t idx = base + kChunk + lane;
             if (idx < range.y) {
-#if R3_ID_AHEAD
                 nxid = nnid;
-#else
-                nxid = global_ptr(a.point_list)[idx];
-#endif
                 const auto* g = (const R3_GLOBAL float4*)global_ptr(a.rec + nxid);
                 nxa = g[0];
                 nxb = g[1];
                 nxc = g[2];
             }
-#if R3_ID_AHEAD
             if (idx + kChunk < range.y) nnid = global_ptr(a.point_list)[idx + kChunk];
-#endif
         }
-#if R3_FWD_PAIRED
         // Two surviving entries per trip: their alphas (the exp and the quadratic form, ~70 % of a step) do not depend on
         // the pixel state, so they are evaluated side by side before the sequential compositing of first one, then the
         // other -- twice the independent work between dependent instructions, half the scalar loop overhead.
@@ -324,10 +297,6 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 a1[q] = fwd_alpha(s1, pxf[q], pyf[q]);
                 a2[q] = fwd_alpha(s2, pxf[q], pyf[q]);
             }
-#if R3_FWD_EARLY_RGB
-            // the colours are read with the rest of the record, not inside the blend branch behind an LDS round trip
-            asm volatile("" ::"v"(s1.r), "v"(s1.g), "v"(s1.b), "v"(s2.r), "v"(s2.g), "v"(s2.b));
-#endif
             const uint32_t p1 = base - range.x + (uint32_t)j1 + 1u, p2 = base - range.x + (uint32_t)j2 + 1u;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
@@ -344,7 +313,6 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
                 }
             }
         }
-#endif
         while (anymask) {  // surviving entries, front to back
             const int j = __builtin_ctzll(anymask);
             anymask &= anymask - 1ull;
@@ -416,14 +384,11 @@ void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the flush reads without bank conflicts)
 
+// REUSE: the region pre-test masks are the forward's (BinState::quad_masks) instead of being recomputed per chunk.
 // 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
-// (0.5174 vs 0.5170 ms): occupancy is not what limits this kernel.
-#ifndef R3_BWD_OCC
-#define R3_BWD_OCC 5
-#endif
-// REUSE: the region pre-test masks are the forward's (BinState::quad_masks) instead of being recomputed per chunk
+// (0.5174 vs 0.5170 ms), 3 / 4 likewise: the grid only has 6.5 waves per SIMD.
 template <int PPL, bool REUSE>
-__global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
+__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
     // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from
@@ -438,10 +403,8 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
     uint2 range = a.ranges[tile];
-#if R3_BWD_SCALAR_RANGE
     range.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);   // wave-uniform: kept in SGPRs
     range.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.y);
-#endif
     const size_t plane = (size_t)a.W * a.H;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
@@ -491,11 +454,9 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         nxb = g[1];
         nxc = g[2];
     }
-    // the forward's masks of a chunk travel with its records: lane q < 4 fetches quadrant q's word one chunk ahead
-#if R3_ID_AHEAD
-    uint32_t nnid = 0;
+    uint32_t nnid = 0;   // list ids run one more chunk ahead than the records they index
     if (cfirst >= kChunk) nnid = a.point_list[range.x + (uint32_t)(cfirst - kChunk) + (uint32_t)lane];
-#endif
+    // the forward's masks of a chunk travel with its records: lane q < 4 fetches quadrant q's word one chunk ahead
     const unsigned long long* const masks0 = REUSE ? a.quad_masks + quad_mask_slot(range.x, 0u, tile) * 4 : nullptr;
     unsigned long long nxm = 0ull;
     if (REUSE && lane < 4) nxm = masks0[(size_t)(cfirst >> 6) * 4 + lane];
@@ -527,12 +488,8 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             }
         }
         if (cbase >= kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
-#if R3_ID_AHEAD
             nxid = nnid;
             if (cbase >= 2 * kChunk) nnid = a.point_list[range.x + (uint32_t)(cbase - 2 * kChunk) + (uint32_t)lane];
-#else
-            nxid = a.point_list[range.x + (uint32_t)(cbase - kChunk) + (uint32_t)lane];
-#endif
             const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
             nxa = g[0];
             nxb = g[1];

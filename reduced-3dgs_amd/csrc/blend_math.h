@@ -17,20 +17,10 @@ namespace r3 {
 #ifndef R3_HD
 #define R3_HD __host__ __device__ __forceinline__
 #endif
-#ifndef R3_FAST_LOG
-#define R3_FAST_LOG 1
-#endif
-#ifndef R3_FWD_NOIFCVT
-#define R3_FWD_NOIFCVT 1
-#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define R3_EXP2(x) __builtin_amdgcn_exp2f(x)  // v_exp_f32
-#if R3_FAST_LOG
 #define R3_LOG2(x) __builtin_amdgcn_logf(x)  // v_log_f32
-#else
-#define R3_LOG2(x) __log2f(x)
-#endif
 #define R3_RCP(x) __builtin_amdgcn_rcpf(x)  // v_rcp_f32, 1 ulp
 #else
 #define R3_EXP2(x) exp2f(x)
@@ -152,9 +142,7 @@ R3_HD int fwd_apply(const QSplat& s, float alpha, uint32_t pos1, FwdPix& p, floa
         p.T = -fabsf(p.T);
         return 2;
     }
-#if R3_FWD_NOIFCVT
     asm volatile("");   // keeps the rare saturation case a branch: if-converted it costs 6 v_cndmask per blended entry
-#endif
     const float w = alpha * p.T;
     p.C0 += s.r * w;
     p.C1 += s.g * w;

@@ -193,10 +193,8 @@ inline uint32_t higher_msb(uint32_t n)
 // 32-bit words while tile bits + id bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | id)
 // above -- every real scene.  Two or three stable passes of <= 8-bit digits, 1024 keys per workgroup.
 // Forward and backward derive the same layout from (P, #tiles) alone.
-#ifndef R3_RADIX_BLOCK
-#define R3_RADIX_BLOCK 2048   // 1024 / 2048 / 4096: tile binning 0.097 / 0.092 / 0.107 ms at 500 k, 0.327 / 0.280 / 0.294 ms at 2 M
-#endif
-constexpr int kRadixBlock = R3_RADIX_BLOCK;
+constexpr int kRadixBlock = 2048;   // pairs per workgroup of the emission / radix kernels; 1024 / 2048 / 4096: tile binning
+                                    // 0.097 / 0.092 / 0.107 ms at 500 k Gaussians, 0.327 / 0.280 / 0.294 ms at 2 M
 constexpr int kMaxRadixBins = 256;
 constexpr int kMaxRadixPasses = 3;
 struct PairLayout {
