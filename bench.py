@@ -89,6 +89,25 @@ def pmc_traffic(stage, workload, path=None):
     return int(total)
 
 
+def pmc_valu(stage, workload, kernel_ms, path=None, simds=1024, ghz=2.4):
+    """VALU-issue view of the stage's first (main) kernel from the same committed PMC passes: the two blend kernels
+    are bound by the VALU issue rate, which an HBM fraction cannot express.  SQ_ACTIVE_INST_VALU
+    counts quad-cycles; busy_ms = the VALU-busy time per SIMD those instructions imply at `ghz`."""
+    path = path or os.path.join(ROOT, PMC_SUMMARY)
+    if workload != "metric_500k_1600x1062" or stage not in STAGE_KERNELS or not os.path.exists(path):
+        return None
+    k = STAGE_KERNELS[stage][0][0]
+    c = json.load(open(path)).get(k, {})
+    if "SQ_INSTS_VALU" not in c or "SQ_ACTIVE_INST_VALU" not in c:
+        return None
+    busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4.0 / simds / (ghz * 1e9) * 1e3
+    return {"kernel": k, "valu_insts": int(c["SQ_INSTS_VALU"]),
+            "cycles_per_inst": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2),
+            "valu_busy_ms_per_simd": round(busy_ms, 4), "stage_ms": round(kernel_ms, 4),
+            "frac_of_stage_time": round(busy_ms / kernel_ms, 3) if kernel_ms else None,
+            "assumes": f"{simds} SIMDs at {ghz} GHz", "source": PMC_SUMMARY}
+
+
 def cgroup_cpu():
     """CPU bandwidth limit and throttling counters of this container (cgroup v2), or None.  The GPU boxes give a job
     256 visible CPUs but a quota of a few: a host side that spins or fans out threads gets frozen for the rest of
@@ -365,7 +384,8 @@ def main():
                     "frac": round(A / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": (PMC_SUMMARY + " (committed rocprofv3 --pmc passes of this command; not "
                                        "collected in this run)") if traffic is not None else None,
-                    "duration_source": "HIP events around the stage on its stream, inside the timed region"}
+                    "duration_source": "HIP events around the stage on its stream, inside the timed region",
+                    "valu_issue": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
     iters_per_s = args.steps * world / elapsed
     B_iter = P * (718 + 36 * Kbar) + R_mean * 280 + N * 40
     gpu_ms = sum(v["avg_ms"] for v in stages.values())

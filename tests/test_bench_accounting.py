@@ -34,6 +34,10 @@ def test_pmc_traffic_uses_the_committed_counters():
                for name, launches, wide in bench.STAGE_KERNELS["blend_bwd"]) * 1024
     assert t == int(want) and 1e8 < t < 7e8
     assert bench.pmc_traffic("blend_bwd", "some_other_workload") is None
+    v = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", 0.4)
+    assert v and v["kernel"] == bench.STAGE_KERNELS["blend_bwd"][0][0] and 3.5 < v["cycles_per_inst"] < 5.0
+    assert 0.3 < v["frac_of_stage_time"] < 1.2
+    assert bench.pmc_valu("blend_bwd", "some_other_workload", 0.4) is None
 
 
 def test_cgroup_probe_never_raises():
