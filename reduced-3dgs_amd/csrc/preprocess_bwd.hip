@@ -39,39 +39,14 @@ struct ShRowLdsRW {
 // No atomics, fixed summation order: the backward is bit-reproducible.  (Letting each Gaussian's lane loop
 // over its own pairs instead cost 0.86 ms: the largest splats own 600+ pairs.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* __restrict__ ap)
+constexpr int kReduceGroups = 1;   // 64-pair groups per wave and trip (2, with all their loads in flight together, measured the
+                                   // same 49 us: the kernel moves whole 128-byte lines of the slab for the ~45 % of its 48-byte
+                                   // rows that are flagged, ~3.6 TB/s of DRAM traffic)
+
+// segmented sum of one 64-pair group (one pair per lane) and the stores of its run totals
+__device__ __forceinline__ void pair_reduce_group(const PairReduceArgs& a, uint32_t e, int lane, bool valid, uint32_t key,
+                                                  float (&v)[kPairGrad], uint32_t key_before, uint32_t key_after)
 {
-    const PairReduceArgs a = *ap;
-    const uint32_t R = a.hdr->num_pairs;
-  for (uint32_t blk = blockIdx.x; blk * 256u < R; blk += gridDim.x) {   // logical blocks strided over the grid (common.h)
-    const float* __restrict__ pair_grad = a.pair_grad;
-    unsigned char* __restrict__ pair_flag = a.pair_flag;
-    const uint32_t* __restrict__ pair_gid = a.pair_rank;
-    const uint32_t rank_mask = a.rank_mask;
-    const uint32_t* __restrict__ order = a.order;
-    const GRec* __restrict__ rec = a.rec;
-    const uint32_t* __restrict__ tiles = a.tiles;
-    float* __restrict__ acc = a.acc;
-    float* __restrict__ wave_part = a.wave_part;
-    const uint32_t e = blk * 256u + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool valid = e < R;
-    float v[kPairGrad];
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < kPairGrad; k++) v[k] = 0.f;
-    if (valid) {
-        // run key: the Gaussian id (low bits of the pair word)
-        key = pair_gid[e] & rank_mask;
-        if (pair_flag[e]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
-            pair_flag[e] = 0;  // consumed: all flags are zero again when this kernel ends (next backward pass)
-            const float4* src = reinterpret_cast<const float4*>(pair_grad + (size_t)e * kPairStride);
-            const float4 r0 = src[0], r1 = src[1];
-            v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w;
-            v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
-            v[8] = src[2].x;
-        }
-    }
     // Inclusive segmented scan over equal-key runs, on DPP (VALU) moves only: Kogge-Stone inside each row of 16 lanes
     // (row_shr 1, 2, 4, 8), then the classic row_bcast:15 / row_bcast:31 pair carries the row totals across -- valid
     // for a SEGMENTED scan because runs are contiguous: a lane shares the key of the broadcast lane iff its run reaches
@@ -96,25 +71,74 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
     R3_SEG_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2 and 3
 #undef R3_SEG_STEP
     const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
+    const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);   // the group's first run (all lanes active here)
     if (valid && (lane == 63 || knext != key)) {  // last lane of a run: holds the run's sum inside this group
-        const uint32_t gid = order ? order[key] : key;
-        const uint32_t gbase = e & ~63u, start = rec[gid].pair_start, end = start + tiles[gid];
-        if (start >= gbase && end <= gbase + 64u) {
-            float4* dst = reinterpret_cast<float4*>(acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
+        const uint32_t gid = a.order ? a.order[key] : key;
+        // does the run reach across the borders of this group?  The neighbouring pairs' keys say so (runs are contiguous:
+        // same key <=> same run); asking the Gaussian's record for its pair range was a dependent gather per run
+        const bool from_before = key == key0 && key_before == key;
+        const bool into_next = lane == 63 && key_after == key;
+        if (!from_before && !into_next) {
+            float4* dst = reinterpret_cast<float4*>(a.acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
             dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
         } else {
-            float* wp = wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
-            if (start < gbase) {  // continues a run of the previous group: this group's leading piece
+            float* wp = a.wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
+            if (from_before) {  // continues a run of the previous group: this group's leading piece
 #pragma unroll
                 for (int k = 0; k < kPairGrad; k++) wp[k] = v[k];
             }
-            if (end > gbase + 64u) {  // continues into the next group: trailing piece
+            if (into_next) {  // continues into the next group: trailing piece
 #pragma unroll
                 for (int k = 0; k < kPairGrad; k++) wp[kPairGrad + k] = v[k];
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* __restrict__ ap)
+{
+    const PairReduceArgs a = *ap;
+    const uint32_t R = a.hdr->num_pairs;
+    constexpr uint32_t kPerBlock = 256u * kReduceGroups;
+  for (uint32_t blk = blockIdx.x; blk * kPerBlock < R; blk += gridDim.x) {   // logical blocks strided over the grid (common.h)
+    const float* __restrict__ pair_grad = a.pair_grad;
+    unsigned char* __restrict__ pair_flag = a.pair_flag;
+    const uint32_t* __restrict__ pair_gid = a.pair_rank;
+    const uint32_t rank_mask = a.rank_mask;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t e0 = blk * kPerBlock + (uint32_t)wave * (64u * kReduceGroups) + (uint32_t)lane;
+    float v[kReduceGroups][kPairGrad];
+    uint32_t key[kReduceGroups], kb[kReduceGroups], ka[kReduceGroups];
+    bool flag[kReduceGroups];
+    // every load of the wave's groups is issued before the first use: keys, flags, neighbours' keys, then the rows
+#pragma unroll
+    for (int g = 0; g < kReduceGroups; g++) {
+        const uint32_t e = e0 + 64u * g, gbase = e & ~63u;
+        key[g] = e < R ? pair_gid[e] & rank_mask : 0xFFFFFFFFu;   // run key: the Gaussian id
+        flag[g] = e < R && pair_flag[e] != 0;
+        kb[g] = gbase > 0u && gbase < R ? pair_gid[gbase - 1u] & rank_mask : 0xFFFFFFFFu;
+        ka[g] = gbase + 64u < R ? pair_gid[gbase + 64u] & rank_mask : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int g = 0; g < kReduceGroups; g++) {
+        const uint32_t e = e0 + 64u * g;
+#pragma unroll
+        for (int k = 0; k < kPairGrad; k++) v[g][k] = 0.f;
+        if (flag[g]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
+            pair_flag[e] = 0;  // consumed: all flags are zero again when this kernel ends (next backward pass)
+            const float4* src = reinterpret_cast<const float4*>(pair_grad + (size_t)e * kPairStride);
+            const float4 r0 = src[0], r1 = src[1];
+            v[g][0] = r0.x; v[g][1] = r0.y; v[g][2] = r0.z; v[g][3] = r0.w;
+            v[g][4] = r1.x; v[g][5] = r1.y; v[g][6] = r1.z; v[g][7] = r1.w;
+            v[g][8] = src[2].x;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < kReduceGroups; g++) {
+        const uint32_t e = e0 + 64u * g;
+        pair_reduce_group(a, e, lane, e < R, key[g], v[g], kb[g], ka[g]);
     }
   }
 }
@@ -122,7 +146,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
 void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
 {
     if (!p.has_pairs) return;
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.grid_pairs + 255u) / 256u), dim3(256), 0, s, a);
+    constexpr uint32_t per = 256u * kReduceGroups;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.grid_pairs + per - 1u) / per), dim3(256), 0, s, a);
 }
 
 __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
