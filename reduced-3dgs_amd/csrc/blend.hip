@@ -16,9 +16,14 @@
 //     quadrant.  The wave then walks only the surviving entries (bit scan over a wave-uniform mask) and
 //     only their surviving quadrants.  Per-pixel decisions are untouched, so image, n_contrib and gradients
 //     are what they are without the pre-test.
-//   * backward: the 9 partial sums of an entry are added over the lane's pixels, reduced across the wave with
-//     DPP row operations (no LDS traffic; finishing the last two steps with 4 same-address LDS float atomics
-//     instead was measured 45% slower), parked in LDS per list entry, and flushed once per 64-entry chunk
+//   * the forward keeps its pre-test masks (one 64-bit word per chunk and quadrant) and the backward loads them
+//     instead of repeating the minimisation.
+//   * the conic is pre-scaled when an entry is staged, so that log2(G) is three FMAs per (pixel, entry); the
+//     backward accumulates moments of m = G * dL/dalpha (sum m, sum m d, sum m d d^T) per pixel and forms the
+//     gradients once per (tile, entry).
+//   * backward: the 9 sums of an entry are added over the lane's pixels, reduced across the wave with DPP row
+//     operations (bank-masked adds, wave_reduce9 below; finishing the last steps with 4 same-address LDS float
+//     atomics instead was measured 45% slower), parked in LDS per list entry, and flushed once per 64-entry chunk
 //     with plain stores into the entry's own slot of a per-(tile, Gaussian)-pair slab.  The reference issues
 //     one global float atomic per (pixel, Gaussian, component); a first version here issued one per (tile,
 //     Gaussian, component) and still spent 0.25 of 0.87 ms on them (11.8 M atomics per pass at the BASELINE
