@@ -9,8 +9,9 @@
 //   reference: sort R (u64 key, u32 value) pairs on 32+log2(tiles) bits  -> ~6 passes x 24 B x R
 //   here:      1. stable sort the P Gaussians once by their 32 depth bits (P << R): one bucketing pass + an LDS sort
 //              2. inclusive scan of tiles_touched in that depth order (fused into 1.)
-//              3. emit the R pairs in depth order as packed words (tile | depth rank), balanced over OUTPUT slots
-//              4. stable LSD radix sort of the words on the log2(tiles) tile bits only (2 passes x 8 or 16 B x R)
+//              3. emit the R pairs in depth order as words (tile | Gaussian id), balanced over OUTPUT slots
+//              4. stable LSD radix sort of the words on the log2(tiles) tile bits only (2 passes x 8 or 12 B x R:
+//                 32-bit words, or a 16-bit key array + a 32-bit id array above 2^19 Gaussians)
 //   Stability of both sorts + ascending-id input order reproduces the reference's tie-break exactly.
 //
 // Every kernel takes a pointer into the pass's device argument block (common.h) and reads the pair count from the
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const EmitArgs* __restr
 // rocPRIM's onesweep spends more time around its two passes (per-pass fills of the look-back state, histogram and scan
 // kernels: ~65 us of launches and gaps for ~48 us of sorting at R = 3.6 M) than in them.  Here a pass is: per-workgroup
 // digit counts (for the first digit they come out of the emission kernel), one workgroup per digit scanning its row
-// of counts, and a scatter that ranks its 1024 keys stably -- wave-level match by one ballot per digit bit per round,
+// of counts, and a scatter that ranks its kRadixBlock keys stably -- wave-level match by one ballot per digit bit per round,
 // running per-wave digit counts in LDS -- no fills, no look-back chain.  Stable, so the passes give the tile-major
 // order with the emission (depth) order preserved inside a tile.
 template <class IO>

@@ -190,8 +190,9 @@ inline uint32_t higher_msb(uint32_t n)
 // Tile sort of the packed pair words (binning.hip): a pair travels as ONE word, tile << rank_bits | Gaussian id,
 // through a key-only, stable LSD radix sort on the tile bits; emission is in depth order, so the order inside a
 // tile is (depth, id) without the depth ever being part of the key.
-// 32-bit words while tile bits + id bits <= 32 (the BASELINE shape: 13 + 19), 64-bit words (tile << 32 | id)
-// above -- every real scene.  Two or three stable passes of <= 8-bit digits, 1024 keys per workgroup.
+// 32-bit words while tile bits + id bits <= 32 (the BASELINE shape: 13 + 19); above -- every real scene -- the word
+// lives as a 16-bit tile key array + a 32-bit id array (up to 65536 tiles; 64-bit words tile << 32 | id beyond).
+// Two or three stable passes of <= 8-bit digits, kRadixBlock keys per workgroup.
 // Forward and backward derive the same layout from (P, #tiles) alone.
 constexpr int kRadixBlock = 2048;   // pairs per workgroup of the emission / radix kernels; 1024 / 2048 / 4096: tile binning
                                     // 0.097 / 0.092 / 0.107 ms at 500 k Gaussians, 0.327 / 0.280 / 0.294 ms at 2 M
