@@ -139,6 +139,7 @@ struct IoSplit {    // [cap] 32-bit ids, then [cap] 16-bit tile keys; rank_bits 
 // what is dropped are the FARTHEST pairs.
 constexpr int kEmitPerBlock = kRadixBlock;
 constexpr int kEmitSlice = kEmitPerBlock + 8;
+constexpr int kEmitStage = 512;   // Gaussians whose start / id / rect are staged in LDS per round
 
 // Smallest j in [0, n] with a[j] > pos (n if none), a non-decreasing, searched by a whole wave: 64 probes per step,
 // four dependent loads for P = 500k instead of the nineteen of a scalar binary search.  All 64 lanes must call it;
@@ -171,10 +172,10 @@ template <class IO>
 __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, uint32_t blk)
 {
     __shared__ uint32_t s_hist[kMaxRadixBins];   // first radix digit of the tile sort, counted while emitting
-    __shared__ uint32_t s_end[kEmitSlice];
-    __shared__ uint32_t s_id[kEmitSlice];
-    __shared__ ushort4 s_rect[kEmitSlice];
-    __shared__ uint32_t s_owner[kEmitPerBlock];
+    __shared__ uint32_t s_start[kEmitStage];     // staged Gaussians of the current round: first pair, id, tile rect
+    __shared__ uint32_t s_id[kEmitStage];
+    __shared__ ushort4 s_rect[kEmitStage];
+    __shared__ unsigned short s_owner[kEmitPerBlock];   // slice index of the slot's Gaussian (< kEmitSlice <= 65535)
     __shared__ uint32_t s_wmax[4];
     __shared__ uint32_t s_j[2];
     __shared__ uint32_t s_start0;
@@ -196,21 +197,14 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     const uint32_t j_lo = s_j[0], j_hi = s_j[1];
     // every Gaussian inside the slice owns >= 1 slot (culled ones sort to the very end), so n <= slots + 1
     const uint32_t n = min(j_hi - j_lo + 1u, (uint32_t)kEmitSlice);
-    for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t id = a.order[j_lo + k];
-        s_end[k] = offsets[j_lo + k];
-        s_id[k] = id;
-        s_rect[k] = a.rect[id];
-    }
-    __syncthreads();
     const uint32_t start0 = s_start0;
-    // record where each staged Gaussian's pairs begin (blocks sharing a Gaussian write the same value), and mark the
-    // slot it starts at with its slice index: a running maximum over the slots then names every slot's Gaussian
-    // (a binary search per slot over the slice's end offsets cost ~11 dependent LDS reads per pair instead)
+    // record where each Gaussian's pairs begin (blocks sharing a Gaussian write the same value), and mark the slot it
+    // starts at with its slice index: a running maximum over the slots then names every slot's Gaussian (a binary
+    // search per slot over the slice's end offsets cost ~11 dependent LDS reads per pair instead)
     for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t start = k == 0 ? start0 : s_end[k - 1];
-        a.rec[s_id[k]].pair_start = start;
-        if (start >= pos0) s_owner[start - pos0] = k;   // start < pos1: the slice ends at the last slot's Gaussian
+        const uint32_t start = k == 0 ? start0 : offsets[j_lo + k - 1];
+        a.rec[a.order[j_lo + k]].pair_start = start;
+        if (start >= pos0) s_owner[start - pos0] = (unsigned short)k;   // start < pos1: the slice ends at the last slot's Gaussian
     }
     __syncthreads();
     {
@@ -232,25 +226,39 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
         __syncthreads();
         for (int q = 0; q < w; q++) before = max(before, s_wmax[q]);
 #pragma unroll
-        for (int i = 0; i < E; i++) s_owner[threadIdx.x * E + i] = max(v[i], before);
+        for (int i = 0; i < E; i++) s_owner[threadIdx.x * E + i] = (unsigned short)max(v[i], before);
     }
-    __syncthreads();
     typedef typename IO::Reg Word;
     const int rank_bits = a.rank_bits;
+    // The Gaussians' data is staged kEmitStage at a time (a block of 2048 slots typically holds ~200 Gaussians; staging
+    // for the worst case of one per slot cost 33 KB of LDS and two thirds of the kernel's resident workgroups): every
+    // round emits the slots whose Gaussian it holds.
+    for (uint32_t r0 = 0; r0 < n; r0 += (uint32_t)kEmitStage) {
+        __syncthreads();   // s_owner complete / the previous round's staging consumed
+        const uint32_t nr = min(n - r0, (uint32_t)kEmitStage);
+        for (uint32_t k = threadIdx.x; k < nr; k += 256) {
+            const uint32_t g = j_lo + r0 + k, id = a.order[g];
+            s_start[k] = r0 + k == 0 ? start0 : offsets[g - 1];
+            s_id[k] = id;
+            s_rect[k] = a.rect[id];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < kEmitPerBlock / 256; e++) {
-        const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
-        if (pos < pos1) {
-            const uint32_t lo = s_owner[pos - pos0];   // the staged Gaussian this slot belongs to
-            const uint32_t start = lo == 0 ? start0 : s_end[lo - 1];
-            const uint32_t local = pos - start;
-            const ushort4 r = s_rect[lo];
-            const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
-            const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
-            const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)a.gx + (uint32_t)r.x + tx;
-            IO::store(a.words_out, nullptr, a.cap, pos, ((Word)tile << rank_bits) | (Word)s_id[lo]);   // tile | Gaussian id
-            if (a.pair_rank) a.pair_rank[pos] = s_id[lo];
-            atomicAdd(&s_hist[tile & (uint32_t)(bins - 1)], 1u);
+        for (int e = 0; e < kEmitPerBlock / 256; e++) {
+            const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
+            if (pos < pos1) {
+                const uint32_t lo = (uint32_t)s_owner[pos - pos0] - r0;   // the staged Gaussian this slot belongs to
+                if (lo < nr) {
+                    const uint32_t local = pos - s_start[lo];
+                    const ushort4 r = s_rect[lo];
+                    const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
+                    const uint32_t ty = local / w, tx = local - ty * w;  // row-major (y, x), rasterizer_impl.cu:106-117
+                    const uint32_t tile = ((uint32_t)r.y + ty) * (uint32_t)a.gx + (uint32_t)r.x + tx;
+                    IO::store(a.words_out, nullptr, a.cap, pos, ((Word)tile << rank_bits) | (Word)s_id[lo]);   // tile | Gaussian id
+                    if (a.pair_rank) a.pair_rank[pos] = s_id[lo];
+                    atomicAdd(&s_hist[tile & (uint32_t)(bins - 1)], 1u);
+                }
+            }
         }
     }
     __syncthreads();

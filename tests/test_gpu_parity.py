@@ -152,8 +152,11 @@ def test_golden_cases_forward_backward(C_, golden_dir, name):
     dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02, lam=0.1),
     dict(P=3_000, W=203, H=117, f=150.0, cam_seed=5, gseed=6, degree_mode="all3", scale_mu=0.05, lam=0.0, spread=1.4),
     dict(P=300_000, W=800, H=800, f=600.0, cam_seed=1, gseed=0, degree_mode="all3", scale_mu=0.012, lam=0.0),
+    # splats of about a pixel: ~1.3 pairs per Gaussian, so a 2048-slot emission block holds ~1500 Gaussians and stages
+    # them in several rounds (binning.hip kEmitStage)
+    dict(P=60_000, W=512, H=512, f=400.0, cam_seed=7, gseed=9, degree_mode="mixed", scale_mu=0.0008, lam=0.0),
 ], ids=["cfg0_10k_400x400_deg0", "20k_640x360_mixed_sparsity", "ragged_edges_ewa_clamp",
-        "cfg1_lego_like_300k_800x800_deg3"])
+        "cfg1_lego_like_300k_800x800_deg3", "pixel_sized_splats_many_per_emit_block"])
 def test_oracle_parity_larger(C_, kw):
     """BASELINE.json configs[0] (10k Gaussians, 400x400, degree 0), two wider cases, and the synthetic stand-in
     for configs[1] (300k Gaussians, 800x800, degree 3) -- the largest size compared element-wise
