@@ -198,12 +198,26 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     // every Gaussian inside the slice owns >= 1 slot (culled ones sort to the very end), so n <= slots + 1
     const uint32_t n = min(j_hi - j_lo + 1u, (uint32_t)kEmitSlice);
     const uint32_t start0 = s_start0;
+    // The Gaussians' data is staged kEmitStage at a time (a block of 2048 slots typically holds ~200 Gaussians; staging
+    // for the worst case of one per slot cost 33 KB of LDS and two thirds of the kernel's resident workgroups): every
+    // round emits the slots whose Gaussian it holds.  The first round is staged before anything else needs it.
+    auto stage = [&](uint32_t r0, uint32_t nr) {
+        for (uint32_t k = threadIdx.x; k < nr; k += 256) {
+            const uint32_t g = j_lo + r0 + k, id = a.order[g];
+            s_start[k] = r0 + k == 0 ? start0 : offsets[g - 1];
+            s_id[k] = id;
+            s_rect[k] = a.rect[id];
+        }
+    };
+    const uint32_t nr0 = min(n, (uint32_t)kEmitStage);
+    stage(0u, nr0);
+    __syncthreads();
     // record where each Gaussian's pairs begin (blocks sharing a Gaussian write the same value), and mark the slot it
     // starts at with its slice index: a running maximum over the slots then names every slot's Gaussian (a binary
     // search per slot over the slice's end offsets cost ~11 dependent LDS reads per pair instead)
     for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t start = k == 0 ? start0 : offsets[j_lo + k - 1];
-        a.rec[a.order[j_lo + k]].pair_start = start;
+        const uint32_t start = k < nr0 ? s_start[k] : offsets[j_lo + k - 1];
+        a.rec[k < nr0 ? s_id[k] : a.order[j_lo + k]].pair_start = start;
         if (start >= pos0) s_owner[start - pos0] = (unsigned short)k;   // start < pos1: the slice ends at the last slot's Gaussian
     }
     __syncthreads();
@@ -230,19 +244,13 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     }
     typedef typename IO::Reg Word;
     const int rank_bits = a.rank_bits;
-    // The Gaussians' data is staged kEmitStage at a time (a block of 2048 slots typically holds ~200 Gaussians; staging
-    // for the worst case of one per slot cost 33 KB of LDS and two thirds of the kernel's resident workgroups): every
-    // round emits the slots whose Gaussian it holds.
     for (uint32_t r0 = 0; r0 < n; r0 += (uint32_t)kEmitStage) {
-        __syncthreads();   // s_owner complete / the previous round's staging consumed
         const uint32_t nr = min(n - r0, (uint32_t)kEmitStage);
-        for (uint32_t k = threadIdx.x; k < nr; k += 256) {
-            const uint32_t g = j_lo + r0 + k, id = a.order[g];
-            s_start[k] = r0 + k == 0 ? start0 : offsets[g - 1];
-            s_id[k] = id;
-            s_rect[k] = a.rect[id];
+        __syncthreads();   // s_owner complete / the previous round's staging consumed
+        if (r0 > 0) {
+            stage(r0, nr);
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int e = 0; e < kEmitPerBlock / 256; e++) {
             const uint32_t pos = pos0 + threadIdx.x + (uint32_t)e * 256u;
