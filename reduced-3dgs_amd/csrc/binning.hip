@@ -187,7 +187,20 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
     const uint32_t pos1 = min(R, pos0 + (uint32_t)kEmitPerBlock);  // exclusive
     if (threadIdx.x < 128) {   // wave 0 locates the first slot's Gaussian, wave 1 the last slot's
         const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const uint32_t j = upper_bound_wave(offsets, (uint32_t)a.P, w == 0 ? pos0 : pos1 - 1, lane);
+        const uint32_t* __restrict__ bf = a.block_first;
+        const bool last_blk = pos1 == R;   // the slice ends with the pass's last pair, not at a workgroup border
+        uint32_t j;
+        if (bf && w == 0) {
+            j = bf[blk];   // noted by the depth sort's scan
+        } else if (bf && !last_blk) {
+            // the Gaussian holding pair pos1 (the next workgroup's first) holds pair pos1 - 1 too unless it starts there
+            const uint32_t g = bf[blk + 1];
+            j = (g > 0u && offsets[g - 1] == pos1) ? g - 1u : g;
+        } else if (bf && R == a.hdr->num_rendered) {
+            j = a.hdr->visible - 1u;   // the last visible Gaussian in depth order
+        } else {
+            j = upper_bound_wave(offsets, (uint32_t)a.P, w == 0 ? pos0 : pos1 - 1, lane);
+        }
         if (lane == 0) {
             s_j[w] = j;
             if (w == 0) s_start0 = j == 0 ? 0u : offsets[j - 1];

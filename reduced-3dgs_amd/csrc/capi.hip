@@ -578,6 +578,11 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     d.ovf_id = g.ovf_id;
     d.order = g.order;
     d.offsets = g.offsets;
+    // only on the asynchronous path does the binning blob exist while the depth sort runs (and only the bucketed sort's
+    // scan writes the notes)
+    uint32_t* const block_first = (b && fuse_header && !p.generic_depth_sort) ? b->block_first : nullptr;
+    d.block_first = block_first;
+    d.block_cap = p.reserve / (uint32_t)kRadixBlock + 2u;
 
     const PairLayout& l = p.layout;
     const size_t Tn = (size_t)p.gx * p.gy;
@@ -589,6 +594,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
         e.hdr = g.header;
         e.order = g.order;
         e.offsets = g.offsets;
+        e.block_first = block_first;
         e.rect = g.rect;
         e.rec = g.rec;
         e.rank_bits = l.rank_bits;

@@ -228,6 +228,8 @@ struct BinState {
     uint32_t* radix_rows;  // [bins][R/kRadixBlock + 1] per-workgroup digit counts, digit-major
     uint32_t* radix_base;  // same shape: first slot of each workgroup inside each digit
     uint32_t* radix_total; // [kMaxRadixPasses][kMaxRadixBins] digit totals of the passes
+    uint32_t* block_first;           // [R/kRadixBlock + 2] depth rank of the Gaussian holding pair m * kRadixBlock: written by the
+                                     // depth sort's scan (asynchronous path), spares the emission kernel its search
     unsigned long long* quad_masks;  // [R/64 + Tn + 2][4] region pre-test of the forward blend, kept for the backward:
                                      // bit j of [slot][q] = entry j of a 64-entry chunk of a tile's list may reach 8x8
                                      // quadrant q; slot = quad_mask_slot(first pair of the tile, chunk, tile)
@@ -260,6 +262,7 @@ struct BinState {
         b.radix_base = c.take<uint32_t>((size_t)kMaxRadixBins * radix_row_stride(R));
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
+        b.block_first = c.take<uint32_t>(R / kRadixBlock + 2);
         b.end = c.p;
         return b;
     }
@@ -436,12 +439,15 @@ struct DepthArgs {        // depth_sort.h bucketed depth sort
     uint32_t* ovf_id;
     uint32_t* order;
     uint32_t* offsets;
+    uint32_t* block_first;   // BinState::block_first or nullptr (exact-size path: the binning blob does not exist yet)
+    uint32_t block_cap;      // entries of block_first
 };
 struct EmitArgs {         // binning.hip emit_pairs_kernel
     int P, gx;
     const GeomHeader* hdr;
     const uint32_t* order;
     const uint32_t* offsets;
+    const uint32_t* block_first;   // as DepthArgs::block_first (nullptr: search the scan)
     const ushort4* rect;
     GRec* rec;
     int rank_bits, digit_bits;

@@ -67,6 +67,19 @@ constexpr int kHistPerThread = kHistBatch / 256;
 constexpr int kCountBits = 24;
 constexpr unsigned long long kCountMask = (1ull << kCountBits) - 1;
 
+// offsets[slot] = end of the pairs of the Gaussian at depth rank `slot` (inclusive scan of tiles_touched); the Gaussian
+// holding pair m * kRadixBlock also notes its rank for the emission workgroup that starts there.
+__device__ __forceinline__ void publish_offset(const DepthArgs& a, uint32_t slot, uint32_t end, uint32_t count)
+{
+    a.offsets[slot] = end;
+    if (a.block_first && count) {
+        const uint32_t first = end - count;
+        for (uint32_t m = (first + (uint32_t)kRadixBlock - 1u) / (uint32_t)kRadixBlock;
+             m * (uint32_t)kRadixBlock < end && m < a.block_cap; m++)
+            a.block_first[m] = slot;
+    }
+}
+
 struct DepthRange {
     uint32_t kmin;
     float scale;
@@ -443,7 +456,7 @@ __device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, in
             const uint32_t incl = block256_inclusive_scan(t, s_sum);
             if (r < n) {
                 order[start + r] = id;
-                offsets[start + r] = run + incl;
+                publish_offset(a, start + r, run + incl, t);
             }
             __syncthreads();
             if (threadIdx.x == 255) s_sum[4] = incl;
@@ -504,7 +517,7 @@ __device__ inline void depth_bucket_sort_role(const DepthArgs& a, char* smem, in
         if (r < n) {
             run += tl[k];
             order[start + r] = (uint32_t)s[r];
-            offsets[start + r] = run;
+            publish_offset(a, start + r, run, tl[k]);
         }
     }
 }
@@ -531,7 +544,7 @@ __device__ __forceinline__ void wave_sort_bucket(const DepthArgs& a, uint32_t st
         const uint32_t incl = wave_inclusive_scan(t[r], lane);
         if (i < n) {
             a.order[start + i] = (uint32_t)v[r];
-            a.offsets[start + i] = run + incl;
+            publish_offset(a, start + i, run + incl, t[r]);
         }
         run += (uint32_t)__shfl((int)incl, 63);
     }
