@@ -37,6 +37,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 
+CLOCK_WARMUP_STEPS = 50   # untimed, ahead of the --warmup steps (see main())
+
+
 def stage_bytes(P, R, N, Tn, Kbar):
     """Algorithmic bytes per launch of each stage, SURVEY.md 8d (terms of B_fwd / B_bwd regrouped by the
     library's stages; the sort term is the reference-algorithm figure R*24*ceil(bits/8) as 8d prescribes)."""
@@ -267,6 +270,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # The GPU's clocks take a few tens of milliseconds of load to settle (20 timed steps after 5 warm-up steps measured
+    # 1136-1160 it/s, after 50: 1162-1164): CLOCK_WARMUP_STEPS untimed steps of the same work run ahead of the W
+    # warm-up steps, whatever W is.  Reported as config.clock_warmup_steps; the timed region is exactly K steps.
+    for i in range(CLOCK_WARMUP_STEPS):
+        train_step(i)
     for i in range(args.warmup):
         train_step(i)
     drain()
@@ -416,6 +424,7 @@ def main():
                                 "stats + radii per Gaussian), own stream, double-buffered: overlapped with the next "
                                 "step's render") if world > 1 else None,
                    "grads_born_in_exchange_buffer": born_in_buffer[0],
+                   "clock_warmup_steps": CLOCK_WARMUP_STEPS,
                    "issue": "one hipGraph launch per forward, direct launches for the (event-timed) backward; "
                             "pair reservation instead of a num_rendered read-back",
                    "reserve_overflows_in_run": _C.reserve_overflow_events() - overflow0},
