@@ -476,11 +476,13 @@ def test_repeated_backward_and_pair_sort_path(C_):
         "t.check_forward(_C, fout, ref, 240, 320, 6000)\n"
         "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), t.orc.backward(ref['state'], dl, 0.1), ref['state'], 16)\n"
         "print('pairs-path-ok')\n") % (ROOT, os.path.join(ROOT, "reduced-3dgs_amd"))
-    # wide: 64-bit words; split: 16-bit tile keys + 32-bit ids in two arrays (what scenes of more than 2^19 Gaussians use)
-    for layout, depth in (("wide", "generic"), ("split", "generic"), ("split", "bucket")):
-        env = dict(os.environ, R3DGS_TILE_SORT=layout, R3DGS_DEPTH_SORT=depth)
+    # wide: 64-bit words; split: 16-bit tile keys + 32-bit ids in two arrays (what scenes of more than 2^19 Gaussians use);
+    # last: the backward redoing the region pre-test instead of loading the forward's masks (the other kernel instance)
+    for extra in (dict(R3DGS_TILE_SORT="wide", R3DGS_DEPTH_SORT="generic"), dict(R3DGS_TILE_SORT="split", R3DGS_DEPTH_SORT="generic"),
+                  dict(R3DGS_TILE_SORT="split", R3DGS_DEPTH_SORT="bucket"), dict(R3DGS_KEEP_QUAD_MASKS="0")):
+        env = dict(os.environ, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
-        assert "pairs-path-ok" in out.stdout, layout + out.stdout[-2000:] + out.stderr[-2000:]
+        assert "pairs-path-ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_optimisation_through_the_boundary_fits_target_views(C_):
