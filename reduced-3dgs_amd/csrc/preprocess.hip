@@ -4,9 +4,10 @@
 // forward.cu:245-350 variableSHPreprocessCUDA (ragged degree-sorted SH buffer) and
 // rasterizer_impl.cu:62-74 checkFrustum of /root/reference/submodules/diff-gaussian-rasterization.
 //
-// One lane per Gaussian, 256-thread workgroups, two kernels: geometry (everything the binning needs; its
-// sort keys go to the main stream's depth sort at once) and colour (the HBM-heavy SH stream, launched on a
-// side stream so that it runs underneath that sort).  In the colour kernel each wave first copies the SH rows of
+// One lane per Gaussian, 256-thread workgroups, two roles: geometry (everything the binning needs; its sort keys go
+// to the depth sort at once -- this kernel also installs the pass block, its by-value argument) and colour (the
+// HBM-heavy SH stream, which rides in spare workgroups of the three depth-sort launches so that it runs underneath
+// that sort inside one linear launch chain).  In the colour role each wave first copies the SH rows of
 // its 64 Gaussians -- one contiguous span of the [P,M,3] tensor (or of the ragged buffer) -- into LDS with
 // fully coalesced loads, then every lane evaluates its own row out of LDS (bank-skewed index), instead of 64
 // lanes striding 192 B apart through global memory.  Output is one 48-byte record per visible Gaussian (GRec),
