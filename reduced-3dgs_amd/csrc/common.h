@@ -88,13 +88,14 @@ inline size_t depth_hist_per_block(size_t P)
     const size_t per = ((want + kHistBatch - 1) / kHistBatch) * kHistBatch;
     return per < (size_t)kHistBatch ? (size_t)kHistBatch : per;
 }
-int depth_bucket_load();   // mean Gaussians per bucket aimed for (R3DGS_DEPTH_BUCKET_LOAD; default 128, 256 above 1 M); capi.hip
+int depth_bucket_load();   // mean Gaussians per bucket aimed for up to 1 M Gaussians (R3DGS_DEPTH_BUCKET_LOAD; default 128); capi.hip
 inline int depth_bucket_count(size_t P)
 {
     int nb = kMinDepthBuckets;
-    // every histogram / scatter workgroup carries nb-entry tables, so large scenes take coarser buckets: measured at
-    // 2 M Gaussians, 8192 buckets 0.29 ms vs 16384 buckets 0.38 ms for the stage; at 500 k, 4096 beat 2048 and 8192
-    const size_t load = (size_t)depth_bucket_load() * (P > (1u << 20) ? 2 : 1);
+    // every histogram / scatter workgroup carries nb-entry tables, so large scenes take coarser buckets.  Stage time:
+    // 500 k Gaussians: 2048 / 4096 / 8192 buckets 0.099 / 0.084 / 0.106 ms; 2 M: 4096 / 8192 / 16384 0.26 / 0.30 / 0.38 ms;
+    // 6 M: 8192 / 16384 0.76 / 0.98 ms -- i.e. ~128 per bucket up to 1 M, ~512 up to 4 M, ~1024 above
+    const size_t load = (size_t)depth_bucket_load() * (P > (1u << 22) ? 8 : P > (1u << 20) ? 4 : 1);
     while (nb < kMaxDepthBuckets && P / (size_t)nb > load) nb <<= 1;
     return nb;
 }
