@@ -290,6 +290,7 @@ def main():
         _C.profile_enable(True, only=[dom_stage])
     _C.profile_read()
     overflow0 = _C.reserve_overflow_events()
+    stats0 = _C.pass_stats()
     barrier()
     torch.cuda.synchronize()
     # If this container is being CPU-throttled right now (someone in it -- not this process, which uses ~1 CPU -- burns
@@ -320,6 +321,8 @@ def main():
     elapsed = time.perf_counter() - t0
     cg1 = cgroup_cpu()
     gpu_event_ms = ev0.elapsed_time(ev1)
+    stats1 = _C.pass_stats()
+    overflow1 = _C.reserve_overflow_events()
     prof_timed = _C.profile_read()
     _C.profile_enable(False)
     # second, untimed pass with every stage timer on: the per-stage breakdown
@@ -426,8 +429,12 @@ def main():
                    "grads_born_in_exchange_buffer": born_in_buffer[0],
                    "clock_warmup_steps": CLOCK_WARMUP_STEPS,
                    "issue": "one hipGraph launch per forward, direct launches for the (event-timed) backward; "
-                            "pair reservation instead of a num_rendered read-back",
-                   "reserve_overflows_in_run": _C.reserve_overflow_events() - overflow0},
+                            "pair reservation (per camera) instead of a num_rendered read-back; strict: every forward "
+                            "checks its published pair count before returning and redoes an overflowed pass exactly",
+                   "strict": _C.is_strict(),
+                   "reserve_overflows_in_run": overflow1 - overflow0,
+                   "passes_in_timed_region": {k: stats1[k] - stats0[k] for k in
+                                              ("reserved_passes", "exact_passes", "redone_passes")}},
         "exchange_ms": round(exchange_ms, 4) if exchange_ms is not None else None,
         "exchange_bytes_per_rank": (exch.flat.numel() * 4) if exch is not None else None,
         "step_ms_exchange_serialised": round(sync_ms_per_step, 4) if sync_ms_per_step is not None else None,

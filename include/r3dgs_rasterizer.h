@@ -93,19 +93,26 @@ int r3dgs_inference_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, 
  * (rasterizer_impl.cu:441-450).  r3dgs_forward_reserved removes that: the caller passes the three blobs up front
  * (r3dgs_geometry_bytes / r3dgs_binning_bytes(..., reserve) / r3dgs_image_bytes) and a pair reservation; everything
  * is enqueued on `stream` -- as ONE hipGraph launch per pass once the shape has been seen -- and the call returns
- * a pass ticket (> 0) without waiting.  num_rendered lives on the device; if it exceeds `reserve` the FARTHEST
- * pairs are dropped for that pass (emission is in depth order), the pass is flagged R3DGS_PASS_TRUNCATED and
- * r3dgs_reserve_hint grows.  Everything else (arguments, outputs, numerics) is r3dgs_forward's.
- *   r3dgs_reserve_hint: reservation proposed from the num_rendered of earlier passes of this (device, W, H), scaled
- *     to P, with slack (R3DGS_RESERVE_SLACK_PCT, default 150) and kept stable per P; 0 = nothing known yet (run
- *     r3dgs_forward once) or R3DGS_RESERVE=off.
+ * a pass ticket (> 0) without waiting.  The pair count lives on the device; if it exceeds `reserve` the FARTHEST
+ * pairs are dropped for that pass (emission is in depth order) and the pass is flagged R3DGS_PASS_TRUNCATED: a caller
+ * that wants the reference's results MUST look at the flag before the pass's outputs are consumed and redo a flagged
+ * pass with r3dgs_forward (the Python host does: diff_gaussian_rasterization/_C.py, strict mode, the default).  The
+ * numbers are published ~40 us into the pass (long before it ends), so that check does not drain the GPU.
+ * Everything else (arguments, outputs, numerics) is r3dgs_forward's.
+ *   r3dgs_reserve_hint_view: reservation proposed from earlier passes of this camera (key: the device address of its
+ *     view matrix), falling back to the largest recent pair count of this (device, W, H); scaled to P, with slack
+ *     (R3DGS_RESERVE_SLACK_PCT, default 150), rounded up to a geometric grid (a reservation keys the captured graph).
+ *     0 = nothing known yet about this image size (run r3dgs_forward once) or R3DGS_RESERVE=off.
+ *     r3dgs_reserve_hint is the same without a camera.
  *   r3dgs_pass_query: num_rendered / visible / reserve (-1 for exact-size passes) / flags of a ticket; wait = 0
  *     returns 0 if the pass has not produced them yet, wait = 1 blocks (host-memory poll with deadline).
- *     Returns 1 when filled in, negative on error (e.g. the ticket is more than ~1000 passes old).
+ *     Returns 1 when filled in, negative on error (e.g. the ticket is more than ~1000 passes old).  A ticket knows
+ *     its device: the query may come from any thread, with any device current.
  *   r3dgs_reserve_overflow_events: number of truncated passes seen so far (+ the last one's numbers). */
 #define R3DGS_PASS_TRUNCATED 1
 #define R3DGS_PASS_DEPTH_BUCKET_OVERFLOW 2
 int r3dgs_reserve_hint(int P, int width, int height);
+int r3dgs_reserve_hint_view(int P, int width, int height, const float* viewmatrix);
 long long r3dgs_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, int P,
                                  const int* D, int M, const float* background, int width, int height,
                                  const float* means3D, const float* shs, const float* colors_precomp,
@@ -126,6 +133,9 @@ long long r3dgs_inference_forward_reserved(char* geom_buffer, char* binning_buff
                                            int* radii, int calculate_mean_transmittance, int debug, void* stream);
 int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible, int* reserve, int* flags);
 long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserve);
+/* Forget every pair count learnt so far (a new scene is about to be loaded; tests): the next pass of each image size
+ * takes the exact-size path again. */
+void r3dgs_reserve_forget(void);
 
 /* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
  * No host synchronisation; one hipGraph launch once the shape has been seen.  R is the pair capacity the forward

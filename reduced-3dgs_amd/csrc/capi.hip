@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -151,6 +152,11 @@ struct InfoRing {
 std::mutex g_ring_mu;
 std::unordered_map<int, InfoRing> g_rings;
 std::atomic<uint64_t> g_next_ticket{1};
+// A ticket = (device << 48) | running pass number: whoever holds one can find its ring without knowing which device is
+// current (r3dgs_pass_query from another thread / with another GPU selected).
+constexpr int kTicketDevShift = 48;
+inline uint64_t ticket_number(uint64_t t) { return t & ((1ull << kTicketDevShift) - 1ull); }
+inline int ticket_device(uint64_t t) { return (int)(t >> kTicketDevShift); }
 
 InfoRing& info_ring(int dev)
 {
@@ -173,11 +179,11 @@ double now_ms()
 // Wait until the pass has published its header (num_rendered, visible).  Plain loads of host memory: a short spin,
 // then sleeps -- a spinning thread burns CPU quota that a containerised trainer may not have -- and a deadline
 // (R3DGS_SYNC_TIMEOUT_MS, default 30 s) that turns a hung GPU into an error instead of a hung host.
-const volatile PassInfo* wait_info(int dev, uint64_t ticket)
+const volatile PassInfo* wait_info(uint64_t ticket)
 {
     static const int timeout_ms = env_int("R3DGS_SYNC_TIMEOUT_MS", 30000, 1, 3600000);
-    const volatile PassInfo* info = info_ring(dev).host + ticket % kInfoRing;
-    const uint32_t seq = (uint32_t)ticket;
+    const volatile PassInfo* info = info_ring(ticket_device(ticket)).host + ticket_number(ticket) % kInfoRing;
+    const uint32_t seq = (uint32_t)ticket_number(ticket);
     const double t0 = now_ms();
     for (int spins = 0;; spins++) {
         if (info->seq == seq) {
@@ -188,65 +194,109 @@ const volatile PassInfo* wait_info(int dev, uint64_t ticket)
         const double waited = now_ms() - t0;
         if (waited > timeout_ms)
             throw Error("timed out after " + std::to_string(timeout_ms) + " ms waiting for num_rendered of pass " +
-                        std::to_string(ticket) + " (GPU hung or stream never ran?)");
+                        std::to_string(ticket_number(ticket)) + " (GPU hung or stream never ran?)");
         timespec ts = {0, waited < 2.0 ? 5000 : 50000};
         nanosleep(&ts, nullptr);
     }
 }
 
 // ---- reservation advice from the passes seen so far ----------------------------------------------------------------
+// The reservation of a pass is a guess; r3dgs_pass_query says whether it held (R3DGS_PASS_TRUNCATED), and the host side
+// redoes a truncated pass on the exact-size path before anything consumes it (diff_gaussian_rasterization/_C.py), so the
+// advice only decides how often that happens.  Pair counts differ by 2-3x between the cameras of a real scene, so they
+// are remembered per CAMERA (key: the device address of its view matrix -- every scene/cameras.py Camera owns one),
+// with the per-image-size maximum as the answer for a camera not seen yet.
 struct Pending {
     uint64_t ticket;
     int dev, P, W, H;
     uint32_t reserve;   // 0xFFFFFFFF for exact-size passes
+    uintptr_t cam;
+    bool sort_stamp;    // the pass's depth scan stamps PassInfo::sort_seq (bucketed sort)
+};
+struct CamStat {
+    int P;
+    uint32_t pairs;
 };
 struct ViewStats {
-    std::deque<std::pair<int, uint32_t>> recent;   // (P, num_rendered) of the last passes of this (device, W, H)
-    std::map<int, uint32_t> sticky;                // P -> reservation handed out (kept stable: it keys the graph cache)
+    std::deque<std::pair<int, uint32_t>> recent;   // (P, pairs) of the last passes of this (device, W, H)
+    std::unordered_map<uintptr_t, CamStat> cams;   // last pass of each camera
     int prefer_generic = 0;                        // passes left to route through the generic depth sort
 };
 struct Advisor {
     std::mutex mu;
-    std::deque<Pending> pending;
+    std::vector<Pending> pending;
     std::map<std::tuple<int, int, int>, ViewStats> views;
     uint64_t overflow_events = 0;
     uint32_t last_overflow_rendered = 0, last_overflow_reserve = 0;
 } g_adv;
 constexpr size_t kRecentWindow = 1024;
+constexpr size_t kMaxCams = 16384;
 
-void observe_locked(const Pending& p, uint32_t rendered, uint32_t sort_overflow)
+void observe_locked(const Pending& p, uint32_t pairs, uint32_t sort_overflow)
 {
     ViewStats& v = g_adv.views[{p.dev, p.W, p.H}];
-    v.recent.push_back({p.P, rendered});
+    v.recent.push_back({p.P, pairs});
     if (v.recent.size() > kRecentWindow) v.recent.pop_front();
+    if (p.cam) {
+        if (v.cams.size() > kMaxCams) v.cams.clear();
+        v.cams[p.cam] = {p.P, pairs};
+    }
     if (sort_overflow) v.prefer_generic = 64;
-    if (p.reserve != 0xFFFFFFFFu && rendered > p.reserve) {
+    if (p.reserve != 0xFFFFFFFFu && pairs > p.reserve) {
         g_adv.overflow_events++;
-        g_adv.last_overflow_rendered = rendered;
+        g_adv.last_overflow_rendered = pairs;
         g_adv.last_overflow_reserve = p.reserve;
     }
 }
 
-// passes that have published their header since the last call
+// Passes that have published their numbers since the last call.  Entries are looked at independently: a pass sitting on
+// a blocked stream (or one whose launch failed) does not hold up the ones behind it.
 void harvest_locked()
 {
     const uint64_t newest = g_next_ticket.load();
-    while (!g_adv.pending.empty()) {
-        const Pending p = g_adv.pending.front();
-        if (newest - p.ticket >= kInfoRing - 8) {   // its slot is about to be / was reused: forget it
-            g_adv.pending.pop_front();
+    size_t keep = 0;
+    for (size_t k = 0; k < g_adv.pending.size(); k++) {
+        const Pending p = g_adv.pending[k];
+        const uint64_t n = ticket_number(p.ticket);
+        if (newest - n >= kInfoRing - 8) continue;   // its slot is about to be / was reused: forget it
+        const volatile PassInfo* info = info_ring(p.dev).host + n % kInfoRing;
+        // the overflow hint of the bucketed depth sort comes from a later kernel than the header: its own stamp
+        const bool there = info->seq == (uint32_t)n && (!p.sort_stamp || info->sort_seq == (uint32_t)n);
+        if (!there) {
+            g_adv.pending[keep++] = p;
             continue;
         }
-        const volatile PassInfo* info = info_ring(p.dev).host + p.ticket % kInfoRing;
-        if (info->seq != (uint32_t)p.ticket) break;   // not there yet (tickets of one stream complete in order)
         std::atomic_thread_fence(std::memory_order_acquire);
-        observe_locked(p, info->num_rendered, info->sort_overflow);
-        g_adv.pending.pop_front();
+        observe_locked(p, info->pairs, p.sort_stamp ? info->sort_overflow : 0u);
     }
+    g_adv.pending.resize(keep);
     if (g_adv.pending.size() > 4 * kInfoRing) g_adv.pending.clear();
 }
 
-uint32_t reserve_hint(int dev, int P, int W, int H)
+void forget_ticket(uint64_t ticket)   // the launch behind a ticket failed: nothing will ever publish it
+{
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    for (size_t k = 0; k < g_adv.pending.size(); k++)
+        if (g_adv.pending[k].ticket == ticket) {
+            g_adv.pending.erase(g_adv.pending.begin() + (long)k);
+            return;
+        }
+}
+
+// Reservations come from a geometric grid (steps of 2^(1/8) ~ 9 %): a reservation keys the captured graph of its shape,
+// and per-camera pair counts would otherwise make every camera a shape of its own.
+uint32_t quantize_reserve(double want)
+{
+    if (want >= 2147000000.0) return 0;   // beyond a 31-bit pair count: exact path decides
+    const double unit = 65536.0;
+    int k = want <= unit ? 0 : (int)ceil(8.0 * log2(want / unit) - 1e-9);
+    double v = unit * exp2((double)k / 8.0);
+    while (v < want) v = unit * exp2((double)(++k) / 8.0);
+    const uint64_t r = ((uint64_t)v + 4095u) / 4096u * 4096u;
+    return r >= 2147000000ull ? 0u : (uint32_t)r;
+}
+
+uint32_t reserve_hint(int dev, int P, int W, int H, uintptr_t cam)
 {
     static const bool off = env_is("R3DGS_RESERVE", "off");
     static const double slack = 0.01 * env_int("R3DGS_RESERVE_SLACK_PCT", 150, 100, 1600);
@@ -256,20 +306,16 @@ uint32_t reserve_hint(int dev, int P, int W, int H)
     auto it = g_adv.views.find({dev, W, H});
     if (it == g_adv.views.end() || it->second.recent.empty()) return 0;
     ViewStats& v = it->second;
-    double mx = 0.0;
-    for (auto& e : v.recent) {   // scaled to the current Gaussian count (densification / pruning between passes)
-        const double r = e.first > 0 ? (double)e.second * ((double)P / (double)e.first) : (double)e.second;
-        mx = r > mx ? r : mx;
+    // scaled to the current Gaussian count (densification / pruning between passes)
+    auto scaled = [P](int p0, uint32_t pairs) { return p0 > 0 ? (double)pairs * ((double)P / (double)p0) : (double)pairs; };
+    double base = 0.0;
+    auto c = cam ? v.cams.find(cam) : v.cams.end();
+    if (c != v.cams.end()) {
+        base = scaled(c->second.P, c->second.pairs);
+    } else {
+        for (auto& e : v.recent) base = std::max(base, scaled(e.first, e.second));
     }
-    const double want = mx * slack + 65536.0;
-    auto st = v.sticky.find(P);
-    if (st != v.sticky.end() && (double)st->second >= mx * (1.0 + 0.4 * (slack - 1.0)) && (double)st->second <= 4.0 * want)
-        return st->second;
-    if (want >= 2147000000.0) return 0;   // beyond a 31-bit pair count: exact path decides
-    const uint32_t r = (uint32_t)(((uint64_t)want + 65535u) / 65536u * 65536u);
-    if (v.sticky.size() > 64) v.sticky.clear();
-    v.sticky[P] = r;
-    return r;
+    return quantize_reserve(base * slack + 65536.0);
 }
 
 // ---- launch contexts: device argument blocks and captured graphs ---------------------------------------------------
@@ -562,8 +608,9 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.header.n_parts = (int)pre_partials((size_t)c.P);
     a.header.hdr = g.header;
     a.header.info = info_dev;
-    a.header.ticket = (uint32_t)ticket;
+    a.header.ticket = (uint32_t)ticket_number(ticket);
     a.header.reserve = p.reserve;
+    a.header.stamp_sort = p.generic_depth_sort ? 1 : 0;   // no scan kernel behind the header on the generic-sort route
 
     DepthArgs& d = a.depth;
     d.P = c.P;
@@ -575,6 +622,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     d.tiles = g.tiles;
     d.hdr = g.header;
     d.info = info_dev;
+    d.ticket = (uint32_t)ticket_number(ticket);
     d.ds = g.dsort;
     d.hist_rows = g.hist_rows;
     d.hist_base = g.hist_base;
@@ -674,13 +722,14 @@ int current_device()
     return dev;
 }
 
-uint64_t new_ticket(int dev, const FwdCall& c, uint32_t reserve, PassInfo** info_dev)
+uint64_t new_ticket(int dev, const FwdCall& c, uint32_t reserve, bool sort_stamp, PassInfo** info_dev)
 {
-    const uint64_t ticket = g_next_ticket.fetch_add(1);
+    const uint64_t number = g_next_ticket.fetch_add(1);
+    const uint64_t ticket = ((uint64_t)dev << kTicketDevShift) | number;
     InfoRing& ring = info_ring(dev);
-    *info_dev = ring.dev + ticket % kInfoRing;
+    *info_dev = ring.dev + number % kInfoRing;
     std::lock_guard<std::mutex> lk(g_adv.mu);
-    g_adv.pending.push_back({ticket, dev, c.P, c.width, c.height, reserve});
+    g_adv.pending.push_back({ticket, dev, c.P, c.width, c.height, reserve, reinterpret_cast<uintptr_t>(c.viewmatrix), sort_stamp});
     return ticket;
 }
 
@@ -715,19 +764,24 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     ImageState img = ImageState::carve(iptr, N, Tn);
 
     PassInfo* info_dev = nullptr;
-    const uint64_t ticket = new_ticket(dev, c, 0xFFFFFFFFu, &info_dev);
+    const uint64_t ticket = new_ticket(dev, c, 0xFFFFFFFFu, false, &info_dev);
     FwdPassArgs* d_args;
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
-    }
     StageRun hooks{c.debug != 0};
     FwdPassArgs args;
-    fill_fwd_args(args, plan, c, geom, nullptr, img, info_dev, ticket, false);
-    issue_forward(plan, d_args, args, s, 1, hooks, &geom);
+    try {
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
+        }
+        fill_fwd_args(args, plan, c, geom, nullptr, img, info_dev, ticket, false);
+        issue_forward(plan, d_args, args, s, 1, hooks, &geom);
+    } catch (...) {
+        forget_ticket(ticket);
+        throw;
+    }
     // the one structural wait of this entry point (the reference's cudaMemcpy at rasterizer_impl.cu:446)
-    const volatile PassInfo* info = wait_info(dev, ticket);
-    const uint32_t R = info->num_rendered;
+    const volatile PassInfo* info = wait_info(ticket);
+    const uint32_t R = info->pairs;
     if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
     plan.reserve = R ? R : 1u;
     plan.grid_pairs = plan.reserve;   // exact size: one block per chunk
@@ -757,25 +811,30 @@ long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_
     ImageState img = ImageState::carve(image_buffer, (size_t)c.width * c.height, (size_t)plan.gx * plan.gy);
     BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
     PassInfo* info_dev = nullptr;
-    const uint64_t ticket = new_ticket(dev, c, plan.reserve, &info_dev);
-    FwdPassArgs args;
-    // the generic (rocPRIM) depth sort has no histogram kernel to carry the header reduction
-    fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, !plan.generic_depth_sort);
-    const bool direct = !graphs_enabled() || c.debug || plan.generic_depth_sort || (g_prof.mask.load() & kFwdStages);
-    if (direct) {
-        FwdPassArgs* d_args;
-        {
-            std::lock_guard<std::mutex> lk(g_ctx_mu);
-            d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
+    const uint64_t ticket = new_ticket(dev, c, plan.reserve, !plan.generic_depth_sort, &info_dev);
+    try {
+        FwdPassArgs args;
+        // the generic (rocPRIM) depth sort has no histogram kernel to carry the header reduction
+        fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, !plan.generic_depth_sort);
+        const bool direct = !graphs_enabled() || c.debug || plan.generic_depth_sort || (g_prof.mask.load() & kFwdStages);
+        if (direct) {
+            FwdPassArgs* d_args;
+            {
+                std::lock_guard<std::mutex> lk(g_ctx_mu);
+                d_args = static_cast<FwdPassArgs*>(direct_block(dev, 0, s, sizeof(FwdPassArgs)));
+            }
+            StageRun hooks{c.debug != 0};
+            issue_forward(plan, d_args, args, s, 3, hooks, &geom);
+        } else {
+            const CtxKey key{dev, 0, s, c.P, c.M, c.width, c.height, plan.reserve, fwd_flags(plan, c)};
+            launch_graph(key, plan, args, s, [](const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& v, hipStream_t cs) {
+                NoHooks nh;
+                issue_forward(p, d, v, cs, 3, nh, nullptr);
+            });
         }
-        StageRun hooks{c.debug != 0};
-        issue_forward(plan, d_args, args, s, 3, hooks, &geom);
-    } else {
-        const CtxKey key{dev, 0, s, c.P, c.M, c.width, c.height, plan.reserve, fwd_flags(plan, c)};
-        launch_graph(key, plan, args, s, [](const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& v, hipStream_t cs) {
-            NoHooks nh;
-            issue_forward(p, d, v, cs, 3, nh, nullptr);
-        });
+    } catch (...) {
+        forget_ticket(ticket);
+        throw;
     }
     return (long long)ticket;
 }
@@ -955,7 +1014,12 @@ int r3dgs_inference_forward(r3dgs_alloc_fn geometryBuffer, void* geometry_user, 
 
 int r3dgs_reserve_hint(int P, int width, int height)
 {
-    return guarded([&]() { return (int)reserve_hint(current_device(), P, width, height); });
+    return guarded([&]() { return (int)reserve_hint(current_device(), P, width, height, 0); });
+}
+
+int r3dgs_reserve_hint_view(int P, int width, int height, const float* viewmatrix)
+{
+    return guarded([&]() { return (int)reserve_hint(current_device(), P, width, height, reinterpret_cast<uintptr_t>(viewmatrix)); });
 }
 
 long long r3dgs_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, int P,
@@ -997,22 +1061,31 @@ int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible
 {
     return guarded([&]() {
         if (ticket <= 0) throw r3::Error("not a pass ticket");
-        const int dev = current_device();
-        if (g_next_ticket.load() - (uint64_t)ticket >= kInfoRing) throw r3::Error("pass ticket expired (ring reused)");
-        const volatile r3::PassInfo* info = info_ring(dev).host + (uint64_t)ticket % kInfoRing;
+        const uint64_t t = (uint64_t)ticket, n = ticket_number(t);
+        if (g_next_ticket.load() - n >= kInfoRing) throw r3::Error("pass ticket expired (ring reused)");
+        // the ring of the device the pass ran on (carried by the ticket), whatever device is current here
+        const volatile r3::PassInfo* info = info_ring(ticket_device(t)).host + n % kInfoRing;
         if (wait)
-            info = wait_info(dev, (uint64_t)ticket);
-        else if (info->seq != (uint32_t)ticket)
+            info = wait_info(t);
+        else if (info->seq != (uint32_t)n)
             return 0;
         std::atomic_thread_fence(std::memory_order_acquire);
-        const uint32_t R = info->num_rendered, cap = info->reserve;
+        const uint32_t R = info->num_rendered, pairs = info->pairs, cap = info->reserve;
         if (num_rendered) *num_rendered = (int)(R > 0x7fffffffu ? 0x7fffffffu : R);
         if (visible) *visible = (int)info->visible;
         if (reserve) *reserve = cap == 0xFFFFFFFFu ? -1 : (int)cap;
-        if (flags) *flags = (cap != 0xFFFFFFFFu && R > cap ? R3DGS_PASS_TRUNCATED : 0) |
-                            (info->sort_overflow ? R3DGS_PASS_DEPTH_BUCKET_OVERFLOW : 0);
+        // the depth-bucket hint is stamped by a later kernel of the pass than the header: reported once it is there
+        if (flags) *flags = (cap != 0xFFFFFFFFu && pairs > cap ? R3DGS_PASS_TRUNCATED : 0) |
+                            (info->sort_seq == (uint32_t)n && info->sort_overflow ? R3DGS_PASS_DEPTH_BUCKET_OVERFLOW : 0);
         return 1;
     });
+}
+
+void r3dgs_reserve_forget(void)
+{
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    g_adv.views.clear();
+    g_adv.pending.clear();
 }
 
 long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserve)

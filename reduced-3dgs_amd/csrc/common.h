@@ -63,12 +63,15 @@ inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBloc
 // per pass ticket): the host never waits for it on the asynchronous path, and polls plain memory (no HIP calls) on
 // the exact path.  `seq` is stored last, after a system-scope fence.
 struct PassInfo {
-    uint32_t seq;            // low 32 bits of the ticket once num_rendered / visible are valid
-    uint32_t num_rendered;   // true pair count of the view (may exceed `reserve`: then the farthest pairs were dropped)
+    uint32_t seq;            // low 32 bits of the pass number once num_rendered / pairs / visible are valid
+    uint32_t num_rendered;   // sum of tiles_touched as the reference defines it (rasterizer_impl.cu:441-446)
     uint32_t visible;
     uint32_t reserve;
-    uint32_t sort_overflow;  // hint: a depth bucket overflowed (slow in-kernel path was taken)
-    uint32_t pad[3];
+    uint32_t sort_overflow;  // hint: a depth bucket overflowed (slow in-kernel path was taken); valid once ...
+    uint32_t sort_seq;       // ... this equals the pass number (stamped by the depth sort's scan kernel, which runs
+                             // after the header is published)
+    uint32_t pairs;          // (tile, Gaussian) pairs the pass wants to emit; above `reserve` the farthest are dropped
+    uint32_t pad;
 };
 static_assert(sizeof(PassInfo) == 32, "PassInfo = 32 B");
 
@@ -422,6 +425,7 @@ struct HeaderArgs {       // binning.hip header_reduce_kernel
     PassInfo* info;       // host-mapped slot of this pass
     uint32_t ticket;
     uint32_t reserve;
+    uint32_t stamp_sort;  // 1: no depth-scan kernel follows (generic sort): the header stamps PassInfo::sort_seq itself
 };
 struct DepthArgs {        // depth_sort.h bucketed depth sort
     int P, nb, rows, per_block;
@@ -431,6 +435,7 @@ struct DepthArgs {        // depth_sort.h bucketed depth sort
     const uint32_t* tiles;
     GeomHeader* hdr;
     PassInfo* info;
+    uint32_t ticket;      // pass number (stamp of PassInfo::sort_seq)
     DepthSortScratch* ds;
     unsigned long long* hist_rows;
     uint32_t* hist_base;
@@ -587,7 +592,7 @@ void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, bool* present, hipStream_t s);
 
 void issue_header_reduce(const HeaderArgs* a, hipStream_t s);
-void prepare_depth_bucket_sort(int nb);   // one-time LDS opt-in of the depth-sort kernels (not a stream op)
+void prepare_depth_bucket_sort(int nb);   // LDS opt-in of the depth-sort kernels, once per device (not a stream op)
 void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);   // preprocess.hip
 void run_generic_depth_sort(int P, GeomState& g, hipStream_t s);   // rocPRIM, host pointers: direct issue only
 void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);

@@ -160,10 +160,12 @@ __device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
     volatile PassInfo* info = a.info;
     if (info) {
         info->num_rendered = all.num_rendered;
+        info->pairs = all.num_rendered;
         info->visible = all.visible;
         info->reserve = a.reserve;
         info->sort_overflow = 0u;
         __threadfence_system();
+        if (a.stamp_sort) info->sort_seq = a.ticket;
         info->seq = a.ticket;
     }
 }
@@ -249,10 +251,7 @@ __device__ inline void depth_colscan_role(const DepthArgs& a, int wg)
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_over) {   // both were zeroed by header_reduce_kernel earlier in this pass
-        a.hdr->sort_overflow = 1u;
-        if (a.info) a.info->sort_overflow = 1u;
-    }
+    if (threadIdx.x == 0 && s_over) a.hdr->sort_overflow = 1u;   // zeroed by the header earlier in this pass
 }
 
 // Exclusive scan of the nb + 1 bucket totals (both packed fields at once; the count field cannot carry, P < 2^24) by a
@@ -288,6 +287,15 @@ __device__ inline void depth_scatter_role(const DepthArgs& a, char* smem, int wg
     uint32_t* slot0 = reinterpret_cast<uint32_t*>(smem + 256 * sizeof(unsigned long long));   // bucket starts, then this
     uint32_t* rank = slot0 + (nb + 2);                                         // workgroup's first slot of each bucket
     scan_bucket_totals(a.ds, nb, slot0, s_tmp, wg == 0);   // workgroup 0 publishes for the per-bucket sort kernel
+    // The host-visible overflow hint carries its own stamp: the header (PassInfo::seq) is published by an earlier
+    // kernel, and a host looking in between must not take "no overflow" from a slot this pass has not written yet.
+    // Written here, one kernel behind the column scan that decides it, by one thread.
+    if (wg == 0 && threadIdx.x == 0 && a.info) {
+        volatile PassInfo* info = a.info;
+        info->sort_overflow = a.hdr->sort_overflow;
+        __threadfence_system();
+        info->sort_seq = a.ticket;
+    }
     const uint32_t R = a.hdr->num_rendered;   // culled Gaussians add no tiles: their scan value is the total
     const uint32_t* mybase = a.hist_base + (size_t)wg * (nb + 1);
     for (int b = threadIdx.x; b <= nb; b += 256) {

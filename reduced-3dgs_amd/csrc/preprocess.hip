@@ -14,6 +14,7 @@
 // the tile rect, the depth sort key and tiles_touched.
 // Built with -ffp-contract=off: radii / rects / tiles_touched are bit-exact against the oracle.
 #include <cstdlib>
+#include <map>
 #include <mutex>
 
 #include "depth_sort.h"
@@ -315,12 +316,16 @@ static void opt_in_lds(size_t bytes)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-// Not a stream operation: called before a chain is captured / issued, once per bucket count.
+// Not a stream operation: called before a chain is captured / issued.  hipFuncSetAttribute applies to the CURRENT
+// device, so what has been prepared is remembered per device.
 void prepare_depth_bucket_sort(int nb)
 {
     static std::mutex mu;
-    static int prepared_nb = 0;
+    static std::map<int, int> prepared;
     std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    R3_HIP(hipGetDevice(&dev));
+    int& prepared_nb = prepared[dev];
     if (nb <= prepared_nb) return;
     const size_t h = max_sz(depth_hist_lds(nb), kColorLds), sc = max_sz(depth_scatter_lds(nb), kColorLds),
                  bs = max_sz(kBucketSortLds, kColorLds);

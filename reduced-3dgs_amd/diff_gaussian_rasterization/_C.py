@@ -45,6 +45,8 @@ _lib.r3dgs_inference_forward.restype = _i
 _lib.r3dgs_inference_forward.argtypes = [_ALLOC, _vp, _ALLOC, _vp, _ALLOC, _vp, _i, _vp, _i, _vp, _vp, _vp] + _FWD_TAIL
 _lib.r3dgs_reserve_hint.restype = _i
 _lib.r3dgs_reserve_hint.argtypes = [_i, _i, _i]
+_lib.r3dgs_reserve_hint_view.restype = _i
+_lib.r3dgs_reserve_hint_view.argtypes = [_i, _i, _i, _vp]
 _lib.r3dgs_forward_reserved.restype = C.c_longlong
 _lib.r3dgs_forward_reserved.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _i] + _FWD_TAIL
 _lib.r3dgs_inference_forward_reserved.restype = C.c_longlong
@@ -267,12 +269,46 @@ def _blob_bytes(kind, *key):
     return v
 
 
+# ---- strict mode (the default) -------------------------------------------------------------------------------------
+# The asynchronous forward runs on a pair RESERVATION.  The reference never drops a pair (it sizes its buffer from the
+# exact count, rasterizer_impl.cu:441-450), so a pass whose pair count exceeded its reservation must not reach a
+# consumer: in strict mode the forward looks at the pass's published numbers before it returns -- they appear ~40 us
+# into the pass, long before it ends, so the GPU keeps working on the rest of the pass while the host goes on -- and a
+# truncated pass is redone on the exact-size path (same stream, same output tensors: the redo overwrites them in
+# stream order).  What the caller gets is therefore always the exact result; the reservation only decides how often a
+# redo happens.  R3DGS_STRICT=0 / set_strict(False) selects the old fire-and-forget behaviour (a RuntimeWarning after
+# the fact), for host-side A/B measurements only.
+_strict = os.environ.get("R3DGS_STRICT", "1") != "0"
+_stats = {"reserved_passes": 0, "exact_passes": 0, "redone_passes": 0}
 _overflow_seen = 0
 _calls = 0
 
 
+def set_strict(on):
+    """True (default): a pass that overflowed its pair reservation is detected before its outputs are returned and
+    redone on the exact-size path.  False: nothing waits; such a pass drops its farthest pairs and only warns."""
+    global _strict
+    _strict = bool(on)
+
+
+def is_strict():
+    return _strict
+
+
+def pass_stats():
+    """{reserved_passes, exact_passes, redone_passes, overflow_events}: how the forwards of this process were issued."""
+    d = dict(_stats)
+    d["overflow_events"] = reserve_overflow_events()
+    return d
+
+
+def reserve_forget():
+    """Forget the pair counts learnt so far (new scene; tests): the next pass of each image size is an exact-size one."""
+    _lib.r3dgs_reserve_forget()
+
+
 def reserve_overflow_events():
-    """Passes whose num_rendered exceeded their pair reservation so far (the reservation grows afterwards)."""
+    """Passes whose pair count exceeded their reservation so far (strict mode redid them; the reservation grows)."""
     return int(_lib.r3dgs_reserve_overflow_events(None, None))
 
 
@@ -286,14 +322,14 @@ def _watch_overflow():
     if n > _overflow_seen:
         _overflow_seen = n
         import warnings
-        warnings.warn(f"diff_gaussian_rasterization: a pass needed {r.value} (tile, Gaussian) pairs but {cap.value} "
-                      "were reserved; its farthest pairs were dropped and the reservation has been raised "
-                      "(raster_settings.debug=True or R3DGS_RESERVE=off selects the exact-size path)", RuntimeWarning)
+        warnings.warn(f"diff_gaussian_rasterization (strict mode OFF): a pass needed {r.value} (tile, Gaussian) pairs but "
+                      f"{cap.value} were reserved; its farthest pairs were dropped and the reservation has been raised",
+                      RuntimeWarning)
 
 
 def _forward_common(ragged, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                     viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
-                    prefiltered, debug, counters=None, exact=False, _reserve=None):
+                    prefiltered, debug, counters=None, exact=False, _reserve=None, _strict_override=None):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:158-161
     dev = means3D.device
@@ -329,12 +365,13 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
             head = (P, _ptr(deg), int(perband.numel()) if perband is not None else 0, _ptr(coeffs), _ptr(perband),
                     _ptr(cumsum))
             fn_exact, fn_reserved = _lib.r3dgs_inference_forward, _lib.r3dgs_inference_forward_reserved
-        # Asynchronous path: blobs sized up front from a pair reservation, nothing waits for num_rendered.  The exact-size
-        # path (allocator callbacks, one wait) runs when nothing is known about this view size yet, in debug mode, or
-        # when asked for.
-        reserve = 0 if (exact or debug) else _lib.r3dgs_reserve_hint(P, W, H)
+        # Asynchronous path: blobs sized up front from a pair reservation, one graph launch, no wait for the pass.  The
+        # exact-size path (allocator callbacks, one wait in the middle) runs when nothing is known about this view size
+        # yet, in debug mode, when asked for -- and to redo a pass that overflowed its reservation (strict mode).
+        reserve = 0 if (exact or debug) else _lib.r3dgs_reserve_hint_view(P, W, H, _ptr(vm))
         if _reserve is not None:   # tests: a chosen reservation
             reserve = int(_reserve)
+        strict = _strict if _strict_override is None else bool(_strict_override)
         if reserve > 0:
             geom = torch.empty(_blob_bytes("geom", P), **u8)
             binning = torch.empty(_blob_bytes("bin", P, W, H, reserve), **u8)
@@ -342,14 +379,26 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
             ticket = fn_reserved(geom.data_ptr(), binning.data_ptr(), img.data_ptr(), reserve, *head, *tail)
             if ticket < 0:
                 _check(-1, "rasterize_gaussians")
-            _watch_overflow()
-            return NumRendered(ticket, reserve), out_color, radii, geom, binning, img
+            _stats["reserved_passes"] += 1
+            nr = NumRendered(ticket, reserve)
+            if not strict:
+                _watch_overflow()
+                return nr, out_color, radii, geom, binning, img
+            if not nr.truncated:   # waits for the pass's header (not for the pass)
+                return nr, out_color, radii, geom, binning, img
+            # The reservation did not hold: redo on the exact-size path.  Counter mode accumulates into its outputs.
+            _stats["redone_passes"] += 1
+            if counters is not None:
+                touched.zero_()
+                transm.zero_()
+            del geom, binning, img
         geom, binning, img = _Blob(dev), _Blob(dev), _Blob(dev)
         rendered = fn_exact(geom.cb, None, binning.cb, None, img.cb, None, *head, *tail)
     for blob in (geom, binning, img):
         if blob.error is not None:   # e.g. torch OOM inside the allocator callback: surface the original exception
             raise blob.error
     _check(rendered, "rasterize_gaussians")
+    _stats["exact_passes"] += 1
     return NumRendered(0, max(rendered, 1), rendered), out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
