@@ -54,7 +54,8 @@ int r3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, con
 
 /* Rasterizer::forward (rasterizer.h:31-56, rasterizer_impl.cu:359-504).
  * Returns num_rendered (>= 0) or a negative status.  Exact-size contract of the reference: the binning blob is
- * requested through the callback once num_rendered is known, i.e. this entry point waits for that one number
+ * requested through the callback once the pair count is known (r3dgs_forward_pairs; == num_rendered unless the
+ * opacity-aware rects left tiles out), i.e. this entry point waits for that one number
  * (the reference's cudaMemcpy at rasterizer_impl.cu:446) -- by polling host-mapped memory the pass writes, with a
  * deadline (R3DGS_SYNC_TIMEOUT_MS).  Training loops should use r3dgs_forward_reserved, which never waits.
  *   D        : per-Gaussian SH degree [P] (int32)
@@ -133,15 +134,32 @@ long long r3dgs_inference_forward_reserved(char* geom_buffer, char* binning_buff
                                            int* radii, int calculate_mean_transmittance, int debug, void* stream);
 int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible, int* reserve, int* flags);
 long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserve);
+/* (tile, Gaussian) pairs of a pass, as opposed to its num_rendered.  num_rendered keeps the reference's definition (sum
+ * over the visible Gaussians of the tile count of the 3-sigma bounding square, rasterizer_impl.cu:441-446); the lists
+ * this library builds leave out the tiles of that square which the Gaussian cannot reach with alpha >= 1/255
+ * (opacity-aware rects, on by default: no pixel decision changes, so image and gradients are those of the full lists),
+ * so pairs <= num_rendered.  The binning blob and R3DGS_PASS_TRUNCATED are about pairs.
+ *   r3dgs_pass_pairs: pair count of a ticket (wait as for r3dgs_pass_query); negative on error.
+ *   r3dgs_forward_pairs: pair count of the last r3dgs_forward / r3dgs_inference_forward call of this thread -- the
+ *     capacity its binning callback was asked for, which is what r3dgs_backward / r3dgs_export_binning take as R.
+ *   r3dgs_set_tight_rects(0): bin into the reference's rects (lists identical to the reference's; pairs ==
+ *     num_rendered); returns the previous setting (a negative argument only queries).  Also R3DGS_TIGHT_RECT=0.
+ *   r3dgs_export_rects: debug accessor, the tile rect (x0, y0, x1, y1; exclusive maxima) each Gaussian was binned
+ *     into, [P][4] uint16 device array (undefined for culled Gaussians). */
+int r3dgs_pass_pairs(long long ticket, int wait);
+int r3dgs_forward_pairs(void);
+int r3dgs_set_tight_rects(int on);
+int r3dgs_export_rects(int P, char* geom_buffer, unsigned short* rects, void* stream);
+
 /* Forget every pair count learnt so far (a new scene is about to be loaded; tests): the next pass of each image size
  * takes the exact-size path again. */
 void r3dgs_reserve_forget(void);
 
 /* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
  * No host synchronisation; one hipGraph launch once the shape has been seen.  R is the pair capacity the forward
- * sized the binning blob with: num_rendered as returned by r3dgs_forward, or the `reserve` passed to
- * r3dgs_forward_reserved (r3dgs_binning_capacity recovers it from the blob's size); the pair count itself is read
- * from the device.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
+ * sized the binning blob with: r3dgs_forward_pairs() after r3dgs_forward (== the num_rendered it returned when the
+ * opacity-aware rects are off), or the `reserve` passed to r3dgs_forward_reserved (r3dgs_binning_capacity recovers a
+ * capacity with the same layout from the blob's size); the pair count itself is read from the device.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
  * rasterize_points.cu:245; the multiplier lambda / (visible * 45) is formed on the device).
  * Every element of every output is written (zeros where the reference relies on zero-initialised
  * tensors), so outputs may be uninitialised.  dL_dconic ([P,2,2]) may be NULL.

@@ -32,6 +32,8 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.orc_bin.restype = C.c_int64
+        _LIB.orc_bin_rects.restype = C.c_int64
+        _LIB.orc_culled_tile_violations.restype = C.c_int64
         _LIB.orc_higher_msb.restype = C.c_uint32
     return _LIB
 
@@ -56,12 +58,15 @@ TILE = 16
 
 def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modifier, cov3D_precomp,
             viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degrees, campos,
-            ragged=None, counter_mode=False, want_ambig=False, ambig_rel=1e-4):
+            ragged=None, counter_mode=False, want_ambig=False, ambig_rel=1e-4, rects=None):
     """Oracle of `_C.rasterize_gaussians` (and `_variableSH_bands` when `ragged`
     = (coeffs_num, per_band_count, cumsum_count) and `sh` is the flat ragged buffer).
     Absent optional inputs: None or empty arrays.  Returns a dict with the public
     outputs (num_rendered, color[3,H,W], radii[P]) and the internal state needed by
-    `backward` / bit-exact binning checks (keys, point_list, ranges, n_contrib, final_T...)."""
+    `backward` / bit-exact binning checks (keys, point_list, ranges, n_contrib, final_T...).
+    rects ([P,4] tile rects x0, y0, x1, y1 with exclusive maxima): bin every visible Gaussian into THAT rect instead of
+    the reference's 3-sigma square (see orc_bin_rects); `culled_tile_violations` says whether the rects are admissible.
+    num_rendered stays the reference's count, state["pairs"] is the length of the lists."""
     L = lib()
     means3D = _f32(means3D)
     P = 0 if means3D is None else means3D.shape[0]
@@ -94,7 +99,7 @@ def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modif
     final_T = np.zeros(N, np.float32)
     n_contrib = np.zeros(N, np.uint32)
     ranges = np.zeros((gx * gy, 2), np.uint32)
-    R = 0
+    R = pairs = 0
     keys = np.zeros(0, np.uint64)
     plist = np.zeros(0, np.uint32)
     touched = transm = ambig = None
@@ -106,11 +111,15 @@ def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modif
                          _p(conic_op), _p(rgb), _p(clamped), _p(tiles))
         R = int(L.orc_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
                           None, None, None))
-        keys = np.zeros(max(R, 1), np.uint64)
-        plist = np.zeros(max(R, 1), np.uint32)
-        L.orc_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
-                  _p(keys), _p(plist), _p(ranges))
-        keys, plist = keys[:R], plist[:R]
+        if rects is not None:
+            rects = np.ascontiguousarray(rects, dtype=np.uint16).reshape(P, 4)
+        pairs = int(L.orc_bin_rects(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
+                                    _p(rects), None, None, None))
+        keys = np.zeros(max(pairs, 1), np.uint64)
+        plist = np.zeros(max(pairs, 1), np.uint32)
+        L.orc_bin_rects(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles), _p(rects),
+                        _p(keys), _p(plist), _p(ranges))
+        keys, plist = keys[:pairs], plist[:pairs]
         feat = colors_precomp if colors_precomp is not None else rgb
         if counter_mode:
             touched = np.zeros(P, np.int32)
@@ -124,13 +133,55 @@ def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modif
         color[:] = 0  # reference returns the zero-initialised image when P == 0 (rasterize_points.cu:170,185)
     st.update(radii=radii, xy=xy, depths=depths, cov3D=cov3D, conic_op=conic_op, rgb=rgb, clamped=clamped,
               tiles_touched=tiles, keys=keys, point_list=plist, ranges=ranges, final_T=final_T,
-              n_contrib=n_contrib, num_rendered=R)
+              n_contrib=n_contrib, num_rendered=R, pairs=pairs, rects=rects)
     out = dict(num_rendered=R, color=color, radii=radii, state=st)
     if counter_mode:
         out.update(touched_pixels=touched, transmittance=transm)
     if want_ambig:
         out["ambig"] = ambig.reshape(H, W)
     return out
+
+
+def with_rects(out, rects, want_ambig=False, ambig_rel=1e-4):
+    """The forward result `out` (of `forward`) re-binned into `rects` and re-blended: same per-Gaussian quantities, the
+    reference's binning algorithm over the given rects, the reference's blend over those lists."""
+    L = lib()
+    st = dict(out["state"])
+    P, W, H = st["P"], st["W"], st["H"]
+    rects = np.ascontiguousarray(rects, dtype=np.uint16).reshape(P, 4)
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    args = (C.c_int(P), C.c_int(W), C.c_int(H), _p(st["radii"]), _p(st["xy"]), _p(st["depths"]), _p(st["tiles_touched"]),
+            _p(rects))
+    pairs = int(L.orc_bin_rects(*args, None, None, None))
+    keys, plist = np.zeros(max(pairs, 1), np.uint64), np.zeros(max(pairs, 1), np.uint32)
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    L.orc_bin_rects(*args, _p(keys), _p(plist), _p(ranges))
+    color = np.zeros((3, H, W), np.float32)
+    final_T, n_contrib = np.zeros(W * H, np.float32), np.zeros(W * H, np.uint32)
+    ambig = np.zeros(W * H, np.uint8) if want_ambig else None
+    feat = st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]
+    L.orc_blend_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(plist), _p(st["xy"]), _p(feat), _p(st["conic_op"]),
+                    _p(st["bg"]), _p(color), _p(final_T), _p(n_contrib), None, None, _p(ambig), C.c_float(ambig_rel))
+    vis = st["radii"] > 0
+    tiles = np.where(vis, (rects[:, 2].astype(np.int64) - rects[:, 0]) * (rects[:, 3].astype(np.int64) - rects[:, 1]), 0)
+    st.update(keys=keys[:pairs], point_list=plist[:pairs], ranges=ranges, final_T=final_T, n_contrib=n_contrib,
+              pairs=pairs, rects=rects, tiles_binned=tiles.astype(np.uint32))
+    res = dict(num_rendered=out["num_rendered"], color=color, radii=out["radii"], state=st)
+    if want_ambig:
+        res["ambig"] = ambig.reshape(H, W)
+    return res
+
+
+def culled_tile_violations(st, rects):
+    """(violations, tiles_left_out) of binning the state's Gaussians into `rects` ([P,4] tiles, exclusive maxima) instead
+    of the reference's squares: violations counts the pixels of left-out tiles that the reference's per-pixel test would
+    have blended (and rects sticking out of the reference's).  0 <=> the shorter lists take the same pixel decisions."""
+    L = lib()
+    rects = np.ascontiguousarray(rects, dtype=np.uint16).reshape(st["P"], 4)
+    left = C.c_int64(0)
+    bad = int(L.orc_culled_tile_violations(C.c_int(st["P"]), C.c_int(st["W"]), C.c_int(st["H"]), _p(st["radii"]),
+                                           _p(st["xy"]), _p(st["conic_op"]), _p(rects), C.byref(left)))
+    return bad, int(left.value)
 
 
 def backward(st, dL_dout_color, lambda_sh_sparsity=0.0):

@@ -316,13 +316,23 @@ uint32_t orc_higher_msb(uint32_t n)
  * :465-473 stable radix sort on bits [0, 32+msb), :124-146 identifyTileRanges.
  * Call with keys==NULL to obtain R only.  Returns R.
  * ------------------------------------------------------------------------- */
-int64_t orc_bin(int P, int W, int H, const int* radii, const float* xy, const float* depths,
-                const uint32_t* tiles_touched, uint64_t* keys /*R*/, uint32_t* point_list /*R*/,
-                uint32_t* ranges /*2*Tn*/)
+/* rects == NULL: the reference's binning (rasterizer_impl.cu:78-146): every tile of getRect(radius).
+ * rects != NULL ([P][4] = x0, y0, x1, y1 in tiles, exclusive maxima; the rows of the Gaussians with radii > 0 are used):
+ * the same algorithm over GIVEN rects -- the product bins a Gaussian into the sub-rect of the reference's square that it
+ * can reach with alpha >= 1/255 (csrc/gauss_math.h tighten_rect), the tests hand the product's rects in here and check
+ * with orc_culled_tile_violations that every tile left out is one the reference's own per-pixel test rejects. */
+int64_t orc_bin_rects(int P, int W, int H, const int* radii, const float* xy, const float* depths,
+                      const uint32_t* tiles_touched, const uint16_t* rects, uint64_t* keys /*R*/,
+                      uint32_t* point_list /*R*/, uint32_t* ranges /*2*Tn*/)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     int64_t R = 0;
-    for (int i = 0; i < P; i++) R += tiles_touched[i];
+    for (int i = 0; i < P; i++) {
+        if (!rects)
+            R += tiles_touched[i];
+        else if (radii[i] > 0)
+            R += (int64_t)(rects[4 * i + 2] - rects[4 * i]) * (int64_t)(rects[4 * i + 3] - rects[4 * i + 1]);
+    }
     if (!keys) return R;
     uint64_t* ku = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(R ? R : 1));
     uint32_t* vu = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(R ? R : 1));
@@ -330,7 +340,14 @@ int64_t orc_bin(int P, int W, int H, const int* radii, const float* xy, const fl
     for (int i = 0; i < P; i++) {
         if (radii[i] > 0) {
             int rmin[2], rmax[2];
-            get_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, rmin, rmax);
+            if (rects) {
+                rmin[0] = rects[4 * i];
+                rmin[1] = rects[4 * i + 1];
+                rmax[0] = rects[4 * i + 2];
+                rmax[1] = rects[4 * i + 3];
+            } else {
+                get_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, rmin, rmax);
+            }
             uint32_t dbits;
             memcpy(&dbits, depths + i, 4);
             for (int y = rmin[1]; y < rmax[1]; y++)
@@ -403,6 +420,50 @@ int64_t orc_bin(int P, int W, int H, const int* radii, const float* xy, const fl
  * of its threshold -- a different-but-valid exp() rounding could flip it; parity
  * tests exclude exactly those pixels from the 1e-5 bound.
  * ------------------------------------------------------------------------- */
+int64_t orc_bin(int P, int W, int H, const int* radii, const float* xy, const float* depths,
+                const uint32_t* tiles_touched, uint64_t* keys /*R*/, uint32_t* point_list /*R*/,
+                uint32_t* ranges /*2*Tn*/)
+{
+    return orc_bin_rects(P, W, H, radii, xy, depths, tiles_touched, NULL, keys, point_list, ranges);
+}
+
+/* Number of (tile, Gaussian, pixel) triples where the Gaussian's GIVEN rect leaves out a tile of the reference's rect
+ * (auxiliary.h:46-56) although a pixel of that tile passes the reference's own per-pixel test (forward.cu:534-546:
+ * power <= 0 and alpha = min(0.99, opacity * exp(power)) >= 1/255), plus the number of given rects that are not inside
+ * the reference's.  0 <=> blending the shorter lists takes exactly the per-pixel decisions of the full lists.
+ * Same fp32 expressions as orc_blend_fwd. */
+int64_t orc_culled_tile_violations(int P, int W, int H, const int* radii, const float* xy, const float* conic_op,
+                                   const uint16_t* rects, int64_t* tiles_left_out)
+{
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    int64_t bad = 0, left = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : bad, left)
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        int rmin[2], rmax[2];
+        get_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, rmin, rmax);
+        const int x0 = rects[4 * i], y0 = rects[4 * i + 1], x1 = rects[4 * i + 2], y1 = rects[4 * i + 3];
+        if (x1 > x0 && y1 > y0 && (x0 < rmin[0] || y0 < rmin[1] || x1 > rmax[0] || y1 > rmax[1])) bad++;
+        const float* co = conic_op + 4 * i;
+        for (int ty = rmin[1]; ty < rmax[1]; ty++)
+            for (int tx = rmin[0]; tx < rmax[0]; tx++) {
+                if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) continue; /* kept */
+                left++;
+                for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+                    for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+                        const float dx = xy[2 * i] - (float)px, dy = xy[2 * i + 1] - (float)py;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float alpha = fminf_(0.99f, co[3] * expf(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        bad++;
+                    }
+            }
+    }
+    if (tiles_left_out) *tiles_left_out = left;
+    return bad;
+}
+
 void orc_blend_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
                    const float* colors, const float* conic_op, const float* bg, float* out_color,
                    float* final_T, uint32_t* n_contrib, int* touched, float* transmittance,

@@ -59,7 +59,7 @@ void run_generic_depth_sort(int P, GeomState& g, hipStream_t s)
 // path lets the histogram workgroups do it (DepthArgs::fuse_header).
 __global__ __launch_bounds__(1024) void header_reduce_kernel(const HeaderArgs* __restrict__ ap)
 {
-    __shared__ uint32_t s_red[16][4];
+    __shared__ uint32_t s_red[16][6];
     const HeaderArgs a = *ap;
     const PrePartial all = reduce_partials(a.parts, a.n_parts, s_red);
     if (threadIdx.x == 0) write_header(a, all);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
             const uint32_t g = bf[blk + 1];
             j = (g > 0u && offsets[g - 1] == pos1) ? g - 1u : g;
         } else if (bf && R == a.hdr->num_rendered) {
-            j = a.hdr->visible - 1u;   // the last visible Gaussian in depth order
+            j = a.hdr->binned - 1u;   // the last Gaussian in depth order that owns pairs
         } else {
             j = upper_bound_wave(offsets, (uint32_t)a.P, w == 0 ? pos0 : pos1 - 1, lane);
         }

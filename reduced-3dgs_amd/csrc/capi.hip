@@ -63,6 +63,20 @@ namespace {
 using namespace r3;
 
 thread_local std::string g_last_error;
+thread_local int g_last_forward_pairs = 0;   // r3dgs_forward_pairs()
+
+// Opacity-aware tile rects (gauss_math.h tighten_rect) are the default; R3DGS_TIGHT_RECT=0 / r3dgs_set_tight_rects(0)
+// bins into the reference's 3-sigma squares (identical lists to the reference's: the bit-exact binning tests).
+std::atomic<int> g_tight_rects{-1};
+int tight_rects()
+{
+    int v = g_tight_rects.load();
+    if (v < 0) {
+        v = env_int("R3DGS_TIGHT_RECT", 1, 0, 1);
+        g_tight_rects.store(v);
+    }
+    return v;
+}
 
 bool env_is(const char* name, const char* value)
 {
@@ -564,6 +578,7 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     p.color_split[1] = split0 + split1 > 100 ? 100 - split0 : split1;
     p.color_split[2] = 100 - p.color_split[0] - p.color_split[1];
     p.generic_depth_sort = (generic_env || c.P >= (1 << 24)) ? 1 : 0;   // the bucket histogram packs the count in 24 bits
+    p.tight = tight_rects();
     return p;
 }
 
@@ -603,6 +618,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.pre.partials = g.partials;
     a.pre.radii = radii;
     a.pre.color_blocks = (c.P + kPreBlockSize - 1) / kPreBlockSize;
+    a.pre.tight = p.tight;
 
     a.header.parts = g.partials;
     a.header.n_parts = (int)pre_partials((size_t)c.P);
@@ -712,7 +728,8 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
 {
     return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
-           ((uint32_t)p.layout.wide << 8) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7);
+           ((uint32_t)p.layout.wide << 8) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7) |
+           ((uint32_t)p.tight << 10);
 }
 
 int current_device()
@@ -746,6 +763,7 @@ bool take_prefer_generic(int dev, const FwdCall& c)
 int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer, void* binning_user,
                   r3dgs_alloc_fn imageBuffer, void* image_user, const FwdCall& c)
 {
+    g_last_forward_pairs = 0;
     if (c.P <= 0) return 0;
     if (!geometryBuffer || !binningBuffer || !imageBuffer) throw Error("allocator callbacks must not be NULL");
     validate_forward(c);
@@ -781,8 +799,9 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     }
     // the one structural wait of this entry point (the reference's cudaMemcpy at rasterizer_impl.cu:446)
     const volatile PassInfo* info = wait_info(ticket);
-    const uint32_t R = info->pairs;
-    if (R > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
+    const uint32_t R = info->pairs, R_ref = info->num_rendered;
+    if (R > 0x7fffffffu || R_ref > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
+    g_last_forward_pairs = (int)R;
     plan.reserve = R ? R : 1u;
     plan.grid_pairs = plan.reserve;   // exact size: one block per chunk
     char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy), binning_user);
@@ -791,7 +810,7 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, false);
     launch_write_args(d_args, args, s);   // the completed block (binning pointers, pair capacity)
     issue_forward(plan, d_args, args, s, 2, hooks, &geom);
-    return (int)R;
+    return (int)R_ref;   // what the reference returns: the tile count of ITS rects (== R with the tight rects off)
 }
 
 // Reserved forward: caller-provided blobs, no host wait.  Returns the pass ticket.
@@ -1078,6 +1097,45 @@ int r3dgs_pass_query(long long ticket, int wait, int* num_rendered, int* visible
         if (flags) *flags = (cap != 0xFFFFFFFFu && pairs > cap ? R3DGS_PASS_TRUNCATED : 0) |
                             (info->sort_seq == (uint32_t)n && info->sort_overflow ? R3DGS_PASS_DEPTH_BUCKET_OVERFLOW : 0);
         return 1;
+    });
+}
+
+int r3dgs_pass_pairs(long long ticket, int wait)
+{
+    return guarded([&]() {
+        if (ticket <= 0) throw r3::Error("not a pass ticket");
+        const uint64_t t = (uint64_t)ticket, n = ticket_number(t);
+        if (g_next_ticket.load() - n >= kInfoRing) throw r3::Error("pass ticket expired (ring reused)");
+        const volatile r3::PassInfo* info = info_ring(ticket_device(t)).host + n % kInfoRing;
+        if (wait)
+            info = wait_info(t);
+        else if (info->seq != (uint32_t)n)
+            throw r3::Error("pass not published yet");
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const uint32_t pairs = info->pairs;
+        return (int)(pairs > 0x7fffffffu ? 0x7fffffffu : pairs);
+    });
+}
+
+int r3dgs_forward_pairs(void) { return g_last_forward_pairs; }
+
+int r3dgs_set_tight_rects(int on)   // on < 0: query only
+{
+    const int before = tight_rects();
+    if (on >= 0) g_tight_rects.store(on ? 1 : 0);
+    return before;
+}
+
+int r3dgs_export_rects(int P, char* geom_buffer, unsigned short* rects, void* stream)
+{
+    return guarded([&]() {
+        using namespace r3;
+        if (P <= 0) return 0;
+        if (!geom_buffer || !rects) throw Error("a required pointer is NULL");
+        GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
+        R3_HIP(hipMemcpyAsync(rects, geom.rect, sizeof(ushort4) * (size_t)P, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+        return 0;
     });
 }
 

@@ -45,16 +45,22 @@ constexpr int kPairStride = 12; // floats per row of the per-pair slab: 48-B row
 constexpr int kPreBlockSize = 256;
 struct PrePartial {
     uint32_t visible;        // #Gaussians with radii > 0 in the workgroup (SH-sparsity normaliser, rasterizer_impl.cu:549-566)
-    uint32_t num_rendered;   // sum of tiles_touched
-    uint32_t depth_max;      // max depth bits over the visible Gaussians (0 if none)
+    uint32_t num_rendered;   // sum of tiles_touched of the rects the Gaussians are BINNED into: the pairs the pass wants
+    uint32_t depth_max;      // max depth bits over the binned Gaussians (0 if none)
     uint32_t depth_inv_min;  // max of ~(depth bits), i.e. ~min (0 if none)
+    uint32_t binned;         // #Gaussians with tiles_touched > 0 (<= visible: opacity-aware rects, gauss_math.h tighten_rect)
+    uint32_t rendered_ref;   // sum of the tile counts of the REFERENCE's rects: what the reference calls num_rendered
+    uint32_t pad[2];
 };
+static_assert(sizeof(PrePartial) == 32, "two 16-byte loads per partial");
 struct GeomHeader {
-    uint32_t visible, num_rendered, depth_max, depth_inv_min;
+    uint32_t visible, num_rendered, depth_max, depth_inv_min;   // num_rendered: pairs wanted (see PrePartial)
     uint32_t num_pairs;       // min(num_rendered, reserve): the pairs every later kernel of the pass works on
     uint32_t reserve;         // pair capacity of the binning blob of this pass
     uint32_t sort_overflow;   // a depth bucket exceeded the LDS sort capacity (handled on the device; host hint only)
-    uint32_t pad[57];
+    uint32_t binned;          // Gaussians that own pairs: the first `binned` entries of the depth order
+    uint32_t rendered_ref;    // the reference's num_rendered (reported; nothing on the device uses it)
+    uint32_t pad[55];
 };
 static_assert(sizeof(GeomHeader) == 256, "header = 256 B");
 inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBlockSize; }
@@ -417,6 +423,7 @@ struct PreArgs {          // preprocess.hip
     PrePartial* partials;
     int* radii;
     int color_blocks;     // workgroup-sized chunks of the colour kernel's persistent loop
+    int tight;            // 1: bin into the opacity-aware rect (gauss_math.h tighten_rect), 0: into the reference's
 };
 struct HeaderArgs {       // binning.hip header_reduce_kernel
     const PrePartial* parts;
@@ -572,6 +579,7 @@ struct FwdPlan {
     int color_fuse;        // 1: the colour chunks ride in spare workgroups of the depth-sort kernels
     int color_split[3];    // percent of the colour chunks in the histogram / scatter / bucket-sort launches
     int generic_depth_sort;  // rocPRIM sort + scan instead of the bucketed sort (never inside a graph)
+    int tight;             // opacity-aware tile rects (default) or the reference's 3-sigma squares
 };
 struct BwdPlan {
     int P, M, W, H, gx, gy;

@@ -108,22 +108,26 @@ inline size_t depth_hist_lds(int nb) { return (size_t)(nb + 1) * sizeof(unsigned
 inline size_t depth_scatter_lds(int nb) { return (size_t)2 * (nb + 2) * sizeof(uint32_t) + 256 * sizeof(unsigned long long); }
 constexpr size_t kBucketSortLds = (size_t)kBucketCap * 8 + 256 * 4 + (256 + 256 + 4 * 256 + 4) * 4;
 
-// Sum / max of the preprocess workgroups' partials by one workgroup (s_red: 16 x 4 words).
-__device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[4])
+// Sum / max of the preprocess workgroups' partials by one workgroup (s_red: 16 x 6 words).
+__device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ parts, int n, uint32_t (*s_red)[6])
 {
-    PrePartial acc = {0u, 0u, 0u, 0u};
+    PrePartial acc = {0u, 0u, 0u, 0u, 0u, 0u, {0u, 0u}};
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint4 v = reinterpret_cast<const uint4*>(parts)[i];
+        const uint4 v = reinterpret_cast<const uint4*>(parts)[2 * i], w = reinterpret_cast<const uint4*>(parts)[2 * i + 1];
         acc.visible += v.x;
         acc.num_rendered += v.y;
         acc.depth_max = max(acc.depth_max, v.z);
         acc.depth_inv_min = max(acc.depth_inv_min, v.w);
+        acc.binned += w.x;
+        acc.rendered_ref += w.y;
     }
     for (int off = 32; off > 0; off >>= 1) {
         acc.visible += (uint32_t)__shfl_xor((int)acc.visible, off);
         acc.num_rendered += (uint32_t)__shfl_xor((int)acc.num_rendered, off);
         acc.depth_max = max(acc.depth_max, (uint32_t)__shfl_xor((int)acc.depth_max, off));
         acc.depth_inv_min = max(acc.depth_inv_min, (uint32_t)__shfl_xor((int)acc.depth_inv_min, off));
+        acc.binned += (uint32_t)__shfl_xor((int)acc.binned, off);
+        acc.rendered_ref += (uint32_t)__shfl_xor((int)acc.rendered_ref, off);
     }
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
@@ -131,22 +135,26 @@ __device__ inline PrePartial reduce_partials(const PrePartial* __restrict__ part
         s_red[w][1] = acc.num_rendered;
         s_red[w][2] = acc.depth_max;
         s_red[w][3] = acc.depth_inv_min;
+        s_red[w][4] = acc.binned;
+        s_red[w][5] = acc.rendered_ref;
     }
     __syncthreads();
-    PrePartial out = {0u, 0u, 0u, 0u};
+    PrePartial out = {0u, 0u, 0u, 0u, 0u, 0u, {0u, 0u}};
     for (int k = 0; k < nw; k++) {
         out.visible += s_red[k][0];
         out.num_rendered += s_red[k][1];
         out.depth_max = max(out.depth_max, s_red[k][2]);
         out.depth_inv_min = max(out.depth_inv_min, s_red[k][3]);
+        out.binned += s_red[k][4];
+        out.rendered_ref += s_red[k][5];
     }
     __syncthreads();
     return out;
 }
 
-// The device header every later kernel reads (visible count, num_rendered, the pair count clamped to the reservation,
-// depth range), and num_rendered / visible published in the pass's host-mapped PassInfo slot: the host never has to
-// wait for it, and when it wants it (exact-size path, lazy statistics) it polls plain memory.  One thread.
+// The device header every later kernel reads (visible count, the pairs wanted, that count clamped to the reservation,
+// depth range), and the pass's numbers published in its host-mapped PassInfo slot: the host never has to wait for the
+// pass, and when it wants them (strict mode's check, exact-size path) it polls plain memory.  One thread.
 __device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
 {
     GeomHeader* hdr = a.hdr;
@@ -157,9 +165,11 @@ __device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
     hdr->num_pairs = min(all.num_rendered, a.reserve);
     hdr->reserve = a.reserve;
     hdr->sort_overflow = 0u;
+    hdr->binned = all.binned;
+    hdr->rendered_ref = all.rendered_ref;
     volatile PassInfo* info = a.info;
     if (info) {
-        info->num_rendered = all.num_rendered;
+        info->num_rendered = all.rendered_ref;
         info->pairs = all.num_rendered;
         info->visible = all.visible;
         info->reserve = a.reserve;
@@ -175,7 +185,7 @@ __device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
 // workgroup 0 writes the header: the one-workgroup header kernel and its launch gap leave the chain.
 __device__ inline void depth_hist_role(const DepthArgs& a, const HeaderArgs& h, char* smem, int wg)
 {
-    __shared__ uint32_t s_red[16][4];
+    __shared__ uint32_t s_red[16][6];
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);   // [nb + 1]
     const int P = a.P, nb = a.nb;
     for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;

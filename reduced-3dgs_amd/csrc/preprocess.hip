@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
             q[2] = qv.z;
             q[3] = qv.w;
         }
-        preprocess_one(cam, mx, my, mz, sc, q, c6p, a.in.opacities[i], &o);
+        preprocess_one(cam, mx, my, mz, sc, q, c6p, a.in.opacities[i], &o, a.tight != 0);
         uint32_t dkey = 0xFFFFFFFFu;
         if (o.radius > 0) {
             GRec r;
@@ -101,7 +101,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
             a.rec[i] = r;
             a.rect[i] = make_ushort4((unsigned short)o.rmin[0], (unsigned short)o.rmin[1], (unsigned short)o.rmax[0],
                                      (unsigned short)o.rmax[1]);
-            dkey = __float_as_uint(o.depth);
+            // a visible Gaussian whose opacity-aware rect is empty owns no pair: it stays out of the depth order like a
+            // culled one (its radius, record and gradients are those of a visible Gaussian)
+            if (o.tiles > 0) dkey = __float_as_uint(o.depth);
         }
         a.radii[i] = o.radius;
         a.tiles[i] = o.tiles;
@@ -111,28 +113,35 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
     // num_rendered, and the depth range of the visible Gaussians (bucketed depth sort, binning.hip).  R does not depend
     // on the depth order, so the host can fetch it while the GPU is busy with the depth sort (capi.hip).
     const unsigned long long vmask = __ballot(o.radius > 0);
-    uint32_t tsum = o.tiles;
-    uint32_t dmax = o.radius > 0 ? __float_as_uint(o.depth) : 0u, dinv = o.radius > 0 ? ~__float_as_uint(o.depth) : 0u;
+    const bool binned = o.tiles > 0;
+    const unsigned long long bmask = __ballot(binned);
+    uint32_t tsum = o.tiles, rsum = o.tiles_ref;
+    uint32_t dmax = binned ? __float_as_uint(o.depth) : 0u, dinv = binned ? ~__float_as_uint(o.depth) : 0u;
     for (int off = 32; off > 0; off >>= 1) {
         tsum += (uint32_t)__shfl_xor((int)tsum, off);
+        rsum += (uint32_t)__shfl_xor((int)rsum, off);
         dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off));
         dinv = max(dinv, (uint32_t)__shfl_xor((int)dinv, off));
     }
-    __shared__ uint32_t s_cnt[kPreBlock / 64][4];
+    __shared__ uint32_t s_cnt[kPreBlock / 64][6];
     if (lane == 0) {
         s_cnt[wave][0] = (uint32_t)__popcll(vmask);
         s_cnt[wave][1] = tsum;
         s_cnt[wave][2] = dmax;
         s_cnt[wave][3] = dinv;
+        s_cnt[wave][4] = (uint32_t)__popcll(bmask);
+        s_cnt[wave][5] = rsum;
     }
     __syncthreads();
     if (tid == 0) {
-        PrePartial pp = {0u, 0u, 0u, 0u};
+        PrePartial pp = {0u, 0u, 0u, 0u, 0u, 0u, {0u, 0u}};
         for (int k = 0; k < kPreBlock / 64; k++) {
             pp.visible += s_cnt[k][0];
             pp.num_rendered += s_cnt[k][1];
             pp.depth_max = max(pp.depth_max, s_cnt[k][2]);
             pp.depth_inv_min = max(pp.depth_inv_min, s_cnt[k][3]);
+            pp.binned += s_cnt[k][4];
+            pp.rendered_ref += s_cnt[k][5];
         }
         a.partials[blockIdx.x] = pp;
     }

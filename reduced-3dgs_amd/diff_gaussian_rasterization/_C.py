@@ -53,6 +53,13 @@ _lib.r3dgs_inference_forward_reserved.restype = C.c_longlong
 _lib.r3dgs_inference_forward_reserved.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp] + _FWD_TAIL
 _lib.r3dgs_pass_query.restype = _i
 _lib.r3dgs_pass_query.argtypes = [C.c_longlong, _i, _vp, _vp, _vp, _vp]
+_lib.r3dgs_pass_pairs.restype = _i
+_lib.r3dgs_pass_pairs.argtypes = [C.c_longlong, _i]
+_lib.r3dgs_forward_pairs.restype = _i
+_lib.r3dgs_set_tight_rects.restype = _i
+_lib.r3dgs_set_tight_rects.argtypes = [_i]
+_lib.r3dgs_export_rects.restype = _i
+_lib.r3dgs_export_rects.argtypes = [_i, _vp, _vp, _vp]
 _lib.r3dgs_reserve_overflow_events.restype = C.c_longlong
 _lib.r3dgs_reserve_overflow_events.argtypes = [_vp, _vp]
 _lib.r3dgs_backward.restype = _i
@@ -187,15 +194,18 @@ class _on_device:
 
 
 class NumRendered:
-    """The `num_rendered` slot of the forward's return tuple (rasterize_points.cu:221).  The asynchronous forward
-    does not wait for the number: it lives on the device, and this object fetches it the first time someone looks
-    (int(), index, comparison, print) -- the training loop never does, it only hands the object back to
-    rasterize_gaussians_backward.  `.capacity` is the pair capacity the binning buffer was sized with."""
+    """The `num_rendered` slot of the forward's return tuple (rasterize_points.cu:221), with the reference's meaning:
+    the sum over the visible Gaussians of the tile count of their 3-sigma squares.  The asynchronous forward does not
+    wait for the number: it lives on the device, and this object fetches it the first time someone looks (int(),
+    index, comparison, print) -- the training loop never does, it only hands the object back to
+    rasterize_gaussians_backward.  `.capacity` is the pair capacity the binning buffer was sized with, `.pairs` the
+    (tile, Gaussian) pairs the pass binned (<= num_rendered: opacity-aware rects leave out tiles a Gaussian cannot
+    reach; equal with set_tight_rects(False))."""
 
-    __slots__ = ("ticket", "capacity", "_value", "_flags")
+    __slots__ = ("ticket", "capacity", "_value", "_flags", "_pairs")
 
-    def __init__(self, ticket, capacity, value=None):
-        self.ticket, self.capacity, self._value, self._flags = ticket, capacity, value, 0
+    def __init__(self, ticket, capacity, value=None, pairs=None):
+        self.ticket, self.capacity, self._value, self._flags, self._pairs = ticket, capacity, value, 0, pairs
 
     def _resolve(self, wait=True):
         if self._value is None:
@@ -205,6 +215,12 @@ class NumRendered:
             if st == 1:
                 self._value, self._flags = r.value, fl.value
         return self._value
+
+    @property
+    def pairs(self):
+        if self._pairs is None:
+            self._pairs = _check(_lib.r3dgs_pass_pairs(self.ticket, 1), "pairs")
+        return self._pairs
 
     @property
     def truncated(self):
@@ -341,7 +357,7 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
         out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.zeros((0,), dtype=torch.int32, device=dev)
         e = torch.empty(0, **u8)
-        return NumRendered(0, 0, 0), out_color, radii, e, e.clone(), e.clone()
+        return NumRendered(0, 0, 0, 0), out_color, radii, e, e.clone(), e.clone()
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     bg = _dev_f32(background, dev)
@@ -399,7 +415,8 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
             raise blob.error
     _check(rendered, "rasterize_gaussians")
     _stats["exact_passes"] += 1
-    return NumRendered(0, max(rendered, 1), rendered), out_color, radii, geom.tensor, binning.tensor, img.tensor
+    pairs = int(_lib.r3dgs_forward_pairs())   # what the binning blob was sized for (<= num_rendered)
+    return NumRendered(0, max(pairs, 1), rendered, pairs), out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -500,7 +517,7 @@ def export_binning(P, R, H, W, geomBuffer, binningBuffer, imageBuffer):
     dev = geomBuffer.device
     gx, gy = (W + 15) // 16, (H + 15) // 16
     if isinstance(R, NumRendered):
-        cap, R = R.capacity, int(R)
+        cap, R = R.capacity, R.pairs
     else:
         cap = _lib.r3dgs_binning_capacity(P, W, H, int(binningBuffer.numel())) if binningBuffer.numel() else 0
     R = min(int(R), cap)
@@ -515,6 +532,26 @@ def export_binning(P, R, H, W, geomBuffer, binningBuffer, imageBuffer):
                                          _ptr(keys), _ptr(plist), _ptr(ranges), _ptr(n_contrib), _ptr(final_T),
                                          _ptr(tiles), _stream()), "export_binning")
     return dict(keys=keys, point_list=plist, ranges=ranges, n_contrib=n_contrib, final_T=final_T, tiles_touched=tiles)
+
+
+def export_rects(P, geomBuffer):
+    """Debug accessor (not in the reference): the tile rect (x0, y0, x1, y1; exclusive maxima) every Gaussian was binned
+    into, int32[P,4] (rows of culled Gaussians are undefined)."""
+    out = torch.empty((P, 4), dtype=torch.int16, device=geomBuffer.device)
+    with _on_device(geomBuffer.device):
+        _check(_lib.r3dgs_export_rects(P, _ptr(geomBuffer), _ptr(out), _stream()), "export_rects")
+    return out.to(torch.int32) & 0xFFFF
+
+
+def set_tight_rects(on):
+    """True (default): a Gaussian is binned into the tiles of the reference's 3-sigma square that it can actually reach
+    with alpha >= 1/255 (bounding box of that ellipse); False: into the whole square, i.e. lists identical to the
+    reference's.  Image, radii, num_rendered and gradients are the same either way.  Returns the previous setting."""
+    return bool(_lib.r3dgs_set_tight_rects(int(bool(on))))
+
+
+def tight_rects():
+    return bool(_lib.r3dgs_set_tight_rects(-1))
 
 
 def rasterize_gaussians_counters(*args):

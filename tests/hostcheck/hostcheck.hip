@@ -74,6 +74,30 @@ void hc_preprocess(int P, int M, const int* degs, const float* means, const floa
     }
 }
 
+// The product's opacity-aware tile rects (gauss_math.h tighten_rect) for a whole scene: rects [P][4] uint16 (x0, y0, x1,
+// y1; rows of culled Gaussians zero), tiles [P] = their areas.  tests/test_hostcheck.py checks with the oracle that the
+// tiles they leave out of the reference's squares hold no pixel the reference would blend.
+void hc_tight_rects(int P, const float* means, const float* scales, float mod, const float* rots, const float* opac,
+                    const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany,
+                    int* radii, unsigned short* rects, unsigned* tiles, unsigned* tiles_ref)
+{
+    const Camera cam = make_cam(view, proj, campos, W, H, tanx, tany, mod);
+    for (int i = 0; i < P; i++) {
+        PreOut o;
+        preprocess_one(cam, means[3 * i], means[3 * i + 1], means[3 * i + 2], scales + 3 * i, rots + 4 * i, nullptr, opac[i],
+                       &o, true);
+        radii[i] = o.radius;
+        tiles[i] = o.tiles;
+        tiles_ref[i] = o.tiles_ref;
+        for (int k = 0; k < 4; k++) rects[4 * i + k] = 0;
+        if (o.radius <= 0) continue;
+        rects[4 * i] = (unsigned short)o.rmin[0];
+        rects[4 * i + 1] = (unsigned short)o.rmin[1];
+        rects[4 * i + 2] = (unsigned short)o.rmax[0];
+        rects[4 * i + 3] = (unsigned short)o.rmax[1];
+    }
+}
+
 static Splat splat_of(const float* xy, const float* conic_op, const float* rgb, unsigned id)
 {
     Splat s;

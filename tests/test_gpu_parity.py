@@ -73,13 +73,32 @@ def oracle_forward(bg, g, cam, H, W, colors=None, cov=None, use_sh=True, use_sr=
 
 
 def check_forward(C_, fout, ref, H, W, P):
+    """Public outputs against the reference-list oracle `ref`; the lists against the reference's binning algorithm run
+    over the rects the product binned into.  With set_tight_rects(False) those are the reference's squares and the lists
+    must be the reference's; with the opacity-aware rects (default) the left-out tiles are checked pixel by pixel with
+    the oracle (none may hold a pixel the reference would blend) and the oracle's blend over the shorter lists must
+    reproduce the reference-list image BIT FOR BIT."""
     R, color, radii, geom, binning, img = fout
-    st = ref["state"]
-    assert R == ref["num_rendered"]
+    assert R == ref["num_rendered"]                     # num_rendered keeps the reference's meaning
     np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
     assert not R.truncated
+    rects = C_.export_rects(P, geom).cpu().numpy()
+    vis = ref["radii"] > 0
+    rects[~vis] = 0
+    if C_.tight_rects():
+        bad, left = orc.culled_tile_violations(ref["state"], rects)
+        assert bad == 0, f"{bad} pixels of tiles left out of the lists would have been blended by the reference"
+        assert R.pairs == ref["num_rendered"] - left
+        tight = orc.with_rects(ref, rects)
+        np.testing.assert_array_equal(tight["color"], ref["color"])
+        np.testing.assert_array_equal(tight["state"]["final_T"], ref["state"]["final_T"])
+        st = tight["state"]
+        tiles_want = st["tiles_binned"]
+    else:
+        st = ref["state"]
+        tiles_want = st["tiles_touched"]
     ex = C_.export_binning(P, R, H, W, geom, binning, img)
-    np.testing.assert_array_equal(ex["tiles_touched"].cpu().numpy().astype(np.uint32), st["tiles_touched"])
+    np.testing.assert_array_equal(ex["tiles_touched"].cpu().numpy().astype(np.uint32), tiles_want)
     np.testing.assert_array_equal(ex["keys"].cpu().numpy().view(np.uint64), st["keys"])
     np.testing.assert_array_equal(ex["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
     np.testing.assert_array_equal(ex["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
@@ -173,6 +192,45 @@ def test_oracle_parity_larger(C_, kw):
     gr = orc.backward(ref["state"], dl, kw["lam"])
     bout = hip_backward(C_, fargs, fout, dl, kw["lam"])
     check_backward(bout, gr, ref["state"], 16)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=10_000, W=400, H=400, f=300.0, cam_seed=None, gseed=0, degree_mode="all0", scale_mu=0.012, lam=0.0),
+    dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02, lam=0.1),
+    dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3", scale_mu=0.012, lam=0.0),
+], ids=["cfg0_10k", "20k_mixed", "metric_500k_1600x1062"])
+def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
+    """set_tight_rects(False): every Gaussian is binned into the reference's whole 3-sigma square, and tiles_touched, the
+    sorted 64-bit keys, the point list, the tile ranges and n_contrib are the reference's (oracle's) bit for bit.  The
+    default (opacity-aware rects) must return the SAME image, radii and num_rendered bit for bit and the same gradients
+    (up to the rounding of one fp32 sum): the tiles it leaves out hold no pixel that takes part in anything."""
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw["scale_mu"])
+    bg = np.array([0.1, 0.4, 0.9], np.float32)
+    dl = ss.upstream_grad(W, H, seed=2) * (W * H)
+    ref = oracle_forward(bg, g, cam, H, W)
+    gr = orc.backward(ref["state"], dl, kw["lam"])
+    was = C_.set_tight_rects(False)
+    try:
+        fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
+        assert fout[0].pairs == int(fout[0]) == ref["num_rendered"]
+        check_forward(C_, fout, ref, H, W, P)
+        bout = hip_backward(C_, fargs, fout, dl, kw["lam"])
+        check_backward(bout, gr, ref["state"], 16)
+        _, fout_r = hip_forward(C_, bg, g, cam, H, W)          # reserved path, same mode
+        assert fout_r[0].pairs == fout[0].pairs and torch.equal(fout_r[1], fout[1])
+    finally:
+        C_.set_tight_rects(was)
+    assert C_.tight_rects()
+    fargs_t, fout_t = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    assert fout_t[0].pairs < fout[0].pairs and int(fout_t[0]) == int(fout[0])
+    assert torch.equal(fout_t[1], fout[1]) and torch.equal(fout_t[2], fout[2])
+    bout_t = hip_backward(C_, fargs_t, fout_t, dl, kw["lam"])
+    # the per-pair gradient rows are the same numbers; a Gaussian's rows sit at other slots of the slab, so the tree of
+    # its segmented sum associates them differently: equal up to fp32 rounding of that sum, not bit for bit
+    for a, b in zip(bout, bout_t):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30
 
 
 @pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])
@@ -367,7 +425,8 @@ def test_full_size_properties(C_, metric_scene):
     R, color, radii, geom, binning, img = fout
     ex = C_.export_binning(P, R, H, W, geom, binning, img)
     keys = ex["keys"]
-    assert R == int(ex["tiles_touched"].to(torch.int64).sum())                      # checksum of checksums
+    R = R.pairs   # the lists: <= num_rendered (tiles a Gaussian cannot reach are left out)
+    assert R <= int(fout[0]) and R == int(ex["tiles_touched"].to(torch.int64).sum())   # checksum of checksums
     assert bool((keys[1:] >= keys[:-1]).all())                                      # sortedness (tile, depth)
     rng_ = ex["ranges"].to(torch.int64)
     assert int((rng_[:, 1] - rng_[:, 0]).sum()) == R                                # ranges partition the list
@@ -378,7 +437,7 @@ def test_full_size_properties(C_, metric_scene):
     same = keys[1:] == keys[:-1]
     pl = ex["point_list"].to(torch.int64)
     assert bool((pl[1:][same] > pl[:-1][same]).all())
-    assert bool(((radii > 0) == (ex["tiles_touched"] > 0)).all())
+    assert bool(((radii > 0) | (ex["tiles_touched"] == 0)).all())   # only visible Gaussians are binned
     # every Gaussian occupies exactly the tiles of one rectangle, once each, tiles_touched of them (rasterizer_impl.cu:
     # 106-117), checked from the sorted list alone
     gx = (W + 15) // 16
@@ -392,13 +451,13 @@ def test_full_size_properties(C_, metric_scene):
     y0, y1 = per_gaussian(ty, "amin", big), per_gaussian(ty, "amax", -1)
     count = torch.bincount(pl, minlength=P)
     seen = count > 0
-    assert bool((seen == (radii > 0)).all())
+    assert bool((seen == (ex["tiles_touched"] > 0)).all())
     assert bool((count == ex["tiles_touched"].to(torch.int64)).all())
     assert bool((((x1 - x0 + 1) * (y1 - y0 + 1))[seen] == count[seen]).all())
     assert int(torch.unique(keys >> 32 << 32 | pl).numel()) == R                   # no (tile, Gaussian) pair twice
     # idempotence / determinism of the forward
     _, fout2 = hip_forward(C_, black, g, cam, H, W)
-    assert fout2[0] == R and torch.equal(fout2[1], color) and torch.equal(fout2[2], radii)
+    assert fout2[0] == int(fout[0]) and fout2[0].pairs == R and torch.equal(fout2[1], color) and torch.equal(fout2[2], radii)
     # background linearity: out(bg) = C + T*bg  =>  out(white) - out(black) = final_T on every channel
     _, foutw = hip_forward(C_, white, g, cam, H, W)
     T = ex["final_T"].reshape(1, H, W)
@@ -567,7 +626,7 @@ def test_reserved_graph_path_equals_exact_path(C_):
             R2 = fout2[0]
             if R2.ticket:
                 taken += 1
-                assert R2.capacity > int(R2) and not R2.truncated
+                assert R2.capacity > R2.pairs and not R2.truncated
             assert R2 == int(fout[0])
             assert torch.equal(fout2[1], fout[1]) and torch.equal(fout2[2], fout[2])
             ex2 = C_.export_binning(P, R2, H, W, fout2[3], fout2[4], fout2[5])
@@ -590,12 +649,12 @@ def test_truncated_pass_drops_the_farthest_pairs_and_is_flagged(C_):
     bg = np.array([0.3, 0.2, 0.1], np.float32)
     dl = ss.upstream_grad(W, H, seed=7) * (W * H)
     fargs, fex = hip_forward(C_, bg, g, cam, H, W, exact=True)
-    R = int(fex[0])
+    R = fex[0].pairs
     events0 = C_.reserve_overflow_events()
     reserve = R // 2
     out = C_._forward_common(None, *fargs, _reserve=reserve, _strict_override=False)   # strict mode would redo it
     nr = out[0]
-    assert nr.capacity == reserve and int(nr) == R and nr.truncated
+    assert nr.capacity == reserve and nr.pairs == R and int(nr) == int(fex[0]) and nr.truncated
     assert torch.equal(out[2], fex[2])                                   # radii come from the geometry stage
     assert bool(torch.isfinite(out[1]).all())
     ex = C_.export_binning(P, nr, H, W, out[3], out[4], out[5])           # exports min(R, capacity) entries
@@ -606,7 +665,7 @@ def test_truncated_pass_drops_the_farthest_pairs_and_is_flagged(C_):
     depth = torch.from_numpy(oracle_forward(bg, g, cam, H, W)["state"]["depths"]).cuda()
     kept = torch.zeros(P, dtype=torch.bool, device="cuda")
     kept[pl] = True
-    vis = fex[2] > 0
+    vis = C_.export_binning(P, fex[0], H, W, fex[3], fex[4], fex[5])["tiles_touched"] > 0   # Gaussians that own pairs
     assert float(depth[kept].max()) <= float(depth[vis & ~kept].min())   # what was dropped lies behind what was kept
     bout = C_.rasterize_gaussians_backward(fargs[0], fargs[1], out[2], fargs[2], fargs[4], fargs[5], fargs[6], fargs[7],
                                            fargs[8], fargs[9], fargs[10], fargs[11], dev(dl), fargs[14], fargs[15],

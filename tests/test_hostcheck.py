@@ -173,3 +173,51 @@ def test_region_pretest_is_conservative_fuzz():
     assert bad == 0
     assert skip.value > 0.3 * n            # the fuzz distribution exercises the skip path
     assert keep_empty.value < 0.02 * n     # exact minimisation: almost no false keeps
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=4000, W=200, H=136, f=150.0, cam_seed=3, gseed=5, scale_mu=0.05, op_mu=0.0, gain=0.85),
+    dict(P=3000, W=160, H=120, f=120.0, cam_seed=None, gseed=6, scale_mu=0.15, op_mu=-3.0, gain=0.7),   # faint, large splats
+    dict(P=3000, W=176, H=96, f=130.0, cam_seed=8, gseed=7, scale_mu=0.02, op_mu=4.0, gain=0.95),        # opaque, small splats
+], ids=["mid", "faint_large", "opaque_small"])
+def test_opacity_aware_rects_change_no_pixel_decision(kw):
+    """The product bins a Gaussian into the part of the reference's 3-sigma square that it can reach with alpha >= 1/255
+    (gauss_math.h tighten_rect, run here on the CPU).  Claim: the shorter lists give the reference's results.  Checked
+    with the oracle alone: (1) every rect lies inside the reference's, (2) no pixel of a left-out tile passes the
+    reference's per-pixel test (exhaustive), (3) the oracle's blend over the shorter lists returns the image and final T
+    of the full lists BIT FOR BIT and the same gradients, (4) the lists really are shorter."""
+    L = _lib()
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode="mixed", scale_mu=kw["scale_mu"], scale_sigma=0.8)
+    g["opacity"] = (g["opacity"] + kw["op_mu"]).astype(np.float32)
+    # a few extreme aspect ratios and opacities right at the 1/255 threshold
+    g["scales"][:50, 0] *= 30.0
+    g["opacity"][50:80] = np.float32(np.log((1 / 255.0) / (1 - 1 / 255.0)))
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    fwd = lambda rects=None: orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
+                                         cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W,
+                                         g["sh"], g["degrees"], cam.camera_center, rects=rects)
+    ref = fwd()
+    radii = np.zeros(P, np.int32)
+    rects = np.zeros((P, 4), np.uint16)
+    tiles = np.zeros(P, np.uint32)
+    tiles_ref = np.zeros(P, np.uint32)
+    view, proj, campos = (np.ascontiguousarray(a, np.float32) for a in
+                          (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+    L.hc_tight_rects(C.c_int(P), p(g["means3D"]), p(g["scales"]), C.c_float(1.0), p(g["rotations"]),
+                     p(np.ascontiguousarray(g["opacity"].reshape(-1))), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
+                     C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(radii), p(rects), p(tiles), p(tiles_ref))
+    np.testing.assert_array_equal(radii, ref["radii"])                      # the radii output is the reference's
+    np.testing.assert_array_equal(tiles_ref, ref["state"]["tiles_touched"])  # and so is what num_rendered counts
+    bad, left = orc.culled_tile_violations(ref["state"], rects)
+    assert bad == 0, f"{bad} pixels of left-out tiles would have been blended by the reference"
+    tight = fwd(rects)
+    assert tight["state"]["pairs"] == int(tiles[radii > 0].sum()) == ref["num_rendered"] - left
+    assert tight["state"]["pairs"] < kw["gain"] * ref["num_rendered"], "the rects are not tighter than the reference's"
+    np.testing.assert_array_equal(tight["color"], ref["color"])
+    np.testing.assert_array_equal(tight["state"]["final_T"], ref["state"]["final_T"])
+    dl = ss.upstream_grad(W, H, seed=3) * (W * H)
+    ga, gb = orc.backward(ref["state"], dl, 0.05), orc.backward(tight["state"], dl, 0.05)
+    for k in ga:
+        np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)

@@ -28,11 +28,14 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, DPP_ADD, CNDMASK, FMA_EXP_MIX, MAD_U32, NUM_KINDS };
+enum Kind { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, DPP_ADD, CNDMASK, FMA_EXP_MIX, MAD_U32, CNDMASK_VCC_SET, CNDMASK_SGPR, CMP_CNDMASK, MINF, FMAC, FMA_SGPR, MOV, LDS_B128_BCAST, LDS_B32_BCAST, BPERMUTE, READLANE, NUM_KINDS };
 static const char* kNames[NUM_KINDS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_fma_f32 (2 lanes-ops/lane)",
                                         "v_pk_mul_f32 (2 lanes-ops/lane)", "v_exp_f32", "v_rcp_f32",
                                         "v_add_f32_dpp row_ror:4", "v_cndmask_b32", "7 x v_fma_f32 + 1 x v_exp_f32",
-                                        "v_mad_u32_u24"};
+                                        "v_mad_u32_u24", "v_cndmask_b32 vcc (vcc set to 0x5555..)", "v_cndmask_b32_e64 sgpr pair",
+                                        "v_cmp_gt_f32 + v_cndmask_b32 (per pair)", "v_min_f32", "v_fmac_f32 (2 vgpr srcs + acc)",
+                                        "v_fma_f32 with one SGPR source", "v_mov_b32", "ds_read_b128 same address (per read)",
+                                        "ds_read_b32 same address (per read)", "ds_bpermute_b32", "v_readlane_b32"};
 
 #define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 
@@ -42,6 +45,15 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
     v2f ps = {s, s};
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f q0, q1, q2, q3;
+    __shared__ float lds[64];
+    lds[threadIdx.x] = a0;
+    __syncthreads();
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // every lane: the same address
+    const unsigned perm_addr = ((threadIdx.x + 17u) & 63u) * 4u;
+    const unsigned long long mask = 0x5555555555555555ull;
+    int sacc = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -89,7 +101,58 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
                 asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_exp_f32 %3, %3\n"
                              "v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
-            else if (KIND == MAD_U32)
+            else if (KIND == CNDMASK_VCC_SET)
+                asm volatile("s_mov_b64 vcc, %9\n s_nop 4\n"
+                             "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "s"(mask) : "vcc");
+            else if (KIND == CNDMASK_SGPR)
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                             "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "s"(mask));
+            else if (KIND == CMP_CNDMASK)
+                asm volatile("v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cmp_gt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                             "v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_cmp_gt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cmp_gt_f32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cmp_gt_f32 vcc, %5, %8\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                             "v_cmp_gt_f32 vcc, %6, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_cmp_gt_f32 vcc, %7, %8\n v_cndmask_b32 %7, %7, %8, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "vcc");
+            else if (KIND == MINF)
+                asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n"
+                             "v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
+            else if (KIND == FMAC)
+                asm volatile("v_fmac_f32 %0, %1, %8\n v_fmac_f32 %1, %2, %8\n v_fmac_f32 %2, %3, %8\n v_fmac_f32 %3, %4, %8\n"
+                             "v_fmac_f32 %4, %5, %8\n v_fmac_f32 %5, %6, %8\n v_fmac_f32 %6, %7, %8\n v_fmac_f32 %7, %0, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
+            else if (KIND == FMA_SGPR)
+                asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n"
+                             "v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(s));
+            else if (KIND == MOV)
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                             "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if (KIND == LDS_B128_BCAST) {
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(lds_addr) : "memory");
+                a0 += q0.x + q1.y + q2.z + q3.w;
+            } else if (KIND == LDS_B32_BCAST) {
+                asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:4\n ds_read_b32 %2, %8 offset:8\n ds_read_b32 %3, %8 offset:12\n"
+                             "ds_read_b32 %4, %8 offset:16\n ds_read_b32 %5, %8 offset:20\n ds_read_b32 %6, %8 offset:24\n ds_read_b32 %7, %8 offset:28\n"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(lds_addr) : "memory");
+            } else if (KIND == BPERMUTE) {
+                asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                             "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(perm_addr) : "memory");
+            } else if (KIND == READLANE) {
+                int r0, r1, r2, r3;
+                asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %5, 7\n v_readlane_b32 %2, %6, 11\n v_readlane_b32 %3, %7, 19"
+                             : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                sacc += r0 + r1 + r2 + r3;
+            } else if (KIND == MAD_U32)
                 asm volatile("v_mad_u32_u24 %0, %0, %8, %0\n v_mad_u32_u24 %1, %1, %8, %1\n v_mad_u32_u24 %2, %2, %8, %2\n v_mad_u32_u24 %3, %3, %8, %3\n"
                              "v_mad_u32_u24 %4, %4, %8, %4\n v_mad_u32_u24 %5, %5, %8, %5\n v_mad_u32_u24 %6, %6, %8, %6\n v_mad_u32_u24 %7, %7, %8, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
@@ -98,7 +161,7 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
     const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
-    if (r == 123.456f) sink[0] = r;   // never true: keeps the chains alive
+    if (r == 123.456f || sacc == 12345) sink[0] = r;   // never true: keeps the chains alive
 }
 
 template <int KIND>
@@ -127,7 +190,8 @@ static void run(int waves_per_simd, int iters, unsigned long long* d_cyc, float*
             mean_cyc = sum / blocks;
         }
     }
-    const double insts = (double)iters * 64.0;
+    const double per_trip = KIND == CMP_CNDMASK ? 64.0 : KIND == LDS_B128_BCAST ? 32.0 : KIND == READLANE ? 32.0 : 64.0;   // CMP_CNDMASK: 64 pairs
+    const double insts = (double)iters * per_trip;
     // s_memtime ticks: MI355X_MICROARCH.md says one tick = one shader cycle; the wall-clock columns do not depend on it
     const double per_wave = mean_cyc / insts;
     const double per_simd = mean_cyc / (insts * waves_per_simd);
@@ -169,5 +233,16 @@ int main(int argc, char** argv)
     sweep<CNDMASK>(iters, d_cyc, d_sink, e0, e1);
     sweep<FMA_EXP_MIX>(iters, d_cyc, d_sink, e0, e1);
     sweep<MAD_U32>(iters, d_cyc, d_sink, e0, e1);
+    sweep<CNDMASK_VCC_SET>(iters, d_cyc, d_sink, e0, e1);
+    sweep<CNDMASK_SGPR>(iters, d_cyc, d_sink, e0, e1);
+    sweep<CMP_CNDMASK>(iters, d_cyc, d_sink, e0, e1);
+    sweep<MINF>(iters, d_cyc, d_sink, e0, e1);
+    sweep<FMAC>(iters, d_cyc, d_sink, e0, e1);
+    sweep<FMA_SGPR>(iters, d_cyc, d_sink, e0, e1);
+    sweep<MOV>(iters, d_cyc, d_sink, e0, e1);
+    sweep<LDS_B128_BCAST>(iters, d_cyc, d_sink, e0, e1);
+    sweep<LDS_B32_BCAST>(iters, d_cyc, d_sink, e0, e1);
+    sweep<BPERMUTE>(iters, d_cyc, d_sink, e0, e1);
+    sweep<READLANE>(iters, d_cyc, d_sink, e0, e1);
     return 0;
 }
