@@ -69,6 +69,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
     PreOut o;
     o.radius = 0;
     o.tiles = 0;
+    o.tiles_ref = 0;
+    o.depth = 0.f;
     if (valid) {
         const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
         float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6];
