@@ -219,7 +219,11 @@ def main():
 
     born_in_buffer = [None]
     pending = [None]     # exchange of the previous step still in flight
-    overlap = [os.environ.get("R3DGS_BENCH_NO_OVERLAP") != "1"]
+    # N > 1: the timed region (-> `value`) runs the SERIALISED exchange: step k's sums are complete before step k+1
+    # starts, i.e. "all-reduce before the optimizer / prune step" as BASELINE.json words it.  The overlapped form (step
+    # k's buffer travels while step k+1 renders; its sums would be applied one step late) is measured afterwards and
+    # reported as `value_overlapped`.
+    overlap = [False]
 
     def cam_index(step):
         return (step * world + rank) % len(cams)
@@ -333,12 +337,11 @@ def main():
     torch.cuda.synchronize()
     prof = _C.profile_read()
     _C.profile_enable(False)
-    # N > 1: the exchange alone (events around a synchronous exchange) and the same steps with the exchange
-    # serialised behind the backward, to see how much of it the overlap hides
-    exchange_ms = sync_ms_per_step = None
+    # N > 1: the exchange alone (events around a synchronous exchange), whether every replica ended up with the same
+    # bits, and the same K steps in the overlapped (one-step-late) form
+    exchange_ms = overlapped_ms_per_step = replicas_identical = None
     if exch is not None:
         n_x = min(args.steps, 10)
-        overlap[0] = False
         xa, xb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         torch.cuda.synchronize()
@@ -348,14 +351,34 @@ def main():
         xb.record()
         torch.cuda.synchronize()
         exchange_ms = xa.elapsed_time(xb) / n_x
+        # one more serialised step, then compare a checksum of the exchanged buffer (sums, statistics, radii) across ranks:
+        # the combine runs in rank order on every rank, so the replicas must agree bit for bit
+        train_step(args.warmup)
+        torch.cuda.synchronize()
+        bits = exch.flat[:exch.total].view(torch.int32).to(torch.int64)
+        mine = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=device) % 8191 + 1)).sum()])
+        if os.environ.get("R3DGS_BENCH_BACKEND", "nccl") != "nccl":
+            mine = mine.cpu()   # gloo gathers host tensors
+        allsums = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allsums, mine)
+        replicas_identical = all(bool(torch.equal(allsums[0], t)) for t in allsums)
+        assert replicas_identical, "view-parallel exchange: the ranks' summed gradients differ"
+        overlap[0] = True
+        for i in range(3):
+            train_step(i)
+        drain()
         barrier()
+        torch.cuda.synchronize()
         ts0 = time.perf_counter()
-        for i in range(n_x):
+        for i in range(args.steps):
             train_step(args.warmup + i)
+        drain()
         torch.cuda.synchronize()
         barrier()
-        sync_ms_per_step = 1e3 * (time.perf_counter() - ts0) / n_x
-        overlap[0] = os.environ.get("R3DGS_BENCH_NO_OVERLAP") != "1"
+        t_o = torch.tensor([time.perf_counter() - ts0], dtype=torch.float64, device=device)
+        dist.all_reduce(t_o, op=dist.ReduceOp.MAX)
+        overlapped_ms_per_step = 1e3 * float(t_o.item()) / args.steps
+        overlap[0] = False
     if prof_timed.get(dom_stage, (0, 0))[1]:
         prof[dom_stage] = prof_timed[dom_stage]  # the roofline kernel's time is the one from the timed region
     if world > 1:
@@ -424,8 +447,11 @@ def main():
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                    "exchange": ("all-to-all + local SUM/MAX combine + all-gather of one flat buffer (59 fp32 grads + 2 "
-                                "stats + radii per Gaussian), own stream, double-buffered: overlapped with the next "
-                                "step's render") if world > 1 else None,
+                                "stats + radii per Gaussian) after every step's backward, complete before the next step "
+                                "starts (value / value_serialised); value_overlapped: the same exchange on its own "
+                                "stream, double-buffered, travelling while the next step renders (sums one step late)")
+                   if world > 1 else None,
+                   "replicas_bit_identical": replicas_identical,
                    "grads_born_in_exchange_buffer": born_in_buffer[0],
                    "clock_warmup_steps": CLOCK_WARMUP_STEPS,
                    "issue": "one hipGraph launch per forward, direct launches for the (event-timed) backward; "
@@ -435,11 +461,14 @@ def main():
                    "reserve_overflows_in_run": overflow1 - overflow0,
                    "passes_in_timed_region": {k: stats1[k] - stats0[k] for k in
                                               ("reserved_passes", "exact_passes", "redone_passes")}},
+        "value_serialised": round(iters_per_s, 2) if world > 1 else None,
+        "value_overlapped": round(args.steps * world / (overlapped_ms_per_step * 1e-3 * args.steps), 2)
+        if overlapped_ms_per_step else None,
         "exchange_ms": round(exchange_ms, 4) if exchange_ms is not None else None,
         "exchange_bytes_per_rank": (exch.flat.numel() * 4) if exch is not None else None,
-        "step_ms_exchange_serialised": round(sync_ms_per_step, 4) if sync_ms_per_step is not None else None,
-        "overlap_frac": (round(max(0.0, min(1.0, (sync_ms_per_step - 1e3 * elapsed / args.steps) / exchange_ms)), 3)
-                         if exchange_ms else None),
+        "step_ms_exchange_overlapped": round(overlapped_ms_per_step, 4) if overlapped_ms_per_step is not None else None,
+        "overlap_frac": (round(max(0.0, min(1.0, (1e3 * elapsed / args.steps - overlapped_ms_per_step) / exchange_ms)), 3)
+                         if exchange_ms and overlapped_ms_per_step else None),
         "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
         "render_fps": round(args.steps / render_s, 1),
         "roofline": roofline,

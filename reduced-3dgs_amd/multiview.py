@@ -40,11 +40,20 @@ class ViewParallelExchange:
         {"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)}."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.P = P
         self.device = torch.device(device)
+        self.shapes = {k: tuple(v) for k, v in shapes.items()}
+        self.nbuf = max(1, int(buffers))
+        self.two_phase = two_phase and self.world > 1
+        self.on_gpu = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self._pending = [None] * self.nbuf
+        self._layout(P)
+
+    def _layout(self, P):
+        self.P = P
         self.slices = {}
         off = 0
-        for name, shp in shapes.items():
+        for name, shp in self.shapes.items():
             n = 1
             for s in shp:
                 n *= s
@@ -56,16 +65,22 @@ class ViewParallelExchange:
         pad = (-total) % max(self.world, 1)
         self.total = total
         self.shard = (total + pad) // max(self.world, 1)
-        self.nbuf = max(1, int(buffers))
-        self.flats = [torch.zeros(total + pad, dtype=torch.float32, device=device) for _ in range(self.nbuf)]
+        self.flats = [torch.zeros(total + pad, dtype=torch.float32, device=self.device) for _ in range(self.nbuf)]
         self.cur = 0
-        self.two_phase = two_phase and self.world > 1
-        self.on_gpu = self.device.type == "cuda"
-        if self.two_phase:   # receive / combine scratch, allocated once
-            self.recv = torch.empty(self.world * self.shard, dtype=torch.float32, device=device)
-            self.mine = torch.empty(self.shard, dtype=torch.float32, device=device)
-        self.comm_stream = torch.cuda.Stream(device=device) if self.on_gpu else None
-        self._pending = [None] * self.nbuf
+        if self.two_phase:   # receive / combine scratch, allocated once per layout
+            self.recv = torch.empty(self.world * self.shard, dtype=torch.float32, device=self.device)
+            self.mine = torch.empty(self.shard, dtype=torch.float32, device=self.device)
+
+    def resize(self, P):
+        """The Gaussian count changed (densification / pruning, train.py:132-147): every exchange in flight is waited
+        for, then the buffers are laid out again for P Gaussians.  All ranks must call it with the same P (they do:
+        densify and prune decisions are deterministic functions of the exchanged statistics)."""
+        for k in range(self.nbuf):
+            self.wait(k)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if P != self.P:
+            self._layout(P)
 
     # ---- views of the current buffer -------------------------------------------------------------------------------
     @property

@@ -12,10 +12,11 @@ Bars (BASELINE.json north_star), exactly as asserted below:
     0.02-0.05 %), image checks run on the others, and `mask_ambiguous` removes them from the upstream gradient of BOTH
     sides of a gradient comparison (a flipped decision changes gradients at O(1), not at rounding level);
   * rendered RGB and final T: <= 1e-5 abs on the non-ambiguous pixels;
-  * gradients (check_backward): every tensor max |err| <= 1e-4 * max |ref| (GRAD_REL; 3e-4 for the three tensors that
-    come out of the cancellation-heavy covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- whose fp32
-    evaluation amplifies the rounding of the per-Gaussian sums; the reference's own float atomics leave the same
-    noise), AND per element |err| <= 1e-4 * |ref| + 1e-6 * max |ref| on >= 99.9 % of the elements.
+  * gradients (check_backward): every tensor max |err| <= 1e-4 * max |ref| (GRAD_REL; 1.5e-4 allowed for the three
+    tensors that come out of the cancellation-heavy covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- whose
+    fp32 evaluation amplifies the rounding of the per-Gaussian sums, as the reference's own float atomics do; measured
+    worst case over every test of this module: 9.4e-5 for dL_drotations, <= 1.9e-5 for all others), AND per element
+    |err| <= 1e-4 * |ref| + 1e-6 * max |ref| on >= 99.9 % of the elements (measured: >= 99.997 %).
 """
 import os
 
@@ -121,7 +122,7 @@ def check_forward(C_, fout, ref, H, W, P):
     return ok
 
 
-GRAD_REL_COV_CHAIN = 3e-4   # dL_dcov3D / dL_dscales / dL_drotations (see the module docstring)
+GRAD_REL_COV_CHAIN = 1.5e-4   # dL_dcov3D / dL_dscales / dL_drotations (see the module docstring); measured worst: 9.4e-5
 ELEM_OK_FRACTION = 0.999
 achieved = {}               # name -> largest (max-normalised error, fraction of elements outside the per-element bar) seen
 

@@ -105,6 +105,80 @@ def test_exchange_async_double_buffered():
     _run(two_phase=True, arena=True, use_async=True)
 
 
+# ---- world size 4, Gaussian count not divisible by 4 and changing between steps ---------------------------------------
+def _rank_inputs_p(rank, Pn, step):
+    g = torch.Generator().manual_seed(1000 * step + 10 * Pn + rank)
+    grads = {k: torch.randn((Pn,) + s, generator=g) for k, s in SHAPES.items()}
+    vgrad = torch.randn(Pn, 3, generator=g)
+    radii = torch.randint(0, 40, (Pn,), generator=g, dtype=torch.int32)
+    radii[torch.rand(Pn, generator=g) < 0.3] = 0
+    return grads, vgrad, radii
+
+
+W4_SIZES = [257, 301, 301, 94]   # densify, (same), prune: none divisible by 4
+
+
+def _w4_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reduced-3dgs_amd"))
+    from multiview import ViewParallelExchange
+    ex = ViewParallelExchange(SHAPES, W4_SIZES[0], torch.device("cpu"), two_phase=True)
+    res = []
+    for step, Pn in enumerate(W4_SIZES):
+        ex.resize(Pn)                       # what a trainer calls after densify_and_prune
+        assert ex.P == Pn and ex.flat.numel() % world == 0
+        grads, vgrad, radii = _rank_inputs_p(rank, Pn, step)
+        born = {}
+        for k, v in grads.items():          # gradients born in the (possibly re-allocated) buffer
+            t = ex.arena(k, tuple(v.shape))
+            assert t is not None
+            t.copy_(v)
+            born[k] = t
+        ex.pack(born, vgrad, radii)
+        k = ex.exchange_async()
+        ex.wait(k)
+        out, gnorm, vis, rmax = ex.unpack(k)
+        res.append(({n: v.clone().numpy() for n, v in out.items()}, gnorm.clone().numpy(), vis.clone().numpy(),
+                    rmax.clone().numpy()))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_exchange_with_changing_gaussian_count():
+    """Four ranks, P not divisible by the world size (the flat buffer is padded to a multiple of it), P changing between
+    steps as densification / pruning does (buffers re-laid out by resize()): every rank ends every step with the SUM of
+    the gradients / statistics and the MAX of the radii, and all four replicas hold the same bits."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_w4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step, Pn in enumerate(W4_SIZES):
+        ins = [_rank_inputs_p(r, Pn, step) for r in range(world)]
+        for rank in range(world):
+            out, gnorm, vis, rmax = results[rank][step]
+            for k in SHAPES:
+                np.testing.assert_allclose(out[k], sum(i[0][k] for i in ins).numpy(), rtol=1e-6, atol=1e-5)
+                np.testing.assert_array_equal(out[k], results[0][step][0][k])      # replicas bit-identical
+            exp_norm = sum((torch.norm(i[1][:, :2], dim=-1) * (i[2] > 0)) for i in ins).numpy()
+            np.testing.assert_allclose(gnorm, exp_norm, rtol=1e-6, atol=1e-5)
+            np.testing.assert_array_equal(vis, sum((i[2] > 0).float() for i in ins).numpy())
+            want = ins[0][2]
+            for i in ins[1:]:
+                want = torch.maximum(want, i[2])
+            np.testing.assert_array_equal(rmax, want.numpy())
+
+
 # ---- camera-sharded statistics (SURVEY.md 8e tier 2) ------------------------------------------------------------------
 def _cv_partial(cams):
     """numpy model of the per-camera recurrence of calculate_colours_variance (reduced_3dgs.cu:154-198, with the
