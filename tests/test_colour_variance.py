@@ -100,10 +100,32 @@ def test_gpu_matches_oracle():
     assert d.shape == ref_d.shape and v.shape == ref_v.shape and m.shape == ref_m.shape
     np.testing.assert_array_equal(np.isnan(d), np.isnan(ref_d))
     np.testing.assert_array_equal(np.isnan(v), np.isnan(ref_v))
-    # weights are mean transmittances over blended pixels: a threshold-ambiguous pixel moves one by ~1/touched
+    # The weights are mean transmittances over the pixels a Gaussian was blended into, so ONE threshold-ambiguous pixel
+    # (a blend decision the oracle took within 1e-5 of its threshold, which another exp may take the other way) moves a
+    # weight by ~1/touched.  Gaussians that can see such a pixel in any camera (pixel within their radius) are compared
+    # loosely, all others -- the bulk -- to 1e-5.
+    P = a["means3D"].shape[0]
+    near_ambiguous = np.zeros(P, bool)
+    for i in range(len(a["cam_positions"])):
+        H, W = int(a["image_height"][i]), int(a["image_width"][i])
+        o = orc.forward(np.zeros(3, np.float32), a["means3D"], None, a["opacity"], a["scales"], a["rotations"], 1.0, None,
+                        a["cam_viewmatrices"][i], a["cam_projmatrices"][i], float(a["tan_fovxs"][i]),
+                        float(a["tan_fovys"][i]), H, W, a["sh"], a["degrees"], a["cam_positions"][i], want_ambig=True,
+                        ambig_rel=1e-5)
+        ys, xs = np.nonzero(o["ambig"])
+        xy, rad = o["state"]["xy"], o["radii"].astype(np.float32)
+        for x, y in zip(xs, ys):
+            near_ambiguous |= (rad > 0) & (np.abs(xy[:, 0] - x) <= rad + 1) & (np.abs(xy[:, 1] - y) <= rad + 1)
+    seen = ~np.isnan(ref_d[:, 0])
+    clean = seen & ~near_ambiguous
+    assert clean.sum() >= 0.8 * seen.sum(), (clean.sum(), seen.sum())
+    np.testing.assert_allclose(d[clean], ref_d[clean], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v[clean], ref_v[clean], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m[clean], ref_m[clean], rtol=1e-5, atol=1e-6)
+    print(f"\ncolour variance: {clean.sum()} of {seen.sum()} seen Gaussians away from ambiguous pixels, max rel err there: "
+          f"d {np.abs(d[clean] - ref_d[clean]).max():.2e} v {np.abs(v[clean] - ref_v[clean]).max():.2e} "
+          f"m {np.abs(m[clean] - ref_m[clean]).max():.2e}")
+    # the others: bounded by one pixel's worth
     np.testing.assert_allclose(d, ref_d, rtol=2e-3, atol=2e-4, equal_nan=True)
     np.testing.assert_allclose(v, ref_v, rtol=5e-3, atol=1e-5, equal_nan=True)
     np.testing.assert_allclose(m, ref_m, rtol=2e-3, atol=2e-4)
-    # and the bulk agrees far tighter
-    ok = ~np.isnan(ref_d[:, 0])
-    assert np.median(np.abs(d[ok] - ref_d[ok])) < 1e-6
