@@ -211,6 +211,7 @@ __device__ __forceinline__ unsigned long long fwd_batches(unsigned long long any
         int j[N];
         QSplat sp[N];
         float al[N][PPL];
+        bool inb[N][PPL];
 #pragma unroll
         for (int i = 0; i < N; i++) {
             j[i] = __builtin_ctzll(anymask);
@@ -220,14 +221,14 @@ __device__ __forceinline__ unsigned long long fwd_batches(unsigned long long any
 #pragma unroll
         for (int i = 0; i < N; i++)
 #pragma unroll
-            for (int q = 0; q < PPL; q++) al[i][q] = fwd_alpha(sp[i], pxf[q], pyf[q]);
+            for (int q = 0; q < PPL; q++) al[i][q] = fwd_alpha(sp[i], pxf[q], pyf[q], &inb[i][q]);
 #pragma unroll
         for (int i = 0; i < N; i++)
 #pragma unroll
             for (int q = 0; q < PPL; q++)
                 if (PPL == 1 || ((qmask[q] >> j[i]) & 1ull)) {   // one quadrant per wave: anymask IS its mask
                     float Tb;
-                    fwd_apply(sp[i], al[i][q], first_pos + (uint32_t)j[i] + 1u, pix[q], &Tb);
+                    fwd_apply(sp[i], al[i][q], inb[i][q], first_pos + (uint32_t)j[i] + 1u, pix[q], &Tb);
                 }
     }
     return anymask;

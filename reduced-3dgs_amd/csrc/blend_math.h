@@ -123,20 +123,22 @@ R3_HD void fwd_pix_init(FwdPix& p, bool inside)
 R3_HD bool fwd_pix_live(const FwdPix& p) { return p.T > 0.0f; }
 R3_HD float fwd_pix_T(const FwdPix& p) { return fabsf(p.T); }
 
-// alpha of one list entry at one pixel (forward.cu:534-546); 0 where the reference skips on power > 0
-R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf)
+// alpha of one list entry at one pixel (forward.cu:534-546) and whether the reference's first skip (power > 0, which
+// only a conic that is not positive definite can trigger) leaves it in.  The two skips (power > 0, alpha < 1/255) stay
+// ONE divergence point: two compares whose lane masks are AND-ed on the scalar unit (a compare + select + compare costs
+// one more half-rate VALU instruction: v_cmp and v_cndmask issue at half the rate of an FMA, profiles/r03_valu_rate.txt).
+R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf, bool* in_bound)
 {
     const float p2 = log2_falloff(s, s.x - pxf, s.y - pyf);
-    // the reference's two skips (power > 0, alpha < 1/255) as ONE divergence point: a select instead of a branch
-    // for the first (it can only fire for a degenerate conic), then a single test in fwd_apply
-    return p2 > 0.0f ? 0.0f : fminf(0.99f, s.op * R3_EXP2(p2));
+    *in_bound = p2 <= 0.0f;
+    return fminf(0.99f, s.op * R3_EXP2(p2));
 }
 
 // Blends an entry of opacity-weighted falloff `alpha` into pixel `p`.  Returns 0: skipped, 1: blended, 2: pixel
 // saturated (done).  `pos1` = 1-based position of the entry in the tile list.  *T_before = transmittance it saw.
-R3_HD int fwd_apply(const QSplat& s, float alpha, uint32_t pos1, FwdPix& p, float* T_before)
+R3_HD int fwd_apply(const QSplat& s, float alpha, bool in_bound, uint32_t pos1, FwdPix& p, float* T_before)
 {
-    if (alpha < 1.0f / 255.0f) return 0;
+    if (!(in_bound && alpha >= 1.0f / 255.0f)) return 0;
     const float w = alpha * p.T;
     const float test_T = p.T - w;             // T * (1 - alpha), forward.cu:547
     const bool sat = test_T < 0.0001f;        // also true for a pixel that is already done (T < 0)
@@ -155,7 +157,9 @@ R3_HD int fwd_apply(const QSplat& s, float alpha, uint32_t pos1, FwdPix& p, floa
 // One list entry against one pixel (forward.cu:528-570).
 R3_HD int fwd_step(const QSplat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)
 {
-    return fwd_apply(s, fwd_alpha(s, pxf, pyf), pos1, p, T_before);
+    bool in_bound;
+    const float alpha = fwd_alpha(s, pxf, pyf, &in_bound);
+    return fwd_apply(s, alpha, in_bound, pos1, p, T_before);
 }
 
 R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& p, float* T_before)

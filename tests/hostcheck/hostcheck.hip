@@ -149,6 +149,53 @@ void hc_blend_fwd(int W, int H, const unsigned* ranges, const unsigned* point_li
         }
 }
 
+// Statistics of the (list entry, 8x8 quadrant) pairs of a forward pass (design aid): out[0] = all pairs, out[1] = pairs the
+// region pre-test keeps, out[2] = kept pairs in which at least one pixel really blends the entry (alpha >= 1/255 and the
+// pixel not saturated), out[3] = pairs with a blending pixel (must equal out[2]: the pre-test is conservative),
+// out[4] = (entry, tile) pairs with any blending pixel, out[5] = all (entry, tile) pairs, out[6] = kept pairs the forward
+// kernel evaluates (until every pixel of the quadrant is saturated), out[7] = kept pairs the backward kernel evaluates
+// (in front of the quadrant's deepest contributor).
+void hc_pair_stats(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
+                   const float* conic_op, long* out)
+{
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
+            const unsigned r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            FwdPix pix[256];
+            for (int i = 0; i < 256; i++) fwd_pix_init(pix[i], tx * 16 + (i & 15) < W && ty * 16 + (i >> 4) < H);
+            long kept_before[4] = {0, 0, 0, 0}, kept_at_last[4] = {0, 0, 0, 0};
+            for (unsigned k = r0; k < r1; k++) {
+                const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
+                bool tile_hit = false;
+                for (int q = 0; q < 4; q++) {
+                    const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+                    const bool keep = region_may_contribute(s, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+                    bool hit = false, live = false;
+                    for (int j = 0; j < 64; j++) live |= fwd_pix_live(pix[((q >> 1) * 8 + (j >> 3)) * 16 + (q & 1) * 8 + (j & 7)]);
+                    if (keep && live) out[6]++;
+                    kept_before[q] += keep;
+                    for (int j = 0; j < 64; j++) {
+                        const int lx = (q & 1) * 8 + (j & 7), ly = (q >> 1) * 8 + (j >> 3);
+                        float Tb;
+                        if (fwd_step(s, (float)(tx * 16 + lx), (float)(ty * 16 + ly), k - r0 + 1, pix[ly * 16 + lx], &Tb) == 1) hit = true;
+                    }
+                    out[0]++;
+                    out[1] += keep;
+                    out[2] += keep && hit;
+                    out[3] += hit;
+                    tile_hit |= hit;
+                    if (hit) kept_at_last[q] = kept_before[q];
+                }
+                out[4] += tile_hit;
+                out[5]++;
+            }
+            for (int q = 0; q < 4; q++) out[7] += kept_at_last[q];
+        }
+}
+
 // acc: double[P][9] = mx, my, cA, cB, cC, op, r, g, b  (mx,my already scaled by 0.5W / 0.5H)
 void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
                   const float* xy, const float* conic_op, const float* rgb, const float* final_T,
