@@ -106,9 +106,12 @@ R3_HD float log2_falloff(const QSplat& s, float dx, float dy)
 }
 
 struct FwdPix {
-    float T;        // transmittance; its SIGN is the reference's `done` flag (forward.cu:548-552): once the pixel is
-                    // saturated -- or if it lies outside the image -- T is kept negated, and T * (1 - alpha) < 0.0001
-                    // then rejects every later entry without a separate test
+    float T;        // running product of (1 - alpha) over every entry that passed the alpha test.  The reference stops a
+                    // pixel at the first entry with T (1 - alpha) < 0.0001 (forward.cu:547-552, `done`); the product only
+                    // falls, so "T has dropped below 0.0001" IS that flag: the running product is simply carried on, every
+                    // later entry fails the same test by itself, and nothing has to be selected per entry (v_cndmask
+                    // issues at half the rate of an FMA).  A pixel outside the image starts at -1: never blended.
+    float Tf;       // T after the last BLENDED entry: the reference's final T
     float C0, C1, C2;
     uint32_t last;  // 1-based list position of the last blended entry (n_contrib)
 };
@@ -116,12 +119,13 @@ struct FwdPix {
 R3_HD void fwd_pix_init(FwdPix& p, bool inside)
 {
     p.T = inside ? 1.0f : -1.0f;
+    p.Tf = 1.0f;
     p.C0 = p.C1 = p.C2 = 0.f;
     p.last = 0;
 }
 
-R3_HD bool fwd_pix_live(const FwdPix& p) { return p.T > 0.0f; }
-R3_HD float fwd_pix_T(const FwdPix& p) { return fabsf(p.T); }
+R3_HD bool fwd_pix_live(const FwdPix& p) { return p.T >= 0.0001f; }
+R3_HD float fwd_pix_T(const FwdPix& p) { return p.Tf; }
 
 // alpha of one list entry at one pixel (forward.cu:534-546) and whether the reference's first skip (power > 0, which
 // only a conic that is not positive definite can trigger) leaves it in.  The two skips (power > 0, alpha < 1/255) stay
@@ -140,18 +144,16 @@ R3_HD int fwd_apply(const QSplat& s, float alpha, bool in_bound, uint32_t pos1, 
 {
     if (!(in_bound && alpha >= 1.0f / 255.0f)) return 0;
     const float w = alpha * p.T;
-    const float test_T = p.T - w;             // T * (1 - alpha), forward.cu:547
-    const bool sat = test_T < 0.0001f;        // also true for a pixel that is already done (T < 0)
-    // the saturation case as three selects instead of a nested branch (0.156 -> 0.151 ms: the forward's entry loop is as
-    // sensitive to scalar and branch instructions as to vector ones)
-    const float we = sat ? 0.f : w;
-    p.C0 += s.r * we;
-    p.C1 += s.g * we;
-    p.C2 += s.b * we;
+    const float Tn = p.T - w;                 // T * (1 - alpha), forward.cu:547
     *T_before = p.T;
-    p.T = sat ? -fabsf(p.T) : test_T;
-    p.last = sat ? p.last : pos1;
-    return sat ? 2 : 1;
+    p.T = Tn;
+    if (!(Tn >= 0.0001f)) return 2;           // saturated here, earlier, or outside the image: not blended
+    p.C0 += s.r * w;
+    p.C1 += s.g * w;
+    p.C2 += s.b * w;
+    p.Tf = Tn;
+    p.last = pos1;
+    return 1;
 }
 
 // One list entry against one pixel (forward.cu:528-570).
