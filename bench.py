@@ -34,7 +34,8 @@ import torch.distributed as dist  # noqa: E402
 import synth_scene as ss  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+VALU_RATE = os.path.join("profiles", "r03_valu_rate.txt")
 
 
 CLOCK_WARMUP_STEPS = 50   # untimed, ahead of the --warmup steps (see main())
@@ -92,23 +93,38 @@ def pmc_traffic(stage, workload, path=None):
     return int(total)
 
 
+# Cycles one SIMD needs per wave64 VALU instruction with >= 5 waves resident, measured on this chip with tools/valu_rate.hip
+# (profiles/r03_valu_rate.txt, wall-clock column at 2.4 GHz): add / mul / mov 2.4, fma / fmac 2.8, v_exp / v_rcp 8.2,
+# compares, selects, min/max, DPP, integer mad and anything with an SGPR operand 4.2.  rocprofv3 splits SQ_INSTS_VALU into
+# these classes (ADD_F32 also counts the DPP adds of the backward's reduction, so the floor below is a LOWER bound).
+VALU_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.8,
+               "SQ_INSTS_VALU_TRANS_F32": 8.2, "SQ_INSTS_VALU_INT32": 4.2, "SQ_INSTS_VALU_CVT": 4.2, "other": 4.2}
+
+
 def pmc_valu(stage, workload, kernel_ms, path=None, simds=1024, ghz=2.4):
-    """VALU-issue view of the stage's first (main) kernel from the same committed PMC passes: the two blend kernels
-    are bound by the VALU issue rate, which an HBM fraction cannot express.  SQ_ACTIVE_INST_VALU
-    counts quad-cycles; busy_ms = the VALU-busy time per SIMD those instructions imply at `ghz`."""
+    """VALU-issue view of the stage's first (main) kernel from the committed PMC passes: the two blend kernels are bound
+    by VALU issue, which an HBM fraction cannot express.  floor_ms = the time 1024 SIMDs need to
+    issue the kernel's VALU instructions at the per-class rates measured by tools/valu_rate.hip; frac = floor / measured."""
     path = path or os.path.join(ROOT, PMC_SUMMARY)
     if workload != "metric_500k_1600x1062" or stage not in STAGE_KERNELS or not os.path.exists(path):
         return None
     k = STAGE_KERNELS[stage][0][0]
     c = json.load(open(path)).get(k, {})
-    if "SQ_INSTS_VALU" not in c or "SQ_ACTIVE_INST_VALU" not in c:
+    if "SQ_INSTS_VALU" not in c:
         return None
-    busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4.0 / simds / (ghz * 1e9) * 1e3
-    return {"kernel": k, "valu_insts": int(c["SQ_INSTS_VALU"]),
-            "cycles_per_inst": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2),
-            "valu_busy_ms_per_simd": round(busy_ms, 4), "stage_ms": round(kernel_ms, 4),
-            "frac_of_stage_time": round(busy_ms / kernel_ms, 3) if kernel_ms else None,
-            "assumes": f"{simds} SIMDs at {ghz} GHz", "source": PMC_SUMMARY}
+    classes = {n: c.get(n, 0.0) for n in VALU_CYCLES if n != "other"}
+    other = max(0.0, c["SQ_INSTS_VALU"] - sum(classes.values()))
+    cycles = sum(VALU_CYCLES[n] * v for n, v in classes.items()) + VALU_CYCLES["other"] * other
+    floor_ms = cycles / simds / (ghz * 1e9) * 1e3
+    out = {"kernel": k, "insts": int(c["SQ_INSTS_VALU"]),
+           "insts_by_class": {n.replace("SQ_INSTS_VALU_", "").lower(): int(v) for n, v in classes.items()} | {"other": int(other)},
+           "cycles_per_class": {n.replace("SQ_INSTS_VALU_", "").lower(): v for n, v in VALU_CYCLES.items()},
+           "floor_ms": round(floor_ms, 4), "kernel_ms": round(kernel_ms, 4),
+           "frac": round(floor_ms / kernel_ms, 3) if kernel_ms else None,
+           "assumes": f"{simds} SIMDs at {ghz} GHz", "source": f"{PMC_SUMMARY}, {VALU_RATE}"}
+    if "SQ_ACTIVE_INST_VALU" in c:   # what the SQ itself reports per instruction (quad-cycles, per wave: >= 4)
+        out["sq_active_cycles_per_inst"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2)
+    return out
 
 
 def cgroup_cpu():
@@ -261,13 +277,14 @@ def main():
 
     # num_rendered per camera (property of the input; every per-pair byte term scales with it); these passes also
     # teach the library the pair reservation of this view size
-    Rs, Vs = [], []
+    Rs, Vs, Ps = [], [], []
     with torch.no_grad():
         for s_ in settings:
             out = _C.rasterize_gaussians(s_.bg, leaves["means3D"], empty, leaves["opacity"], leaves["scales"],
                                          leaves["rotations"], 1.0, empty, s_.viewmatrix, s_.projmatrix, s_.tanfovx,
                                          s_.tanfovy, H, W, leaves["sh"], degrees, s_.campos, False, False)
-            Rs.append(int(out[0]))
+            Rs.append(int(out[0]))          # the reference's num_rendered: what the byte formulas of SURVEY 8d are written in
+            Ps.append(out[0].pairs)         # pairs this library bins (opacity-aware rects leave unreachable tiles out)
             Vs.append(int((out[2] > 0).sum()))
 
     def barrier():
@@ -401,6 +418,7 @@ def main():
     used = [cam_index(args.warmup + i) for i in range(args.steps)]
     R_mean = float(np.mean([Rs[k] for k in used]))
     V_mean = float(np.mean([Vs[k] for k in used]))
+    pairs_mean = float(np.mean([Ps[k] for k in used]))
     sb = stage_bytes(P, R_mean, N, Tn, Kbar)
     stages = {}
     for name, (ms, cnt) in prof.items():
@@ -419,7 +437,7 @@ def main():
                     "traffic_source": (PMC_SUMMARY + " (committed rocprofv3 --pmc passes of this command; not "
                                        "collected in this run)") if traffic is not None else None,
                     "duration_source": "HIP events around the stage on its stream, inside the timed region",
-                    "valu_issue": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
+                    "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
     iters_per_s = args.steps * world / elapsed
     B_iter = P * (718 + 36 * Kbar) + R_mean * 280 + N * 40
     gpu_ms = sum(v["avg_ms"] for v in stages.values())
@@ -445,6 +463,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "gaussians": P, "width": W, "height": H, "sh_degree": 3,
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
+                   "pairs_binned_mean": round(pairs_mean), "tight_rects": _C.tight_rects(),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                    "exchange": ("all-to-all + local SUM/MAX combine + all-gather of one flat buffer (59 fp32 grads + 2 "
                                 "stats + radii per Gaussian) after every step's backward, complete before the next step "
