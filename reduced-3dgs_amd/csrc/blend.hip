@@ -53,6 +53,22 @@ __device__ __forceinline__ R3_GLOBAL T* global_ptr(T* p)
 
 constexpr int kChunk = 64;
 
+#if defined(R3_TIMELINE)   // debug builds only (tools/bwd_timeline.py): when and where every backward workgroup ran
+__device__ unsigned long long g_timeline[4 * 65536];
+#define R3_TL_BEGIN(id) const unsigned long long tl0_ = __builtin_amdgcn_s_memtime(); const uint32_t tlid_ = (id);
+#define R3_TL_END(extra)                                                                                                 \
+    if (threadIdx.x == 0 && tlid_ < 65536u) {                                                                            \
+        g_timeline[4 * tlid_] = tl0_;                                                                                     \
+        g_timeline[4 * tlid_ + 1] = __builtin_amdgcn_s_memtime();                                                         \
+        g_timeline[4 * tlid_ + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |     \
+                                    ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+        g_timeline[4 * tlid_ + 3] = (unsigned long long)(extra);                                                          \
+    }
+#else
+#define R3_TL_BEGIN(id)
+#define R3_TL_END(extra)
+#endif
+
 struct LdsRec {  // 48 B: a staged list entry, conic pre-scaled (QSplat); c.yzw = GRec's rect_min, width_clamp, pair_start
     float4 a;    // x, y, qa, qb
     float4 b;    // qc, op, r, g
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdP
     // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from
     // the kernarg segment
     if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, 64);
+    R3_TL_BEGIN(blockIdx.x)
     const BlendBwdArgs a = v.blend;
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
@@ -456,7 +473,10 @@ __global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdP
     }
     for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, off));
     lmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)lmax);
-    if (lmax == 0) return;
+    if (lmax == 0) {
+        R3_TL_END(0)
+        return;
+    }
 
     const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
     float4 nxa, nxb, nxc;
@@ -572,7 +592,15 @@ __global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdP
             a.pair_flag[slot] = 1;
         }
     }
+    R3_TL_END(lmax)
 }
+
+#if defined(R3_TIMELINE)
+extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);
+}
+#endif
 
 void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
 {
