@@ -177,8 +177,12 @@ R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& 
 // which is the same arithmetic up to association (5 fewer registers per pixel, ~10 fewer VALU per step).
 struct BwdPix {
     float T;           // transmittance in front of the current entry (recovered by division)
-    float tb;          // -T_final * (bg . g): background term numerator (backward.cu:569-572)
-    float A, cgp, la;  // see above; la = last_alpha
+    float A, cgp, la;  // see above; la = last_alpha.  A starts at bg . g instead of 0: the background is what lies behind
+                       // the last contributor, and with it inside the recurrence (c . g - A) T already contains the
+                       // reference's separate term -T_final / (1 - alpha) * (bg . g) (backward.cu:569-572):
+                       // A_k = sum_{j behind k} alpha_j c_j.g prod_{k<i<j} (1 - alpha_i) + bg.g prod_{i behind k} (1 - alpha_i)
+                       // and T_k prod_{i behind k} (1 - alpha_i) = T_final / (1 - alpha_k).  One register per pixel and
+                       // one FMA per (pixel, entry) less.
     float g0, g1, g2;  // dL_dpixel
     uint32_t last;     // n_contrib
 };
@@ -186,8 +190,8 @@ struct BwdPix {
 R3_HD void bwd_pix_init(BwdPix& p, float T_final, uint32_t last, float g0, float g1, float g2, float bg_dot)
 {
     p.T = T_final;
-    p.tb = -T_final * bg_dot;
-    p.A = p.cgp = p.la = 0.f;
+    p.A = bg_dot;
+    p.cgp = p.la = 0.f;
     p.g0 = g0;
     p.g1 = g1;
     p.g2 = g2;
@@ -259,7 +263,7 @@ R3_HD void bwd_accumulate(const QSplat& s, const BwdEval& e, BwdPix& p, SplatSum
     const float cg = s.r * p.g0 + s.g * p.g1 + s.b * p.g2;
     p.cgp = cg;
     p.la = e.alpha;
-    const float dL_dalpha = (cg - p.A) * p.T + p.tb * ra;
+    const float dL_dalpha = (cg - p.A) * p.T;
     const float m = e.G * dL_dalpha;
     a.sm += m;
     const float mdx = m * e.dx, mdy = m * e.dy;
