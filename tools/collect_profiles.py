@@ -1,4 +1,4 @@
-"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r02_* and regenerates profiles/README.md."""
+"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r03_* and regenerates profiles/README.md."""
 import os
 import shutil
 import subprocess
@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-R = "r02"
+R = "r03"
 
 
 def last_line(src, dst, mode="w"):
@@ -16,11 +16,18 @@ def last_line(src, dst, mode="w"):
 
 last_line("bench.log", f"{R}_bench_n1_steps20.json")
 last_line("bench_default.log", f"{R}_bench_n1_default.json")
+last_line("bench_nonstrict.log", f"{R}_bench_n1_ab.jsonl")
+last_line("bench_refrects.log", f"{R}_bench_n1_ab.jsonl", "a")
 last_line("bench_burner64_a.log", f"{R}_bench_n1_cpu_burner64.jsonl")
 last_line("bench_burner64_b.log", f"{R}_bench_n1_cpu_burner64.jsonl", "a")
 shutil.copy(os.path.join(G, "prof", "r_kernel_stats.csv"), os.path.join(P, f"{R}_kernel_stats_bench_500k_1600x1062.csv"))
 shutil.copy(os.path.join(G, "pmc_summary.json"), os.path.join(P, f"{R}_pmc_summary.json"))
+shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate.txt"))
 shutil.copy(os.path.join(G, "other_workloads.jsonl"), os.path.join(P, f"{R}_other_workloads.jsonl"))
+if os.path.exists(os.path.join(G, "bwd_timeline.txt")):
+    shutil.copy(os.path.join(G, "bwd_timeline.txt"), os.path.join(P, f"{R}_bwd_timeline.txt"))
+open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-40:]) +
+                                                       "\n" + open(os.path.join(G, "smoke.log")).read()[-1200:])
 for wl, short in (("garden_like_2M_1600x1062", "garden_like_2M"), ("train_like_6M_1920x1080", "train_like_6M")):
     shutil.copy(os.path.join(G, f"prof_{wl}", "r_kernel_stats.csv"), os.path.join(P, f"{R}_kernel_stats_{short}.csv"))
 sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "profiles_readme.py")]))

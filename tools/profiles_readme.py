@@ -1,29 +1,47 @@
-"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r02_*).
+"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r03_*).
 
     python tools/profiles_readme.py
 
-Numbers in that README are therefore exactly the ones in the JSON / CSV files next to it."""
+Numbers in that README are therefore exactly the ones in the JSON / CSV / txt files next to it."""
 import csv
 import json
 import os
+import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
+R = "r03"
 
 
 def jl(name):
     return [json.loads(l) for l in open(os.path.join(P, name)) if l.strip()]
 
 
-d20 = jl("r02_bench_n1_steps20.json")[0]
-d50 = jl("r02_bench_n1_default.json")[0]
-burn = jl("r02_bench_n1_cpu_burner64.jsonl")
-others = jl("r02_other_workloads.jsonl")
-ks = {}
-for r in csv.DictReader(open(os.path.join(P, "r02_kernel_stats_bench_500k_1600x1062.csv"))):
-    name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-    ks[name.split("(")[0]] = float(r["AverageNs"]) / 1e3
-pmc = json.load(open(os.path.join(P, "r02_pmc_summary.json")))
+def kstats(name):
+    ks = {}
+    for r in csv.DictReader(open(os.path.join(P, name))):
+        n = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        ks[n.split("(")[0]] = float(r["AverageNs"]) / 1e3
+    return ks
+
+
+d20 = jl(f"{R}_bench_n1_steps20.json")[0]
+d50 = jl(f"{R}_bench_n1_default.json")[0]
+ab = jl(f"{R}_bench_n1_ab.jsonl")
+burn = jl(f"{R}_bench_n1_cpu_burner64.jsonl")
+others = jl(f"{R}_other_workloads.jsonl")
+old_others = {o["config"]["workload"]: o for o in jl("r02_other_workloads.jsonl")}
+ks = kstats(f"{R}_kernel_stats_bench_500k_1600x1062.csv")
+ks2 = kstats("r02_kernel_stats_bench_500k_1600x1062.csv")
+pmc = json.load(open(os.path.join(P, f"{R}_pmc_summary.json")))
+st = d50["stages"]
+BWD, FWD = "r3::blend_bwd_kernel<4, true>", "r3::blend_fwd_kernel<1, false>"
+
+import bench  # noqa: E402  (the calibrated VALU floor is computed by bench.py's own function)
+vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", ks[BWD] / 1e3)
+vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", ks[FWD] / 1e3)
 
 
 def row(k):
@@ -35,122 +53,134 @@ def row(k):
             f"{v['FETCH_SIZE'] / 1024:.0f} MiB | {v['WRITE_SIZE'] / 1024:.0f} MiB |")
 
 
-st = d50["stages"]
+def stages_of(d):
+    s = d["stages"]
+    return " / ".join(str(s[k]["avg_ms"]) for k in ("preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd", "blend_bwd",
+                                                     "preprocess_bwd"))
 
 
-def _burn_text():
-    hit = [b for b in burn if b["host"]["cgroup"]["throttled_periods_in_timed_region"] > 0]
-    vals = ", ".join(f"**{b['value']} it/s**" for b in burn)
-    t = (f"`r02_bench_n1_cpu_burner64.jsonl`, two consecutive runs: {vals} (idle box, same visit: {d20['value']} it/s); host time per "
-         f"step {burn[0]['host']['host_ms_per_step_min_med_max'][1]} / {burn[1]['host']['host_ms_per_step_min_med_max'][1]} ms median with 60 CPUs busy next to it, "
-         f"slowest step {max(b['host']['host_ms_per_step_min_med_max'][2] for b in burn)} ms.  ")
-    if hit:
-        t += (f"A CFS freeze fell into the timed region of {len(hit)} of them (`throttled_periods_in_timed_region` > 0): the GPU ran dry "
-              "while the host was frozen mid-enqueue.  ")
-    else:
-        t += ("No freeze fell into either 20 ms timed region (`throttled_periods_in_timed_region` 0): bench.py starts its timed region "
-              "at a period rollover when the container has been throttled since start-up "
-              "(`host.cgroup.timed_region_started_at_period_rollover`), which leaves ~25 ms of runway.  An earlier visit of this round "
-              "without that measure saw 233 it/s in the runs a freeze hit.  ")
-    t += "Round 1 measured 190 it/s in every such run because each forward waited for the host."
-    return t
+valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if " 5 waves/SIMD" in l]
 
 
-burn_text = _burn_text()
-burn_ok = max(burn, key=lambda b: b["value"])
-burn_hit = min(burn, key=lambda b: b["value"])
-new = f'''# profiles/ — measurements on MI355X (round 2)
+def rate(prefix):
+    for l in valu_lines:
+        if l.startswith(prefix):
+            return float(re.search(r"([\d.]+) cyc/inst/SIMD@2.4GHz", l).group(1))
+    return float("nan")
 
-All files come from ONE visit of `tools/refresh_profiles.sh` (which drives `tools/gpu_round.sh` / `tools/other_workloads.sh`; `tools/collect_profiles.py` copies the results here) to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch
-2.10+rocm7.0; 256 visible CPUs, **cgroup CPU quota 16**); the command profiled is always `python bench.py` (workload
-`metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe; V̄ = 384k visible, R̄ = 3.64 M
-(tile, Gaussian) pairs, N = 1.70 Mpix).  These are this build's own visits; **the number of record is the driver's
-`BENCH_r02.json`**.  Round-1 files (`r01_*`) are kept for comparison.  This file is generated from the data files by
-`tools/profiles_readme.py`.
+
+timeline = ""
+tl_path = os.path.join(P, f"{R}_bwd_timeline.txt")
+if os.path.exists(tl_path):
+    timeline = "".join(l for l in open(tl_path) if not l.startswith("/opt"))
+
+new = f'''# profiles/ — measurements on MI355X (round 3)
+
+All `r03_*` files come from ONE visit of `tools/refresh_profiles.sh` (`tools/collect_profiles.py` copies the results here
+and runs `tools/profiles_readme.py`, which generates this file from them) to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch
+2.10+rocm7.0; 256 visible CPUs, **cgroup CPU quota 16**).  The command profiled is always `python bench.py` (workload
+`metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe, 8 cameras; V̄ =
+{d50['config']['visible_mean'] / 1e3:.0f}k visible, `num_rendered` R̄ = {d50['config']['num_rendered_mean'] / 1e6:.2f} M — the reference's count, which the byte
+formulas are written in — of which {d50['config']['pairs_binned_mean'] / 1e6:.2f} M (tile, Gaussian) pairs are binned (opacity-aware rects), N = 1.70 Mpix).
+These are this build's own visits; **the number of record is the driver's `BENCH_r03.json`**.  `r01_*` / `r02_*` files are
+kept for comparison.
 
 | file | what |
 |---|---|
-| `r02_bench_n1_default.json` | the JSON line of `python bench.py` (50 steps, 10 warm-up) |
-| `r02_bench_n1_steps20.json` | `python bench.py --steps 20 --warmup 5` (the driver's form) |
-| `r02_bench_n1_cpu_burner64.jsonl` | the same twice while `tools/cpu_burn.py 64` exhausts the container's CPU quota (see below) |
-| `r02_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
-| `r02_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (SQ instruction counters; SQ activity / wait counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` |
-| `r02_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
-| `r02_kernel_stats_garden_like_2M.csv`, `r02_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads (`bench.py --workload … --steps 10 --warmup 3 --cameras 4`) |
-| `r02_launch_bench.txt` | `tools/launch_bench.hip`, `tools/launch_bench2.hip`: host cost of direct launches vs hipGraph replay, idle and under CPU load; safety of refreshing a replayed graph's argument block while the host runs ahead; kernel-written host-mapped flag latency; the box's `cpu.max` |
+| `{R}_bench_n1_default.json` | the JSON line of `python bench.py` (50 steps, 10 warm-up) |
+| `{R}_bench_n1_steps20.json` | `python bench.py --steps 20 --warmup 5` (the driver's form) |
+| `{R}_bench_n1_ab.jsonl` | the driver's form with `R3DGS_STRICT=0` (no check of the pass's pair count: the round-2 behaviour) and with `R3DGS_TIGHT_RECT=0` (the reference's 3σ squares) |
+| `{R}_bench_n1_cpu_burner64.jsonl` | the driver's form twice while `tools/cpu_burn.py 64` exhausts the container's CPU quota |
+| `{R}_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
+| `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` and `roofline.valu` |
+| `{R}_valu_rate.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` |
+| `{R}_bwd_timeline.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran |
+| `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
+| `{R}_kernel_stats_garden_like_2M.csv`, `{R}_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads |
+| `{R}_gpu_tests.txt` | tail of `pytest tests -m gpu -s` (achieved gradient errors, the own-loop report) and the smoke line of that visit |
 
 ## Headline (N = 1)
 
 | | value |
 |---|---|
-| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) |
-| the driver's form, 20 steps / 5 warm-up | **{d20['value']} it/s** ({d20['ms_per_step']} ms/step = {d20['host']['step_over_gpu_stage_sum']} × Σ stage ms) |
-| host time per step (Python + ctypes + one graph launch + the event-timed backward's direct launches) | {d20['host']['host_ms_per_step_min_med_max'][1]} ms median; all 20 steps enqueued in {d20['host']['enqueue_ms_total']} ms (round 1: 1.0 ms per step, one blocking spin per forward) |
+| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, **strict**: every forward checks its pair count before returning), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) |
+| the driver's form, 20 steps / 5 warm-up | **{d20['value']} it/s** ({d20['ms_per_step']} ms/step = {d20['host']['step_over_gpu_stage_sum']} × Σ stage ms); passes in the timed region: {d20['config']['passes_in_timed_region']} |
+| same, strict mode off (round-2 behaviour) | {ab[0]['value']} it/s — the check costs nothing measurable: the pass publishes its numbers ~40 µs after it starts and the GPU has the rest of the forward to work on while the host goes on |
+| same, reference rects (`R3DGS_TIGHT_RECT=0`) | {ab[1]['value']} it/s, stages {stages_of(ab[1])} ms against {stages_of(d20)} ms |
 | render-only (forward, `render.py`'s FPS path) | **{d50['render_fps']} FPS = {d50['render_mpix_per_s'] / 1000:.2f} Gpix/s** |
 | whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %) |
-| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} |
+| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), `roofline.valu.frac` {d50['roofline']['valu']['frac'] if d50['roofline'].get('valu') else 'n/a'} (calibrated VALU issue floor / stage time) |
 | CPU baseline (SURVEY 8d) | configs[0] PyTorch restatement, {d50['cpu_baseline']['threads_effective']} threads: {d50['cpu_baseline']['value']} it/s; the bench workload by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
-| BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are bound by VALU issue, not by memory: DESIGN.md §4 and the PMC view below) |
+| host under `tools/cpu_burn.py 64` | {burn[0]['value']} / {burn[1]['value']} it/s (throttled periods inside the timed region: {burn[0]['host']['cgroup']['throttled_periods_in_timed_region']} / {burn[1]['host']['cgroup']['throttled_periods_in_timed_region']}) |
+| BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are VALU-bound: see below) |
 
-### A loaded host (VERDICT r1 "within 10 % under `stress-ng --cpu 64`")
-
-`stress-ng` is not in the image; `tools/cpu_burn.py 64` is the stand-in. 64 busy processes exhaust the container's
-16-CPU quota, CFS then freezes the whole cgroup — this process included — for ~75 ms of every 100 ms period.
-{burn_text}
-
-## Where the {d50['ms_per_step']} ms go (HIP-event stage timers of `r02_bench_n1_default.json`; kernel times from rocprofv3)
+## Where the {d50['ms_per_step']} ms go (HIP-event stage timers; kernel times from rocprofv3, round 2 in brackets)
 
 | stage | avg ms | kernels (rocprofv3 avg µs) | algorithmic bytes (SURVEY 8d) | GB/s vs 8 TB/s |
 |---|---|---|---|---|
-| preprocess_fwd | {st['preprocess_fwd']['avg_ms']} | `preprocess_geom_kernel` {ks['r3::preprocess_geom_kernel']:.1f} (also installs the pass block) | {st['preprocess_fwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_fwd']['GBps']:.0f} ({st['preprocess_fwd']['GBps'] / 80:.0f} %) |
-| depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f} (histogram + header), `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB (SH read + scan term) | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
-| tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}, `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}, `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} ({st['tile_binning']['GBps'] / 80:.0f} %) — real traffic ≈ 6× lower |
-| blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks['r3::blend_fwd_kernel<1, false>']:.1f} | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
-| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true>` {ks['r3::blend_bwd_kernel<4, true>']:.1f} (also installs the pass block), `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
-| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel` {ks['r3::preprocess_bwd_kernel']:.1f} | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
-| (rest: torch `zeros_like + 0`, launch gaps) | ≈ {d50['ms_per_step'] - d50['host']['gpu_stage_ms_sum']:.2f} | | | |
+| preprocess_fwd | {st['preprocess_fwd']['avg_ms']} | `preprocess_geom_kernel` {ks['r3::preprocess_geom_kernel']:.1f} [{ks2['r3::preprocess_geom_kernel']:.1f}] (+ the opacity-aware rect) | {st['preprocess_fwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_fwd']['GBps']:.0f} ({st['preprocess_fwd']['GBps'] / 80:.0f} %) |
+| depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f}, `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
+| tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f} [{ks2['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}], `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f} [{ks2['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}], `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} — real traffic ≈ 9× lower |
+| blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks[FWD]:.1f} [{ks2[FWD]:.1f}] | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
+| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true>` {ks[BWD]:.1f} [{ks2[BWD]:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}] | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
+| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel` {ks['r3::preprocess_bwd_kernel']:.1f} [{ks2['r3::preprocess_bwd_kernel']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
 
-Round 1 → round 2 on the GPU side (same shape, rocprofv3 µs): `blend_bwd_kernel` 445 → {ks['r3::blend_bwd_kernel<4, true>']:.1f} (reduction with bank-masked DPP adds,
-moments instead of per-pixel gradient products, pre-scaled conic, the forward's quadrant masks reused), `blend_fwd_kernel` 193 →
-{ks['r3::blend_fwd_kernel<1, false>']:.1f} (one quadrant per wave, paired entries, pre-scaled conic, sign of T as the done flag), tile binning 138 →
-{st['tile_binning']['avg_ms'] * 1000:.0f} (ids in the pair words, LDS-staged scatter, 2048 pairs per workgroup), depth sort + colour 61 + 41 (overlapped on a side
-stream) → {st['depth_sort_scan']['avg_ms'] * 1000:.0f} in one linear chain, `pair_reduce` 46 → {ks['r3::pair_reduce_kernel']:.1f}, `preprocess_bwd` 84 → {ks['r3::preprocess_bwd_kernel']:.1f}.
+## What the VALU costs on this chip (`{R}_valu_rate.txt`) and what that says about the blend kernels
 
-## PMC view (per launch; `r02_pmc_summary.json`; FETCH_SIZE raw, before the ×2 correction for 16-B/lane loads)
+Cycles per wave64 instruction and SIMD at 5 waves per SIMD, from the wall-clock rate at 2.4 GHz: `v_add_f32` {rate('v_add_f32 ')},
+`v_mul_f32` {rate('v_mul_f32')}, `v_mov_b32` {rate('v_mov_b32')}, `v_fmac_f32` {rate('v_fmac_f32')}, `v_fma_f32` {rate('v_fma_f32  ')} — with one SGPR source
+{rate('v_fma_f32 with one SGPR')}; `v_min_f32` {rate('v_min_f32')}, `v_cmp + v_cndmask` {rate('v_cmp_gt_f32')} per pair, `v_cndmask_b32_e64` {rate('v_cndmask_b32_e64')},
+`v_add_f32_dpp` {rate('v_add_f32_dpp')}, `v_mad_u32_u24` {rate('v_mad_u32_u24')}; `v_exp_f32` {rate('v_exp_f32')}, `v_rcp_f32` {rate('v_rcp_f32')};
+`v_pk_fma_f32` {rate('v_pk_fma_f32')} and `v_pk_mul_f32` {rate('v_pk_mul_f32')} (for TWO lane-operations each: a gain only for FMAs);
+`ds_read_b128` of one address {rate('ds_read_b128')}, `ds_read_b32` {rate('ds_read_b32')}, `ds_bpermute_b32` {rate('ds_bpermute_b32')}, `v_readlane_b32` {rate('v_readlane_b32')}.
+A lone wave issues one dependent-free VALU instruction per ~5 cycles; two waves reach the rates above.
+
+With rocprofv3's per-class instruction counts (`{R}_pmc_summary.json`) these rates give an issue-time floor per kernel
+(`bench.py` `pmc_valu`, 1024 SIMDs at 2.4 GHz): `blend_fwd` {vf['insts'] / 1e6:.0f} M VALU instructions ({", ".join(f"{k} {v / 1e6:.1f} M" for k, v in vf['insts_by_class'].items())}) →
+**{vf['floor_ms']} ms of {vf['kernel_ms']} ms = {100 * vf['frac']:.0f} %**: the forward sits on its VALU floor.  `blend_bwd` {vb['insts'] / 1e6:.0f} M ({", ".join(f"{k} {v / 1e6:.1f} M" for k, v in vb['insts_by_class'].items())}; the ~28 M DPP adds of its
+reductions are counted as `add_f32` here although they cost 4.2 cycles, so the floor is a lower bound) → **{vb['floor_ms']} ms of {vb['kernel_ms']} ms =
+{100 * vb['frac']:.0f} %**; the SQ's own activity counter says {vb.get('sq_active_cycles_per_inst', float('nan'))} cycles per VALU instruction, i.e. the pipe busy
+{100 * pmc[BWD]['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e6 / ks[BWD]:.0f} % of the kernel's time.  Where the rest goes, from the timeline of its 6700 single-wave workgroups:
+
+```
+{timeline.strip()}
+```
+
+i.e. a workgroup lives ~0.15 ms of the kernel's ~0.34 ms; five fit per SIMD (95 VGPRs), 6.5 exist: for the first half of a
+CU's span 20–22 are resident, then the residency decays to 3 (utilisation below 3 waves per SIMD falls off because a lone
+wave issues one VALU instruction per ~5 cycles), and CUs that happened to receive 29 workgroups instead of 26 finish ~15 %
+after the median.  Tried against that in this round, all measured on this workload (DESIGN.md §6): two waves per tile
+(13 400 half-tile waves, 6–7 per SIMD, the halves' sums joined per chunk in LDS): 0.373–0.383 ms for the stage against 0.378–0.381;
+`v_permlane16/32_swap` instead of the two `ds_bpermute` of the reduction: +2 %; hand-packed `v_pk_*_f32` x/y and r/g arithmetic:
++4 % (forward) / +6 % (backward) — consistent with the rates above; no register prefetch / occupancy 6, 7, 8 by launch bounds:
+spills (27–75 VGPRs).
+
+## PMC view (per launch; FETCH_SIZE raw, before the ×2 correction for 16-B/lane loads)
 
 | kernel | VALU inst | SALU inst | LDS inst | active / wave-cycles | issue-stall (`WAIT_INST_ANY`) | parked (`WAIT_ANY`) | FETCH_SIZE | WRITE_SIZE |
 |---|---|---|---|---|---|---|---|---|
-{row('r3::blend_fwd_kernel<1, false>')}
-{row('r3::blend_bwd_kernel<4, true>')}
+{row(FWD)}
+{row(BWD)}
 {row('r3::pair_reduce_kernel')}
 {row('r3::preprocess_bwd_kernel')}
 {row('r3::depth_sort_color_kernel<2, false>')}
 {row('r3::emit_pairs_kernel<r3::IoNarrow>')}
 {row('r3::radix_scatter_kernel<r3::IoNarrow, 7>')}
 
-VALU issue of the blend kernels (the SQ activity counters count quad-cycles): `SQ_ACTIVE_INST_VALU` ÷ `SQ_INSTS_VALU` =
-{pmc['r3::blend_bwd_kernel<4, true>']['SQ_ACTIVE_INST_VALU'] * 4 / pmc['r3::blend_bwd_kernel<4, true>']['SQ_INSTS_VALU']:.2f} cycles per wave64 instruction in both; `blend_bwd`: {pmc['r3::blend_bwd_kernel<4, true>']['SQ_INSTS_VALU'] / 1e6:.0f} M instructions × that ÷ 1024 SIMDs ÷ 2.4 GHz =
-{pmc['r3::blend_bwd_kernel<4, true>']['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e3:.3f} ms of VALU-busy time per SIMD against {ks['r3::blend_bwd_kernel<4, true>'] / 1e3:.3f} ms measured ({100 * pmc['r3::blend_bwd_kernel<4, true>']['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e6 / ks['r3::blend_bwd_kernel<4, true>']:.0f} %); `blend_fwd`: {pmc['r3::blend_fwd_kernel<1, false>']['SQ_INSTS_VALU'] / 1e6:.0f} M →
-{pmc['r3::blend_fwd_kernel<1, false>']['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e3:.3f} ms against {ks['r3::blend_fwd_kernel<1, false>'] / 1e3:.3f} ms ({100 * pmc['r3::blend_fwd_kernel<1, false>']['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e6 / ks['r3::blend_fwd_kernel<1, false>']:.0f} %).  Round 1's backward issued 226 M VALU instructions for the same work.  The HBM
-traffic of both is a few percent of what 8 TB/s would move in that time: their roof is the VALU issue rate, `roofline.frac`
-(an HBM fraction by bench.py's contract) cannot say so.
+## Other workloads (`{R}_other_workloads.jsonl`, 20 steps, 4 cameras; round 2 in brackets)
 
-## Other workloads (`r02_other_workloads.jsonl`, 20 steps, 4 cameras)
-
-| workload | it/s | ms/step | R̄ | stage ms (pre / depth+colour / binning / blend fwd / blend bwd / pre bwd) | render FPS |
+| workload | it/s | ms/step | R̄ (reference) / pairs binned | stage ms (pre / depth+colour / binning / blend fwd / blend bwd / pre bwd) | render FPS |
 |---|---|---|---|---|---|
 '''
 for o in others:
-    s = o["stages"]
-    new += (f"| `{o['config']['workload']}` | {o['value']} | {o['ms_per_step']} | {o['config']['num_rendered_mean'] / 1e6:.2f} M | "
-            f"{s['preprocess_fwd']['avg_ms']} / {s['depth_sort_scan']['avg_ms']} / {s['tile_binning']['avg_ms']} / "
-            f"{s['blend_fwd']['avg_ms']} / {s['blend_bwd']['avg_ms']} / {s['preprocess_bwd']['avg_ms']} | {o['render_fps']} |\n")
+    wl = o["config"]["workload"]
+    prev = old_others.get(wl)
+    new += (f"| `{wl}` | {o['value']} [{prev['value'] if prev else '-'}] | {o['ms_per_step']} | {o['config']['num_rendered_mean'] / 1e6:.2f} M / "
+            f"{o['config'].get('pairs_binned_mean', 0) / 1e6:.2f} M | {stages_of(o)} | {o['render_fps']} [{prev['render_fps'] if prev else '-'}] |\n")
 new += '''
-Round 1 had `garden_like_2M` at 535 it/s through rocPRIM's pair sort (tile_binning 0.40 + depth_sort 0.27 ms).  Scenes
-above 2^19 Gaussians now sort a 16-bit tile key array + a 32-bit id array (6 bytes per pair and pass) through the same
-hand-written LSD passes; the VERDICT's 700 it/s bar for that shape is still **not** met.  What the stage called
-depth_sort_scan contains at these sizes is mostly the dense `[P,16,3]` SH read (192 B per Gaussian whatever its degree:
-0.38 GB at 2 M, 1.15 GB at 6 M), which round 1 hid on a side stream.
+The per-Gaussian stages dominate above 2 M Gaussians (6 M: geometry + depth sort + binning + per-Gaussian backward are two
+thirds of the step).  The VERDICT's bars for these shapes (2 M >= 750 it/s, 6 M >= 360 it/s) are **not** met; what they would
+need is listed in DESIGN.md section 11.
 '''
 open(os.path.join(P, "README.md"), "w").write(new)
 print("wrote profiles/README.md,", len(new.splitlines()), "lines")
