@@ -22,7 +22,9 @@ last_line("bench_burner64_a.log", f"{R}_bench_n1_cpu_burner64.jsonl")
 last_line("bench_burner64_b.log", f"{R}_bench_n1_cpu_burner64.jsonl", "a")
 shutil.copy(os.path.join(G, "prof", "r_kernel_stats.csv"), os.path.join(P, f"{R}_kernel_stats_bench_500k_1600x1062.csv"))
 shutil.copy(os.path.join(G, "pmc_summary.json"), os.path.join(P, f"{R}_pmc_summary.json"))
-shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate.txt"))
+# the refresh visit runs the rate loops after the benches, i.e. on a warm chip (lower clock): kept apart from the table of
+# the cold visit (profiles/r03_valu_rate.txt, GPU call of its own), whose rates bench.py's VALU_CYCLES are
+shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate_warm.txt"))
 shutil.copy(os.path.join(G, "other_workloads.jsonl"), os.path.join(P, f"{R}_other_workloads.jsonl"))
 if os.path.exists(os.path.join(G, "bwd_timeline.txt")):
     shutil.copy(os.path.join(G, "bwd_timeline.txt"), os.path.join(P, f"{R}_bwd_timeline.txt"))

@@ -93,7 +93,7 @@ kept for comparison.
 | `{R}_bench_n1_cpu_burner64.jsonl` | the driver's form twice while `tools/cpu_burn.py 64` exhausts the container's CPU quota |
 | `{R}_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
 | `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` and `roofline.valu` |
-| `{R}_valu_rate.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` |
+| `{R}_valu_rate.txt`, `{R}_valu_rate_warm.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` (the first from a visit that ran nothing else, the second at the end of the refresh visit, on a warm chip: the wall-clock rates are ~10 % lower there, the clock having come down) |
 | `{R}_bwd_timeline.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran |
 | `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
 | `{R}_kernel_stats_garden_like_2M.csv`, `{R}_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads |
