@@ -93,12 +93,13 @@ def pmc_traffic(stage, workload, path=None):
     return int(total)
 
 
-# Cycles one SIMD needs per wave64 VALU instruction with >= 5 waves resident, measured on this chip with tools/valu_rate.hip
-# (profiles/r03_valu_rate.txt, wall-clock column at 2.4 GHz): add / mul / mov 2.4, fma / fmac 2.8, v_exp / v_rcp 8.2,
-# compares, selects, min/max, DPP, integer mad and anything with an SGPR operand 4.2.  rocprofv3 splits SQ_INSTS_VALU into
-# these classes (ADD_F32 also counts the DPP adds of the backward's reduction, so the floor below is a LOWER bound).
-VALU_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.8,
-               "SQ_INSTS_VALU_TRANS_F32": 8.2, "SQ_INSTS_VALU_INT32": 4.2, "SQ_INSTS_VALU_CVT": 4.2, "other": 4.2}
+# Cycles one SIMD needs per wave64 VALU instruction, measured on this chip with tools/valu_rate.hip (profiles/r03_valu_rate.txt,
+# wall-clock column at 2.4 GHz, 8 waves per SIMD -- the best rate of each kind): add / mul / mov 2.4, fma 2.6 (fmac 2.8),
+# v_exp / v_rcp 8.1, compares, selects, min/max, DPP, integer mad and anything with an SGPR operand 4.1-4.3.  rocprofv3
+# splits SQ_INSTS_VALU into these classes (ADD_F32 also counts the DPP adds of the backward's reduction at the plain add's
+# rate), so the floor below is a LOWER bound.
+VALU_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.6,
+               "SQ_INSTS_VALU_TRANS_F32": 8.1, "SQ_INSTS_VALU_INT32": 4.1, "SQ_INSTS_VALU_CVT": 4.1, "other": 4.1}
 
 
 def pmc_valu(stage, workload, kernel_ms, path=None, simds=1024, ghz=2.4):

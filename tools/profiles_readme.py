@@ -59,7 +59,7 @@ def stages_of(d):
                                                      "preprocess_bwd"))
 
 
-valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if " 5 waves/SIMD" in l]
+valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if " 8 waves/SIMD" in l]
 
 
 def rate(prefix):
@@ -127,7 +127,7 @@ kept for comparison.
 
 ## What the VALU costs on this chip (`{R}_valu_rate.txt`) and what that says about the blend kernels
 
-Cycles per wave64 instruction and SIMD at 5 waves per SIMD, from the wall-clock rate at 2.4 GHz: `v_add_f32` {rate('v_add_f32 ')},
+Cycles per wave64 instruction and SIMD at 8 waves per SIMD, from the wall-clock rate at 2.4 GHz: `v_add_f32` {rate('v_add_f32 ')},
 `v_mul_f32` {rate('v_mul_f32')}, `v_mov_b32` {rate('v_mov_b32')}, `v_fmac_f32` {rate('v_fmac_f32')}, `v_fma_f32` {rate('v_fma_f32  ')} — with one SGPR source
 {rate('v_fma_f32 with one SGPR')}; `v_min_f32` {rate('v_min_f32')}, `v_cmp + v_cndmask` {rate('v_cmp_gt_f32')} per pair, `v_cndmask_b32_e64` {rate('v_cndmask_b32_e64')},
 `v_add_f32_dpp` {rate('v_add_f32_dpp')}, `v_mad_u32_u24` {rate('v_mad_u32_u24')}; `v_exp_f32` {rate('v_exp_f32')}, `v_rcp_f32` {rate('v_rcp_f32')};
