@@ -419,8 +419,11 @@ constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the 
 // REUSE: the region pre-test masks are the forward's (BinState::quad_masks) instead of being recomputed per chunk.
 // 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
 // (0.5174 vs 0.5170 ms), 3 / 4 likewise: the grid only has 6.5 waves per SIMD.
+#ifndef R3_BWD_OCC
+#define R3_BWD_OCC 5
+#endif
 template <int PPL, bool REUSE>
-__global__ __launch_bounds__(64, 5) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
+__global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
     // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from

@@ -171,18 +171,18 @@ R3_HD int fwd_step(const Splat& s, float pxf, float pyf, uint32_t pos1, FwdPix& 
 
 // per-pixel state of the back-to-front walk.  The reference keeps accum_rec[3] and last_color[3] per
 // pixel (backward.cu:487-494) and forms  dL_dalpha = sum_ch (c_ch - accum_rec_ch) * g_ch.  Both recurrences
-// are linear, so only their projections on the pixel's upstream gradient g are needed:
-//   A   = accum_rec . g      A   <- A + la * (cgp - A)
-//   cgp = last_color . g     cgp <- c . g
-// which is the same arithmetic up to association (5 fewer registers per pixel, ~10 fewer VALU per step).
+// are linear, so only their projection on the pixel's upstream gradient g is needed:
+//   A = accum_rec . g,      A <- A + alpha * (c . g - A)     after an entry (alpha, c) has been processed,
+// which is the reference's  accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec  evaluated when the entry
+// is left instead of when the next one is entered -- the same arithmetic up to association (the difference c . g - A is
+// needed for dL_dalpha anyway), 13 fewer registers per pixel than carrying accum_rec, last_color and last_alpha.
+// A starts at bg . g instead of 0: the background is what lies behind the last contributor, and with it inside the
+// recurrence (c . g - A) T already contains the reference's separate term -T_final / (1 - alpha) * (bg . g)
+// (backward.cu:569-572):  A_k = sum_{j behind k} alpha_j c_j.g prod_{k<i<j} (1 - alpha_i) + bg.g prod_{i behind k} (1 - alpha_i)
+// and T_k prod_{i behind k} (1 - alpha_i) = T_final / (1 - alpha_k).
 struct BwdPix {
     float T;           // transmittance in front of the current entry (recovered by division)
-    float A, cgp, la;  // see above; la = last_alpha.  A starts at bg . g instead of 0: the background is what lies behind
-                       // the last contributor, and with it inside the recurrence (c . g - A) T already contains the
-                       // reference's separate term -T_final / (1 - alpha) * (bg . g) (backward.cu:569-572):
-                       // A_k = sum_{j behind k} alpha_j c_j.g prod_{k<i<j} (1 - alpha_i) + bg.g prod_{i behind k} (1 - alpha_i)
-                       // and T_k prod_{i behind k} (1 - alpha_i) = T_final / (1 - alpha_k).  One register per pixel and
-                       // one FMA per (pixel, entry) less.
+    float A;           // see above
     float g0, g1, g2;  // dL_dpixel
     uint32_t last;     // n_contrib
 };
@@ -191,7 +191,6 @@ R3_HD void bwd_pix_init(BwdPix& p, float T_final, uint32_t last, float g0, float
 {
     p.T = T_final;
     p.A = bg_dot;
-    p.cgp = p.la = 0.f;
     p.g0 = g0;
     p.g1 = g1;
     p.g2 = g2;
@@ -259,11 +258,10 @@ R3_HD void bwd_accumulate(const QSplat& s, const BwdEval& e, BwdPix& p, SplatSum
     a.r += dch * p.g0;
     a.g += dch * p.g1;
     a.b += dch * p.g2;
-    p.A = fmaf(p.la, p.cgp - p.A, p.A);
     const float cg = s.r * p.g0 + s.g * p.g1 + s.b * p.g2;
-    p.cgp = cg;
-    p.la = e.alpha;
-    const float dL_dalpha = (cg - p.A) * p.T;
+    const float behind = cg - p.A;
+    const float dL_dalpha = behind * p.T;
+    p.A = fmaf(e.alpha, behind, p.A);
     const float m = e.G * dL_dalpha;
     a.sm += m;
     const float mdx = m * e.dx, mdy = m * e.dy;
