@@ -417,10 +417,11 @@ void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s)
 constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the flush reads without bank conflicts)
 
 // REUSE: the region pre-test masks are the forward's (BinState::quad_masks) instead of being recomputed per chunk.
-// 5 waves per SIMD (96 VGPRs).  Forcing 6 (80 VGPRs, a few spills outside the entry loop) measured the same time
-// (0.5174 vs 0.5170 ms), 3 / 4 likewise: the grid only has 6.5 waves per SIMD.
+// 6 waves per SIMD (80 VGPRs, three spilled values outside the entry loop).  With round 2's 96-register body 5 and 6
+// measured the same; since the accumulated-colour recurrence and the offset products took 10 registers out of the
+// loop, 6 is the faster by 1 % (0.3602 / 0.3603 vs 0.3644 / 0.3627 ms, two runs each, same box).
 #ifndef R3_BWD_OCC
-#define R3_BWD_OCC 5
+#define R3_BWD_OCC 6
 #endif
 template <int PPL, bool REUSE>
 __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)

@@ -100,9 +100,26 @@ R3_HD QSplat scale_splat(const Splat& s)
     return q;
 }
 
-R3_HD float log2_falloff(const QSplat& s, float dx, float dy)
+// The three products of the pixel offset are formed first and kept: the backward's second moments are sums of
+// m * dx^2, m * dx dy, m * dy^2 and take them as they are (one FMA each instead of a multiply and an FMA).
+struct Offset2 {
+    float dx, dy, dxx, dxy, dyy;
+};
+
+R3_HD Offset2 pixel_offset(const QSplat& s, float pxf, float pyf)
 {
-    return fmaf(s.qb * dx, dy, fmaf(s.qc * dy, dy, (s.qa * dx) * dx));
+    Offset2 o;
+    o.dx = s.x - pxf;
+    o.dy = s.y - pyf;
+    o.dxx = o.dx * o.dx;
+    o.dxy = o.dx * o.dy;
+    o.dyy = o.dy * o.dy;
+    return o;
+}
+
+R3_HD float log2_falloff(const QSplat& s, const Offset2& o)
+{
+    return fmaf(s.qa, o.dxx, fmaf(s.qb, o.dxy, s.qc * o.dyy));
 }
 
 struct FwdPix {
@@ -133,7 +150,7 @@ R3_HD float fwd_pix_T(const FwdPix& p) { return p.Tf; }
 // one more half-rate VALU instruction: v_cmp and v_cndmask issue at half the rate of an FMA, profiles/r03_valu_rate.txt).
 R3_HD float fwd_alpha(const QSplat& s, float pxf, float pyf, bool* in_bound)
 {
-    const float p2 = log2_falloff(s, s.x - pxf, s.y - pyf);
+    const float p2 = log2_falloff(s, pixel_offset(s, pxf, pyf));
     *in_bound = p2 <= 0.0f;
     return fminf(0.99f, s.op * R3_EXP2(p2));
 }
@@ -232,16 +249,16 @@ R3_HD SplatGrad splat_grad_of(const QSplat& s, const SplatSums& u)
 // before it branches on it.  bwd_test: the reference's three skips -- entry behind this pixel's last contributor
 // (backward.cu:524-526), power > 0, alpha < 1/255 -- evaluated together: one divergence point instead of three.
 struct BwdEval {
-    float dx, dy, G, alpha;
+    Offset2 o;
+    float G, alpha;
     bool in_list, in_bound, visible;   // the three decisions, kept apart: a kernel can ballot each compare for free
     R3_HD bool valid() const { return in_list && in_bound && visible; }
 };
 
 R3_HD bool bwd_test(const QSplat& s, float pxf, float pyf, uint32_t pos, const BwdPix& p, BwdEval& e)
 {
-    e.dx = s.x - pxf;
-    e.dy = s.y - pyf;
-    const float p2 = log2_falloff(s, e.dx, e.dy);
+    e.o = pixel_offset(s, pxf, pyf);
+    const float p2 = log2_falloff(s, e.o);
     e.G = R3_EXP2(p2);
     e.alpha = fminf(0.99f, s.op * e.G);
     e.in_list = pos < p.last;
@@ -264,12 +281,11 @@ R3_HD void bwd_accumulate(const QSplat& s, const BwdEval& e, BwdPix& p, SplatSum
     p.A = fmaf(e.alpha, behind, p.A);
     const float m = e.G * dL_dalpha;
     a.sm += m;
-    const float mdx = m * e.dx, mdy = m * e.dy;
-    a.sx += mdx;
-    a.sy += mdy;
-    a.sxx += mdx * e.dx;
-    a.sxy += mdx * e.dy;
-    a.syy += mdy * e.dy;
+    a.sx = fmaf(m, e.o.dx, a.sx);
+    a.sy = fmaf(m, e.o.dy, a.sy);
+    a.sxx = fmaf(m, e.o.dxx, a.sxx);
+    a.sxy = fmaf(m, e.o.dxy, a.sxy);
+    a.syy = fmaf(m, e.o.dyy, a.syy);
 }
 
 // Whole step for one (pixel, entry) pair, adding into `a`; returns true when the entry contributed.
