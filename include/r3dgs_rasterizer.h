@@ -151,6 +151,18 @@ int r3dgs_forward_pairs(void);
 int r3dgs_set_tight_rects(int on);
 int r3dgs_export_rects(int P, char* geom_buffer, unsigned short* rects, void* stream);
 
+/* Launch order of the backward blend's tiles.  1 (default): heaviest first -- the tiles whose lists the backward has to walk
+ * deepest (the forward leaves the depth of every 8x8 quadrant's last contributor in the image blob) are started first, so
+ * that the chip does not drain while the few long walks finish; 0: row-major, as the forward.  Every tile's arithmetic is
+ * its own: the gradients are bit-identical either way.  Returns the previous setting (a negative argument only queries).
+ * Also R3DGS_TILE_ORDER=0.  (No counterpart in the reference, whose backward.cu:405-618 takes tiles in grid order.) */
+int r3dgs_set_tile_order(int on);
+/* Debug accessor: the forward's per-quadrant depths ([tiles][4] uint32: quadrant q = (x half) + 2 * (y half) of the
+ * 16x16 tile) and, after a backward with the order on, the launch order it used ([tiles] uint32); device arrays, either
+ * may be NULL. */
+int r3dgs_export_tile_order(int width, int height, char* image_buffer, unsigned int* quad_depth, unsigned int* tile_order,
+                            void* stream);
+
 /* Forget every pair count learnt so far (a new scene is about to be loaded; tests): the next pass of each image size
  * takes the exact-size path again. */
 void r3dgs_reserve_forget(void);

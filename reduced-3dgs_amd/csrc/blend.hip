@@ -375,6 +375,13 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
             }
         }
     }
+    // deepest contributor of each quadrant: how far the backward will have to walk this tile's list (its launch order)
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        uint32_t m = pix[q].last;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if (lane == 0) global_ptr(a.quad_depth)[tile * 4u + (uint32_t)(part * PPL + q)] = m;
+    }
     const size_t plane = (size_t)a.W * a.H;
     const float bg0 = global_ptr(a.bg)[0], bg1 = global_ptr(a.bg)[1], bg2 = global_ptr(a.bg)[2];
 #pragma unroll
@@ -423,19 +430,20 @@ constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the 
 #ifndef R3_BWD_OCC
 #define R3_BWD_OCC 6
 #endif
-template <int PPL, bool REUSE>
+// FIRST: this is the first kernel of the backward (no tile order): it installs the pass block for the kernels behind it and
+// reads its own arguments from the kernarg segment; otherwise tile_order_kernel did and the arguments come from the block
+// (a graph replay refreshes the by-value arguments of its first node only).
+template <int PPL, bool REUSE, bool FIRST>
 __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ LdsRec s_rec[kChunk];
-    // first kernel of the backward: installs the pass block for the two kernels behind it, reads its own arguments from
-    // the kernarg segment
-    if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, 64);
+    if (FIRST && blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, 64);
     R3_TL_BEGIN(blockIdx.x)
-    const BlendBwdArgs a = v.blend;
+    const BlendBwdArgs a = FIRST ? v.blend : dst->blend;
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
-    const uint32_t wg = xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t wg = a.tile_order ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
@@ -606,14 +614,82 @@ extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 }
 #endif
 
+// Launch order of the backward blend's tiles: heaviest first.  All tiles are resident at once for the first half of the
+// kernel and each wave's duration is set by how many share its SIMD, so in row-major order the chip drains for the whole
+// second half (profiles/r03_bwd_timeline.txt: 20 resident waves per CU for five tenths of a CU's span, then 17, 12, 9, 6,
+// 3); started by decreasing weight, the long walks are under way when the short ones fill the gaps (0.367 -> 0.313 ms on
+// the metric shape).  Weight = sum over the four quadrants of the deepest contributor (ImageState::quad_depth): the
+// entries the wave will visit.  One workgroup, counting sort over 1024 weight classes; the order inside a class is
+// whatever the LDS atomics make it -- every tile's arithmetic is its own, so the gradients do not depend on the order
+// (tests/test_gpu_parity.py compares the two orders bit for bit).  The hardware deals consecutive workgroups over the
+// eight XCDs, i.e. every XCD gets every eighth tile of the sorted list: equal work per XCD as well.
+constexpr int kOrderThreads = 1024, kOrderClasses = 1024;
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* dst, BwdPassArgs v)
+{
+    __shared__ uint32_t s_count[kOrderClasses];
+    __shared__ uint32_t s_scan[kOrderThreads / 64];
+    __shared__ uint32_t s_max;
+    const uint32_t tid = threadIdx.x;
+    install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
+    const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(v.blend.quad_depth);
+    uint32_t* __restrict__ order = v.blend.tile_order;
+    const uint32_t n_tiles = v.blend.nblocks;   // one workgroup of the backward blend per tile
+    s_count[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    uint32_t wmax = 0u;
+    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+        const uint4 d = qd[t];
+        wmax = max(wmax, d.x + d.y + d.z + d.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
+    if ((tid & 63u) == 0u) atomicMax(&s_max, wmax);
+    __syncthreads();
+    const float scale = (float)(kOrderClasses - 1) / (float)max(s_max, 1u);
+    // class 0 = the heaviest
+    auto klass = [&](uint32_t t) {
+        const uint4 d = qd[t];
+        const uint32_t w = d.x + d.y + d.z + d.w;
+        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)w * scale), (uint32_t)(kOrderClasses - 1));
+    };
+    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) atomicAdd(&s_count[klass(t)], 1u);
+    __syncthreads();
+    // exclusive scan of the class counts (one class per thread)
+    const uint32_t mine = s_count[tid];
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((tid & 63u) >= (uint32_t)off) incl += up;
+    }
+    if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0u;
+    for (uint32_t k = 0; k < (tid >> 6); k++) before += s_scan[k];
+    __syncthreads();
+    s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
+    __syncthreads();
+    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) order[atomicAdd(&s_count[klass(t)], 1u)] = t;
+}
+
+template <bool REUSE>
+static void launch_bwd(uint32_t nblocks, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
+{
+    if (v.blend.tile_order) {
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
+        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(nblocks), dim3(64), 0, s, dst, v);
+    } else {
+        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
+    }
+}
+
 void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
 {
     // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
     const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == v.blend.nblocks
     if (v.blend.quad_masks)
-        hipLaunchKernelGGL((blend_bwd_kernel<4, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
+        launch_bwd<true>(nblocks, dst, v, s);
     else
-        hipLaunchKernelGGL((blend_bwd_kernel<4, false>), dim3(nblocks), dim3(64), 0, s, dst, v);
+        launch_bwd<false>(nblocks, dst, v, s);
 }
 
 }  // namespace r3

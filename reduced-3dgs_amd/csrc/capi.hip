@@ -78,6 +78,19 @@ int tight_rects()
     return v;
 }
 
+// The backward blend starts its tiles heaviest first (blend.hip tile_order_kernel); R3DGS_TILE_ORDER=0 /
+// r3dgs_set_tile_order(0): row-major bands, one per XCD, as the forward (A/B runs, the bit-identity test).
+std::atomic<int> g_tile_order{-1};
+int heaviest_tiles_first()
+{
+    int v = g_tile_order.load();
+    if (v < 0) {
+        v = env_int("R3DGS_TILE_ORDER", 1, 0, 1);
+        g_tile_order.store(v);
+    }
+    return v;
+}
+
 bool env_is(const char* name, const char* value)
 {
     const char* v = getenv(name);
@@ -723,6 +736,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     f.touched = p.counters ? c.out_touched_pixels : nullptr;
     f.transmittance = p.counters ? c.out_transmittance : nullptr;
     f.quad_masks = b && keep_quad_masks() ? b->quad_masks : nullptr;
+    f.quad_depth = img.quad_depth;
 }
 
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
@@ -1126,6 +1140,13 @@ int r3dgs_set_tight_rects(int on)   // on < 0: query only
     return before;
 }
 
+int r3dgs_set_tile_order(int on)   // on < 0: query only
+{
+    const int before = heaviest_tiles_first();
+    if (on >= 0) g_tile_order.store(on ? 1 : 0);
+    return before;
+}
+
 int r3dgs_export_rects(int P, char* geom_buffer, unsigned short* rects, void* stream)
 {
     return guarded([&]() {
@@ -1213,6 +1234,8 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         bb.pair_grad = bin.pair_grad;
         bb.pair_flag = bin.pair_flag;
         bb.quad_masks = binning_buffer && keep_quad_masks() ? bin.quad_masks : nullptr;
+        bb.tile_order = heaviest_tiles_first() ? img.tile_order : nullptr;
+        bb.quad_depth = img.quad_depth;
         PairReduceArgs& pr = a.reduce;
         pr.hdr = geom.header;
         pr.pair_grad = bin.pair_grad;
@@ -1273,7 +1296,8 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
             StageRun hooks{debug != 0};
             issue_backward(plan, d_args, a, s, hooks);
         } else {
-            const uint32_t flags = (uint32_t)plan.bwd_ppl | ((uint32_t)plan.has_pairs << 3) | ((uint32_t)plan.layout.wide << 4);
+            const uint32_t flags = (uint32_t)plan.bwd_ppl | ((uint32_t)plan.has_pairs << 3) | ((uint32_t)plan.layout.wide << 4) |
+                                   ((uint32_t)(a.blend.tile_order != nullptr) << 6);   // one more kernel in the chain
             const CtxKey key{dev, 1, s, P, M, width, height, plan.reserve, flags};
             launch_graph(key, plan, a, s, [](const BwdPlan& p, BwdPassArgs* d, const BwdPassArgs& v, hipStream_t cs) {
                 NoHooks nh;
@@ -1368,6 +1392,23 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
         if (final_T) R3_HIP(hipMemcpyAsync(final_T, img.final_T, sizeof(float) * N, hipMemcpyDeviceToDevice, s));
         if (tiles_touched)
             R3_HIP(hipMemcpyAsync(tiles_touched, geom.tiles, sizeof(uint32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
+        check_launch("export", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_export_tile_order(int width, int height, char* image_buffer, uint32_t* quad_depth, uint32_t* tile_order,
+                            void* stream)
+{
+    return guarded([&]() {
+        using namespace r3;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (!image_buffer) throw Error("a required pointer is NULL");
+        const int gx = (width + kTile - 1) / kTile, gy = (height + kTile - 1) / kTile;
+        const size_t Tn = (size_t)gx * gy;
+        ImageState img = ImageState::carve(image_buffer, (size_t)width * height, Tn);
+        if (quad_depth) R3_HIP(hipMemcpyAsync(quad_depth, img.quad_depth, sizeof(uint32_t) * 4 * Tn, hipMemcpyDeviceToDevice, s));
+        if (tile_order) R3_HIP(hipMemcpyAsync(tile_order, img.tile_order, sizeof(uint32_t) * Tn, hipMemcpyDeviceToDevice, s));
         check_launch("export", s, false);
         return 0;
     });

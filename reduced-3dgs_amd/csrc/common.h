@@ -290,6 +290,8 @@ struct ImageState {
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
     uint2* ranges;        // [Tn]
+    uint32_t* quad_depth; // [Tn][4] deepest contributor of each 8x8 quadrant (max of n_contrib), left by the forward blend
+    uint32_t* tile_order; // [Tn] tiles, heaviest backward first (blend.hip tile_order_kernel), written by the backward
     char* end;
     static ImageState carve(char* base, size_t N, size_t Tn)
     {
@@ -298,6 +300,8 @@ struct ImageState {
         s.final_T = c.take<float>(N);
         s.n_contrib = c.take<uint32_t>(N);
         s.ranges = c.take<uint2>(Tn);
+        s.quad_depth = c.take<uint32_t>(Tn * 4);
+        s.tile_order = c.take<uint32_t>(Tn);
         s.end = c.p;
         return s;
     }
@@ -508,6 +512,7 @@ struct BlendFwdArgs {     // blend.hip
     int* touched;
     float* transmittance;
     unsigned long long* quad_masks;   // BinState::quad_masks (null: not kept)
+    uint32_t* quad_depth;             // ImageState::quad_depth
 };
 struct BlendBwdArgs {     // blend.hip
     const uint2* ranges;
@@ -522,6 +527,9 @@ struct BlendBwdArgs {     // blend.hip
     float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
     unsigned char* pair_flag;  // [R] set for rows written in this pass
     const unsigned long long* quad_masks;   // BinState::quad_masks as the forward left them (null: recompute)
+    uint32_t* tile_order;                   // ImageState::tile_order: launch order of the tiles, heaviest first
+                                            // (null: row-major bands, one per XCD)
+    const uint32_t* quad_depth;             // ImageState::quad_depth, what the order is built from
 };
 struct PairReduceArgs {   // preprocess_bwd.hip
     const GeomHeader* hdr;

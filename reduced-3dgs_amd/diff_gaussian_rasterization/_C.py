@@ -58,6 +58,10 @@ _lib.r3dgs_pass_pairs.argtypes = [C.c_longlong, _i]
 _lib.r3dgs_forward_pairs.restype = _i
 _lib.r3dgs_set_tight_rects.restype = _i
 _lib.r3dgs_set_tight_rects.argtypes = [_i]
+_lib.r3dgs_set_tile_order.restype = _i
+_lib.r3dgs_set_tile_order.argtypes = [_i]
+_lib.r3dgs_export_tile_order.restype = _i
+_lib.r3dgs_export_tile_order.argtypes = [_i, _i, _vp, _vp, _vp, _vp]
 _lib.r3dgs_export_rects.restype = _i
 _lib.r3dgs_export_rects.argtypes = [_i, _vp, _vp, _vp]
 _lib.r3dgs_reserve_overflow_events.restype = C.c_longlong
@@ -552,6 +556,27 @@ def set_tight_rects(on):
 
 def tight_rects():
     return bool(_lib.r3dgs_set_tight_rects(-1))
+
+
+def set_tile_order(on):
+    """True (default): the backward blend starts its tiles heaviest first; False: row-major.  Same gradients, bit for bit.
+    Returns the previous setting."""
+    return bool(_lib.r3dgs_set_tile_order(int(bool(on))))
+
+
+def tile_order():
+    return bool(_lib.r3dgs_set_tile_order(-1))
+
+
+def export_tile_order(H, W, imageBuffer):
+    """Debug accessor (not in the reference): quad_depth int32[tiles, 4] (deepest contributor of each 8x8 quadrant, left by
+    the forward) and tile_order int32[tiles] (the backward blend's launch order; valid after a backward)."""
+    n = ((W + 15) // 16) * ((H + 15) // 16)
+    qd = torch.empty((n, 4), dtype=torch.int32, device=imageBuffer.device)
+    order = torch.empty((n,), dtype=torch.int32, device=imageBuffer.device)
+    with _on_device(imageBuffer.device):
+        _check(_lib.r3dgs_export_tile_order(W, H, _ptr(imageBuffer), _ptr(qd), _ptr(order), _stream()), "export_tile_order")
+    return dict(quad_depth=qd, tile_order=order)
 
 
 def rasterize_gaussians_counters(*args):

@@ -267,6 +267,45 @@ def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-30, n
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02),
+    dict(P=3_000, W=333, H=77, f=200.0, cam_seed=None, gseed=1, degree_mode="all3", scale_mu=0.05),
+    dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3", scale_mu=0.012),
+], ids=["20k_mixed", "ragged_333x77", "metric_500k_1600x1062"])
+def test_backward_tile_order_changes_no_bit(C_, kw):
+    """The backward blend starts its tiles heaviest first (set_tile_order, on by default).  Every tile's arithmetic is its
+    own, so every gradient must equal the row-major launch's bit for bit; and the weight the order is built from must be
+    what the forward says it is: per 8x8 quadrant the deepest contributor, i.e. the maximum of n_contrib there."""
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw["scale_mu"])
+    bg = np.array([0.3, 0.1, 0.2], np.float32)
+    dl = ss.upstream_grad(W, H, seed=5) * (W * H)
+    assert C_.tile_order()
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    heavy_first = hip_backward(C_, fargs, fout, dl, 0.05)
+    st = C_.export_tile_order(H, W, fout[5])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    order = st["tile_order"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(gx * gy))                      # a permutation of the tiles
+    ex = C_.export_binning(P, fout[0], H, W, fout[3], fout[4], fout[5])
+    nc = np.zeros((gy * 16, gx * 16), np.int64)
+    nc[:H, :W] = ex["n_contrib"].cpu().numpy().reshape(H, W)
+    want = nc.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5)).transpose(0, 2, 1, 3).reshape(gx * gy, 4)
+    assert np.array_equal(st["quad_depth"].cpu().numpy().astype(np.int64), want)
+    weight = want.sum(axis=1)[order]
+    klass = (weight.astype(np.float64) * 1023.0 / max(int(weight.max()), 1)).astype(np.int64)   # the kernel's 1024 classes
+    assert np.all(np.diff(klass) <= 1), "heavier classes must come first (one class of slack for the fp32 product)"
+    assert weight[0] == weight.max()
+    was = C_.set_tile_order(False)
+    try:
+        row_major = hip_backward(C_, fargs, fout, dl, 0.05)
+    finally:
+        C_.set_tile_order(was)
+    for a, b in zip(heavy_first, row_major):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])
 def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     """Depth-sort corner cases of the bucketed sort (binning.hip): `plane` puts 20k splats at ONE depth (a single
