@@ -53,10 +53,12 @@ __device__ __forceinline__ R3_GLOBAL T* global_ptr(T* p)
 
 constexpr int kChunk = 64;
 
-#if defined(R3_TIMELINE)   // debug builds only (tools/bwd_timeline.py): when and where every backward workgroup ran
+// debug builds only (tools/bwd_timeline.py): when and where every workgroup of the backward (-DR3_TIMELINE) or of the
+// forward (-DR3_TIMELINE_FWD) blend ran
+#if defined(R3_TIMELINE) || defined(R3_TIMELINE_FWD)
 __device__ unsigned long long g_timeline[4 * 65536];
-#define R3_TL_BEGIN(id) const unsigned long long tl0_ = __builtin_amdgcn_s_memtime(); const uint32_t tlid_ = (id);
-#define R3_TL_END(extra)                                                                                                 \
+#define R3_TL_BEGIN_(id) const unsigned long long tl0_ = __builtin_amdgcn_s_memtime(); const uint32_t tlid_ = (id);
+#define R3_TL_END_(extra)                                                                                                \
     if (threadIdx.x == 0 && tlid_ < 65536u) {                                                                            \
         g_timeline[4 * tlid_] = tl0_;                                                                                     \
         g_timeline[4 * tlid_ + 1] = __builtin_amdgcn_s_memtime();                                                         \
@@ -64,9 +66,20 @@ __device__ unsigned long long g_timeline[4 * 65536];
                                     ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
         g_timeline[4 * tlid_ + 3] = (unsigned long long)(extra);                                                          \
     }
+#endif
+#if defined(R3_TIMELINE)
+#define R3_TL_BEGIN(id) R3_TL_BEGIN_(id)
+#define R3_TL_END(extra) R3_TL_END_(extra)
 #else
 #define R3_TL_BEGIN(id)
 #define R3_TL_END(extra)
+#endif
+#if defined(R3_TIMELINE_FWD)
+#define R3_TLF_BEGIN(id) R3_TL_BEGIN_(id)
+#define R3_TLF_END(extra) R3_TL_END_(extra)
+#else
+#define R3_TLF_BEGIN(id)
+#define R3_TLF_END(extra)
 #endif
 
 struct LdsRec {  // 48 B: a staged list entry, conic pre-scaled (QSplat); c.yzw = GRec's rect_min, width_clamp, pair_start
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
 {
     __shared__ LdsRec s_rec[kChunk];
     const BlendFwdArgs a = *ap;   // pass block in device memory: scalar loads, once
+    R3_TLF_BEGIN(blockIdx.x)
     __shared__ uint32_t s_id[kChunk];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
@@ -396,6 +410,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
             global_ptr(a.out_color)[2 * plane + p] = pix[q].C2 + T * bg2;
         }
     }
+    R3_TLF_END(range.y - range.x)
 }
 
 template <int PPL>
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     R3_TL_END(lmax)
 }
 
-#if defined(R3_TIMELINE)
+#if defined(R3_TIMELINE) || defined(R3_TIMELINE_FWD)
 extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);
@@ -637,22 +652,41 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* 
     s_count[tid] = 0u;
     if (tid == 0) s_max = 0u;
     __syncthreads();
+    // up to kOrderKeep tiles per thread stay in registers between the three passes (one memory round trip instead of
+    // three: the kernel is a chain of latencies, 9.5 us when every pass went back to memory); a larger grid re-reads
+    constexpr int kOrderKeep = 8;
+    const bool keep = n_tiles <= (uint32_t)(kOrderKeep * kOrderThreads);
+    uint32_t w[kOrderKeep];
     uint32_t wmax = 0u;
-    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+    auto weight = [&](uint32_t t) {
         const uint4 d = qd[t];
-        wmax = max(wmax, d.x + d.y + d.z + d.w);
+        return d.x + d.y + d.z + d.w;
+    };
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++) {
+            const uint32_t t = tid + (uint32_t)(k * kOrderThreads);
+            w[k] = t < n_tiles ? weight(t) : 0u;
+            wmax = max(wmax, w[k]);
+        }
+    } else {
+        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) wmax = max(wmax, weight(t));
     }
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
     if ((tid & 63u) == 0u) atomicMax(&s_max, wmax);
     __syncthreads();
     const float scale = (float)(kOrderClasses - 1) / (float)max(s_max, 1u);
     // class 0 = the heaviest
-    auto klass = [&](uint32_t t) {
-        const uint4 d = qd[t];
-        const uint32_t w = d.x + d.y + d.z + d.w;
-        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)w * scale), (uint32_t)(kOrderClasses - 1));
+    auto klass = [&](uint32_t wt) {
+        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)wt * scale), (uint32_t)(kOrderClasses - 1));
     };
-    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) atomicAdd(&s_count[klass(t)], 1u);
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++)
+            if (tid + (uint32_t)(k * kOrderThreads) < n_tiles) atomicAdd(&s_count[klass(w[k])], 1u);
+    } else {
+        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) atomicAdd(&s_count[klass(weight(t))], 1u);
+    }
     __syncthreads();
     // exclusive scan of the class counts (one class per thread)
     const uint32_t mine = s_count[tid];
@@ -668,15 +702,24 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* 
     __syncthreads();
     s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
     __syncthreads();
-    for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) order[atomicAdd(&s_count[klass(t)], 1u)] = t;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++) {
+            const uint32_t t = tid + (uint32_t)(k * kOrderThreads);
+            if (t < n_tiles) order[atomicAdd(&s_count[klass(w[k])], 1u)] = t;
+        }
+    } else {
+        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) order[atomicAdd(&s_count[klass(weight(t))], 1u)] = t;
+    }
 }
 
 template <bool REUSE>
 static void launch_bwd(uint32_t nblocks, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
 {
     if (v.blend.tile_order) {
+        static const int lds_pad = env_int("R3DGS_BWD_LDS_PAD", 0, 0, 65536);
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
-        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(nblocks), dim3(64), 0, s, dst, v);
+        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(nblocks), dim3(64), lds_pad, s, dst, v);
     } else {
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
     }

@@ -553,6 +553,7 @@ struct PreBwdArgs {       // preprocess_bwd.hip
     const float* wave_part;
     const GeomHeader* header;
     float lambda_sh;
+    int stagger;   // start-up delay step of the first generation of workgroups, in 64-clock units (preprocess_bwd.hip)
     BwdOutputs out;
 };
 

@@ -26,13 +26,57 @@ constexpr int kMaxCoeff = 16;
 constexpr int kRowFloats = 3 * kMaxCoeff;                        // 48
 constexpr int kWaveShFloats = 64 * kRowFloats + (64 * kRowFloats) / 32;  // + bank skew
 
-__device__ __forceinline__ int skew(int e) { return e + (e >> 5); }
+// Where float e of a wave's SH span sits in LDS (the lanes read the same element of 64 different rows: the rows must start
+// in different banks).  ROWS48 -- a dense [P,16,3] tensor, rows of 48 floats: one word of padding per row, element e of
+// the lane's row is base[49 * lane + e] and e folds into the instruction's offset field; otherwise (ragged rows, other M)
+// one word of padding per 32 and the address is computed per access.
+template <bool ROWS48>
+__device__ __forceinline__ int skew(int e)
+{
+    if (ROWS48) return e + (int)(((uint32_t)e * 43691u) >> 21);   // e + e / 48 for e < 2^16
+    return e + (e >> 5);
+}
 
+template <bool ROWS48>
 struct ShRowLds {
-    const float* base;
-    int roff;
-    __device__ __forceinline__ float at(int e) const { return base[skew(roff + e)]; }
+    const float* base;   // ROWS48: the lane's row (span + 49 * lane); else the wave's span
+    int roff;            // ROWS48: 0; else first float of the lane's row in the span
+    __device__ __forceinline__ float at(int e) const { return ROWS48 ? base[e] : base[skew<false>(roff + e)]; }
 };
+
+// the wave's span (n4 float4s at src4) -> LDS, twelve loads per lane in flight
+template <bool ROWS48>
+__device__ __forceinline__ void stage_span(const float4* __restrict__ src4, int n4, float* dst, int lane)
+{
+    constexpr int kBatch = 12;
+    for (int base = 0; base < n4; base += 64 * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int e4 = base + k * 64 + lane;
+            v[k] = e4 < n4 ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int e4 = base + k * 64 + lane;
+            if (e4 < n4) {
+                const int e = e4 << 2;
+                if (ROWS48) {   // 48 % 4 == 0: the four floats are in one row
+                    float* d = dst + skew<true>(e);
+                    d[0] = v[k].x;
+                    d[1] = v[k].y;
+                    d[2] = v[k].z;
+                    d[3] = v[k].w;
+                } else {
+                    dst[skew<false>(e)] = v[k].x;
+                    dst[skew<false>(e + 1)] = v[k].y;
+                    dst[skew<false>(e + 2)] = v[k].z;
+                    dst[skew<false>(e + 3)] = v[k].w;
+                }
+            }
+        }
+    }
+}
 
 // forward.cu:19-36 getSHOffset (float3 units)
 __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const int* perband, const int* cumsum, int* deg)
@@ -165,6 +209,7 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
     float(*s_sh)[kWaveShFloats] = reinterpret_cast<float(*)[kWaveShFloats]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.in.P, M = a.in.M;
+    const bool rows48 = !RAGGED && M == 16;   // dense degree-3 tensor (wave-uniform)
   for (int blk = first + wg; blk < last; blk += n_wg) {
     const int i = blk * kPreBlock + tid;
     const bool valid = i < P;
@@ -206,29 +251,12 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
             // first LDS store: with one load in flight per wave (load, wait, store, next load) the kernel ran at the
             // 2 TB/s that 12 waves/CU x 1 KB per memory latency allow.
             const float4* src4 = reinterpret_cast<const float4*>(src);
-            const int n4 = span_len >> 2;
-            constexpr int kBatch = 12;
-            for (int base = 0; base < n4; base += 64 * kBatch) {
-                float4 v[kBatch];
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    const int e4 = base + k * 64 + lane;
-                    v[k] = e4 < n4 ? src4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    const int e4 = base + k * 64 + lane;
-                    if (e4 < n4) {
-                        const int e = e4 << 2;
-                        dst[skew(e)] = v[k].x;
-                        dst[skew(e + 1)] = v[k].y;
-                        dst[skew(e + 2)] = v[k].z;
-                        dst[skew(e + 3)] = v[k].w;
-                    }
-                }
-            }
+            if (rows48)
+                stage_span<true>(src4, span_len >> 2, dst, lane);
+            else
+                stage_span<false>(src4, span_len >> 2, dst, lane);
         } else {
-            for (int e = lane; e < span_len; e += 64) dst[skew(e)] = src[e];
+            for (int e = lane; e < span_len; e += 64) dst[rows48 ? skew<true>(e) : skew<false>(e)] = src[e];
         }
     }
     __syncthreads();
@@ -238,9 +266,14 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
         uint32_t cbits = 0;
         if (need_sh) {
             const float campos[3] = {a.view.campos[0], a.view.campos[1], a.view.campos[2]};
-            ShRowLds row{s_sh[wave], roff};
-            sh_to_rgb(deg, row, a.in.means3D[3 * i], a.in.means3D[3 * i + 1], a.in.means3D[3 * i + 2], campos, rgb,
-                      &cbits);
+            const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
+            if (rows48) {
+                const ShRowLds<true> row{s_sh[wave] + 49 * lane, 0};
+                sh_to_rgb(deg, row, mx, my, mz, campos, rgb, &cbits);
+            } else {
+                const ShRowLds<false> row{s_sh[wave], roff};
+                sh_to_rgb(deg, row, mx, my, mz, campos, rgb, &cbits);
+            }
         } else {
             rgb[0] = a.in.colors_precomp[3 * i];
             rgb[1] = a.in.colors_precomp[3 * i + 1];

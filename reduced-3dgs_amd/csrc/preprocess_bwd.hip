@@ -20,13 +20,31 @@ namespace r3 {
 constexpr int kBwdBlock = 256;
 constexpr int kBwdWaveShFloats = 64 * 48 + (64 * 48) / 32;
 
-__device__ __forceinline__ int bskew(int e) { return e + (e >> 5); }
+// Where float e of the wave's span (64 rows x 3M floats, row after row) sits in LDS.  The lanes of a wave read the same
+// element of 64 different rows, so the rows must start in different banks.
+//   ROWS48 (M == 16, every dense degree-3 tensor): one word of padding per row, i.e. rows 49 words apart.  Element e of
+//     lane's row is base[49 * lane + e]: the compiler folds e into the instruction's offset field, no address arithmetic
+//     per access (the general scheme below spent 30 % of the kernel's vector instructions on it).
+//   otherwise: one word of padding per 32.
+template <bool ROWS48>
+__device__ __forceinline__ int bskew(int e)
+{
+    if (ROWS48) return e + (int)(((uint32_t)e * 43691u) >> 21);   // e + e / 48 for e < 2^16
+    return e + (e >> 5);
+}
 
+template <bool ROWS48>
 struct ShRowLdsRW {
-    float* base;
-    int roff;
-    __device__ __forceinline__ float at(int e) const { return base[bskew(roff + e)]; }
-    __device__ __forceinline__ void put(int e, float v) const { base[bskew(roff + e)] = v; }
+    float* base;   // ROWS48: already advanced to the lane's row (base + 49 * lane); else the wave's span
+    int roff;      // ROWS48: 0; else first float of the lane's row in the span
+    __device__ __forceinline__ float at(int e) const { return ROWS48 ? base[e] : base[bskew<false>(roff + e)]; }
+    __device__ __forceinline__ void put(int e, float v) const
+    {
+        if (ROWS48)
+            base[e] = v;
+        else
+            base[bskew<false>(roff + e)] = v;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -150,6 +168,7 @@ void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
     hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.grid_pairs + per - 1u) / per), dim3(256), 0, s, a);
 }
 
+template <bool ROWS48>
 __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
 {
     __shared__ float s_sh[kBwdBlock / 64][kBwdWaveShFloats];
@@ -162,6 +181,12 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     const Camera cam = load_camera(a.view);
     const bool has_sh = a.in.shs != nullptr;
 
+    // The workgroups that start together (three per CU) would load together, compute together and store together: HBM
+    // idle while they compute, the SIMDs idle while they wait.  The second and third of a CU start a step later each.
+    if (a.stagger > 0 && blockIdx.x < 768u) {
+        const int steps = (int)(blockIdx.x >> 8) * a.stagger;
+        for (int k = 0; k < steps; k += 127) __builtin_amdgcn_s_sleep(127);
+    }
     const bool vis = valid && a.radii[i] > 0;
     const int nrows = max(0, min(64, P - wave_first));
     const int span_len = has_sh ? nrows * 3 * M : 0;
@@ -186,15 +211,23 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
                     const int e4 = base + k * 64 + lane;
                     if (e4 < n4) {
                         const int e = e4 << 2;
-                        lds[bskew(e)] = v[k].x;
-                        lds[bskew(e + 1)] = v[k].y;
-                        lds[bskew(e + 2)] = v[k].z;
-                        lds[bskew(e + 3)] = v[k].w;
+                        if (ROWS48) {   // 48 % 4 == 0: the four floats are in one row
+                            float* d = lds + bskew<true>(e);
+                            d[0] = v[k].x;
+                            d[1] = v[k].y;
+                            d[2] = v[k].z;
+                            d[3] = v[k].w;
+                        } else {
+                            lds[bskew<false>(e)] = v[k].x;
+                            lds[bskew<false>(e + 1)] = v[k].y;
+                            lds[bskew<false>(e + 2)] = v[k].z;
+                            lds[bskew<false>(e + 3)] = v[k].w;
+                        }
                     }
                 }
             }
         } else {
-            for (int e = lane; e < span_len; e += 64) lds[bskew(e)] = src[e];
+            for (int e = lane; e < span_len; e += 64) lds[bskew<ROWS48>(e)] = src[e];
         }
     }
     __syncthreads();
@@ -203,7 +236,7 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     float g2x = 0.f, g2y = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f}, gcon[3] = {0.f, 0.f, 0.f};
     int K = 0;
-    ShRowLdsRW row{lds, lane * 3 * M};
+    const ShRowLdsRW<ROWS48> row{ROWS48 ? lds + 49 * lane : lds, ROWS48 ? 0 : lane * 3 * M};
     if (vis) {
         const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
         const GRec r = a.rec[i];
@@ -278,13 +311,19 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
             if (wave_vis) {
                 for (int e4 = lane; e4 < n4; e4 += 64) {
                     const int e = e4 << 2;
-                    dst4[e4] = make_float4(lds[bskew(e)], lds[bskew(e + 1)], lds[bskew(e + 2)], lds[bskew(e + 3)]);
+                    if (ROWS48) {
+                        const float* q = lds + bskew<true>(e);
+                        dst4[e4] = make_float4(q[0], q[1], q[2], q[3]);
+                    } else {
+                        dst4[e4] = make_float4(lds[bskew<false>(e)], lds[bskew<false>(e + 1)], lds[bskew<false>(e + 2)],
+                                               lds[bskew<false>(e + 3)]);
+                    }
                 }
             } else {
                 for (int e4 = lane; e4 < n4; e4 += 64) dst4[e4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else if (wave_vis) {
-            for (int e = lane; e < span_len; e += 64) dst[e] = lds[bskew(e)];
+            for (int e = lane; e < span_len; e += 64) dst[e] = lds[bskew<ROWS48>(e)];
         } else {
             for (int e = lane; e < span_len; e += 64) dst[e] = 0.f;
         }
@@ -328,7 +367,11 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
 void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_t s)
 {
     const int blocks = (p.P + kBwdBlock - 1) / kBwdBlock;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(kBwdBlock), 0, s, a);
+    static const int lds_pad = env_int("R3DGS_PREBWD_LDS_PAD", 0, 0, 65536);
+    if (p.M == 16)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
 }
 
 }  // namespace r3

@@ -271,7 +271,8 @@ def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
     dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02),
     dict(P=3_000, W=333, H=77, f=200.0, cam_seed=None, gseed=1, degree_mode="all3", scale_mu=0.05),
     dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3", scale_mu=0.012),
-], ids=["20k_mixed", "ragged_333x77", "metric_500k_1600x1062"])
+    dict(P=6_000, W=2064, H=1100, f=1500.0, cam_seed=None, gseed=2, degree_mode="all0", scale_mu=0.03),   # 8901 tiles: the
+], ids=["20k_mixed", "ragged_333x77", "metric_500k_1600x1062", "8901_tiles"])                             # re-reading path
 def test_backward_tile_order_changes_no_bit(C_, kw):
     """The backward blend starts its tiles heaviest first (set_tile_order, on by default).  Every tile's arithmetic is its
     own, so every gradient must equal the row-major launch's bit for bit; and the weight the order is built from must be

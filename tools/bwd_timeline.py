@@ -1,5 +1,6 @@
 """Debug aid: when and where every workgroup of the backward blend ran (build: python tools/build_variant.py tl blend.hip --
--DR3_TIMELINE; run with R3DGS_LIB=tl).  Prints the distribution of workgroup durations, the resident workgroups over
+-DR3_TIMELINE; run with R3DGS_LIB=tl) -- or, with the argument `fwd`, of the forward blend (variant tlf, -DR3_TIMELINE_FWD;
+one workgroup per 8x8 quadrant there).  Prints the distribution of workgroup durations, the resident workgroups over
 time and the per-SIMD load; saves the raw table to gpurun_out/bwd_timeline.npy."""
 import ctypes as C
 import os
@@ -10,7 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "reduced-3dgs_amd")]
-os.environ.setdefault("R3DGS_LIB", "tl")
+FWD = len(sys.argv) > 1 and sys.argv[1] == "fwd"
+os.environ.setdefault("R3DGS_LIB", "tlf" if FWD else "tl")
 os.environ["R3DGS_GRAPH"] = "0"
 import synth_scene as ss  # noqa: E402
 from diff_gaussian_rasterization import _C  # noqa: E402
@@ -28,12 +30,12 @@ for rep in range(6):   # warm clocks, then keep the last pass's table
     _C.rasterize_gaussians_backward(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9], args[10],
                                     args[11], dl, args[14], args[15], args[16], geom, R, binning, img, 0.0, False)
 torch.cuda.synchronize()
-n = ((W + 15) // 16) * ((H + 15) // 16)
+n = ((W + 15) // 16) * ((H + 15) // 16) * (4 if FWD else 1)
 tab = np.zeros((n, 4), np.uint64)
 rc = _C._lib.r3dgs_debug_timeline(tab.ctypes.data_as(C.c_void_p), C.c_int(n))
 assert rc == 0, rc
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-np.save(os.path.join(ROOT, "gpurun_out", "bwd_timeline.npy"), tab)
+np.save(os.path.join(ROOT, "gpurun_out", "fwd_timeline.npy" if FWD else "bwd_timeline.npy"), tab)
 t0, t1, hw, lmax = (tab[:, k].astype(np.int64) for k in range(4))
 xcc = (hw >> 32) & 15          # HW_REG_XCC_ID
 hw = hw & 0xFFFFFFFF           # HW_REG_HW_ID: wave slot [3:0], simd [5:4], cu [11:8], sh [12], se [15:13]
