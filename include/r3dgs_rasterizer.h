@@ -157,6 +157,13 @@ int r3dgs_export_rects(int P, char* geom_buffer, unsigned short* rects, void* st
  * its own: the gradients are bit-identical either way.  Returns the previous setting (a negative argument only queries).
  * Also R3DGS_TILE_ORDER=0.  (No counterpart in the reference, whose backward.cu:405-618 takes tiles in grid order.) */
 int r3dgs_set_tile_order(int on);
+/* SH direction derivatives.  A forward over a dense SH tensor leaves d(colour)/d(view direction) of every visible Gaussian
+ * in the geometry blob (36 B each, evaluated while the SH row is staged for the colour anyway); a backward without a
+ * sparsity term (lambda_sh_sparsity == 0) then does not read the SH tensor at all (backward.cu:20-172 reads 12 * M bytes
+ * per Gaussian for exactly these nine numbers).  0: the backward reads the rows, as with a sparsity term.  Bit-identical
+ * gradients either way.  Returns the previous setting (a negative argument only queries).  Also R3DGS_SH_CACHE=0. */
+int r3dgs_set_sh_cache(int on);
+
 /* Debug accessor: the forward's per-quadrant depths ([tiles][4] uint32: quadrant q = (x half) + 2 * (y half) of the
  * 16x16 tile) and, after a backward with the order on, the launch order it used ([tiles] uint32); device arrays, either
  * may be NULL. */

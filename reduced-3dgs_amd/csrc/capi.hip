@@ -91,6 +91,19 @@ int heaviest_tiles_first()
     return v;
 }
 
+// Without a sparsity term the backward takes the SH direction derivatives the forward left (GeomState::sh_ddir) instead of
+// reading every SH row again; R3DGS_SH_CACHE=0 / r3dgs_set_sh_cache(0): it reads the rows (A/B runs, the bit-identity test).
+std::atomic<int> g_sh_cache{-1};
+int sh_derivative_cache()
+{
+    int v = g_sh_cache.load();
+    if (v < 0) {
+        v = env_int("R3DGS_SH_CACHE", 1, 0, 1);
+        g_sh_cache.store(v);
+    }
+    return v;
+}
+
 bool env_is(const char* name, const char* value)
 {
     const char* v = getenv(name);
@@ -632,6 +645,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.pre.radii = radii;
     a.pre.color_blocks = (c.P + kPreBlockSize - 1) / kPreBlockSize;
     a.pre.tight = p.tight;
+    a.pre.sh_ddir = (!p.ragged && c.shs && !c.colors_precomp) ? g.sh_ddir : nullptr;
 
     a.header.parts = g.partials;
     a.header.n_parts = (int)pre_partials((size_t)c.P);
@@ -640,6 +654,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.header.ticket = (uint32_t)ticket_number(ticket);
     a.header.reserve = p.reserve;
     a.header.stamp_sort = p.generic_depth_sort ? 1 : 0;   // no scan kernel behind the header on the generic-sort route
+    a.header.sh_cache = a.pre.sh_ddir ? 1u : 0u;
 
     DepthArgs& d = a.depth;
     d.P = c.P;
@@ -1140,6 +1155,13 @@ int r3dgs_set_tight_rects(int on)   // on < 0: query only
     return before;
 }
 
+int r3dgs_set_sh_cache(int on)   // on < 0: query only
+{
+    const int before = sh_derivative_cache();
+    if (on >= 0) g_sh_cache.store(on ? 1 : 0);
+    return before;
+}
+
 int r3dgs_set_tile_order(int on)   // on < 0: query only
 {
     const int before = heaviest_tiles_first();
@@ -1276,6 +1298,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         pb.wave_part = plan.has_pairs ? bin.wave_part : nullptr;
         pb.header = geom.header;
         pb.lambda_sh = lambda_sh_sparsity;
+        pb.sh_ddir = (lambda_sh_sparsity == 0.f && sh_derivative_cache()) ? geom.sh_ddir : nullptr;
         pb.out.dL_dmean2D = dL_dmean2D;
         pb.out.dL_dopacity = dL_dopacity;
         pb.out.dL_dcolor = dL_dcolor;

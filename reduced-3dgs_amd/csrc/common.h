@@ -60,7 +60,8 @@ struct GeomHeader {
     uint32_t sort_overflow;   // a depth bucket exceeded the LDS sort capacity (handled on the device; host hint only)
     uint32_t binned;          // Gaussians that own pairs: the first `binned` entries of the depth order
     uint32_t rendered_ref;    // the reference's num_rendered (reported; nothing on the device uses it)
-    uint32_t pad[55];
+    uint32_t sh_cache;        // 1: GeomState::sh_ddir holds this pass's SH direction derivatives (dense SH input)
+    uint32_t pad[54];
 };
 static_assert(sizeof(GeomHeader) == 256, "header = 256 B");
 inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBlockSize; }
@@ -148,6 +149,9 @@ struct GeomState {
     uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
     uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
     int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
+    float* sh_ddir;       // [P * 9]  d(colour channel)/d(view direction) of the SH expansion (gauss_math.h sh_dir_derivs),
+                          //          left by the forward's colour stream for visible Gaussians of degree > 0: the backward
+                          //          then needs the 12 * M-byte SH row only for the sparsity term
     uint32_t* ovf_key;    // [P]  ping-pong partner of key_sorted for a depth bucket that overflows the LDS sort
     uint32_t* ovf_id;     // [P]  ... and of bucket_id
     char* temp;           // rocPRIM temp storage of the generic depth sort
@@ -172,6 +176,7 @@ struct GeomState {
         g.order = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.radii_internal = c.take<int>(P);
+        g.sh_ddir = c.take<float>(P * 9);
         g.ovf_key = c.take<uint32_t>(P);
         g.ovf_id = c.take<uint32_t>(P);
         g.temp = c.take<char>(temp_bytes);
@@ -428,6 +433,7 @@ struct PreArgs {          // preprocess.hip
     int* radii;
     int color_blocks;     // workgroup-sized chunks of the colour kernel's persistent loop
     int tight;            // 1: bin into the opacity-aware rect (gauss_math.h tighten_rect), 0: into the reference's
+    float* sh_ddir;       // GeomState::sh_ddir (null: ragged SH / precomputed colours -- nothing to leave)
 };
 struct HeaderArgs {       // binning.hip header_reduce_kernel
     const PrePartial* parts;
@@ -437,6 +443,7 @@ struct HeaderArgs {       // binning.hip header_reduce_kernel
     uint32_t ticket;
     uint32_t reserve;
     uint32_t stamp_sort;  // 1: no depth-scan kernel follows (generic sort): the header stamps PassInfo::sort_seq itself
+    uint32_t sh_cache;    // -> GeomHeader::sh_cache
 };
 struct DepthArgs {        // depth_sort.h bucketed depth sort
     int P, nb, rows, per_block;
@@ -553,6 +560,7 @@ struct PreBwdArgs {       // preprocess_bwd.hip
     const float* wave_part;
     const GeomHeader* header;
     float lambda_sh;
+    const float* sh_ddir; // GeomState::sh_ddir when the backward may use it (no sparsity term, not switched off), else null
     int stagger;   // start-up delay step of the first generation of workgroups, in 64-clock units (preprocess_bwd.hip)
     BwdOutputs out;
 };

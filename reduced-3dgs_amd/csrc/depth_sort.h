@@ -167,6 +167,7 @@ __device__ inline void write_header(const HeaderArgs& a, const PrePartial& all)
     hdr->sort_overflow = 0u;
     hdr->binned = all.binned;
     hdr->rendered_ref = all.rendered_ref;
+    hdr->sh_cache = a.sh_cache;
     volatile PassInfo* info = a.info;
     if (info) {
         info->num_rendered = all.rendered_ref;

@@ -424,11 +424,61 @@ struct ShGradPlain {
     R3_HD void put(int e, float v) const { p[e] = v; }
 };
 
+// backward.cu:61-150: d(colour channel ch)/d(unit view direction), d9[3 * ch + axis], for deg > 0.  A function of the SH
+// row and the direction only -- the forward can evaluate it while it has the row staged (preprocess.hip) and spare the
+// backward the 12 * M bytes per Gaussian of reading the row again.
+template <class ShRow>
+R3_HD void sh_dir_derivs(int deg, const ShRow& sh, float x, float y, float z, float* d9)
+{
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    for (int ch = 0; ch < 3; ch++) {
+#define R3_SH(k) sh.at(3 * (k) + ch)
+        float dx_ = -R3_SH_C1 * R3_SH(3);
+        float dy_ = -R3_SH_C1 * R3_SH(1);
+        float dz_ = R3_SH_C1 * R3_SH(2);
+        if (deg > 1) {
+            dx_ += R3_SH_C2_0 * y * R3_SH(4) + R3_SH_C2_2 * 2.f * -x * R3_SH(6) + R3_SH_C2_3 * z * R3_SH(7) +
+                   R3_SH_C2_4 * 2.f * x * R3_SH(8);
+            dy_ += R3_SH_C2_0 * x * R3_SH(4) + R3_SH_C2_1 * z * R3_SH(5) + R3_SH_C2_2 * 2.f * -y * R3_SH(6) +
+                   R3_SH_C2_4 * 2.f * -y * R3_SH(8);
+            dz_ += R3_SH_C2_1 * y * R3_SH(5) + R3_SH_C2_2 * 2.f * 2.f * z * R3_SH(6) + R3_SH_C2_3 * x * R3_SH(7);
+            if (deg > 2) {
+                dx_ += (R3_SH_C3_0 * R3_SH(9) * 3.f * 2.f * xy + R3_SH_C3_1 * R3_SH(10) * yz +
+                        R3_SH_C3_2 * R3_SH(11) * -2.f * xy + R3_SH_C3_3 * R3_SH(12) * -3.f * 2.f * xz +
+                        R3_SH_C3_4 * R3_SH(13) * (-3.f * xx + 4.f * zz - yy) + R3_SH_C3_5 * R3_SH(14) * 2.f * xz +
+                        R3_SH_C3_6 * R3_SH(15) * 3.f * (xx - yy));
+                dy_ += (R3_SH_C3_0 * R3_SH(9) * 3.f * (xx - yy) + R3_SH_C3_1 * R3_SH(10) * xz +
+                        R3_SH_C3_2 * R3_SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                        R3_SH_C3_3 * R3_SH(12) * -3.f * 2.f * yz + R3_SH_C3_4 * R3_SH(13) * -2.f * xy +
+                        R3_SH_C3_5 * R3_SH(14) * -2.f * yz + R3_SH_C3_6 * R3_SH(15) * -3.f * 2.f * xy);
+                dz_ += (R3_SH_C3_1 * R3_SH(10) * xy + R3_SH_C3_2 * R3_SH(11) * 4.f * 2.f * yz +
+                        R3_SH_C3_3 * R3_SH(12) * 3.f * (2.f * zz - xx - yy) +
+                        R3_SH_C3_4 * R3_SH(13) * 4.f * 2.f * xz + R3_SH_C3_5 * R3_SH(14) * (xx - yy));
+            }
+        }
+#undef R3_SH
+        d9[3 * ch] = dx_;
+        d9[3 * ch + 1] = dy_;
+        d9[3 * ch + 2] = dz_;
+    }
+}
+
+// the forward's side of it: the direction exactly as sh_backward forms it
+template <class ShRow>
+R3_HD void sh_dir_derivs_at(int deg, const ShRow& sh, float mx, float my, float mz, const float* campos, float* d9)
+{
+    const float vx = mx - campos[0], vy = my - campos[1], vz = mz - campos[2];
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    sh_dir_derivs(deg, sh, vx / len, vy / len, vz / len, d9);
+}
+
 // backward.cu:20-172: colour gradient -> SH coefficients (+ L1 sparsity term on bands >= 1) and,
 // through the view direction, an extra contribution added to dmean.
-template <class ShRow, class ShGrad>
-R3_HD void sh_backward(int deg, const ShRow& sh, const ShGrad& dsh, float mx, float my, float mz, const float* campos,
-                       uint32_t clamp_bits, const float* dL_dcolor, float sparsity_mult, float* dmean)
+// CACHED: `d9` holds sh_dir_derivs of this Gaussian as the forward left them and `sh` is never read (the sparsity term
+// needs the coefficients' signs: callers take this form only with sparsity_mult == 0).
+template <bool CACHED, class ShRow, class ShGrad>
+R3_HD void sh_backward(int deg, const ShRow& sh, const ShGrad& dsh, const float* d9_cached, float mx, float my, float mz,
+                       const float* campos, uint32_t clamp_bits, const float* dL_dcolor, float sparsity_mult, float* dmean)
 {
     const float vx = mx - campos[0], vy = my - campos[1], vz = mz - campos[2];
     const float len = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -437,36 +487,16 @@ R3_HD void sh_backward(int deg, const ShRow& sh, const ShGrad& dsh, float mx, fl
     for (int ch = 0; ch < 3; ch++) dRGB[ch] = dL_dcolor[ch] * (((clamp_bits >> ch) & 1u) ? 0.f : 1.f);
     float ddir[3] = {0.f, 0.f, 0.f};
     if (deg > 0) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float d9[9];
+        if (CACHED) {
+            for (int k = 0; k < 9; k++) d9[k] = d9_cached[k];
+        } else {
+            sh_dir_derivs(deg, sh, x, y, z, d9);
+        }
         for (int ch = 0; ch < 3; ch++) {
-#define R3_SH(k) sh.at(3 * (k) + ch)
-            float dx_ = -R3_SH_C1 * R3_SH(3);
-            float dy_ = -R3_SH_C1 * R3_SH(1);
-            float dz_ = R3_SH_C1 * R3_SH(2);
-            if (deg > 1) {
-                dx_ += R3_SH_C2_0 * y * R3_SH(4) + R3_SH_C2_2 * 2.f * -x * R3_SH(6) + R3_SH_C2_3 * z * R3_SH(7) +
-                       R3_SH_C2_4 * 2.f * x * R3_SH(8);
-                dy_ += R3_SH_C2_0 * x * R3_SH(4) + R3_SH_C2_1 * z * R3_SH(5) + R3_SH_C2_2 * 2.f * -y * R3_SH(6) +
-                       R3_SH_C2_4 * 2.f * -y * R3_SH(8);
-                dz_ += R3_SH_C2_1 * y * R3_SH(5) + R3_SH_C2_2 * 2.f * 2.f * z * R3_SH(6) + R3_SH_C2_3 * x * R3_SH(7);
-                if (deg > 2) {
-                    dx_ += (R3_SH_C3_0 * R3_SH(9) * 3.f * 2.f * xy + R3_SH_C3_1 * R3_SH(10) * yz +
-                            R3_SH_C3_2 * R3_SH(11) * -2.f * xy + R3_SH_C3_3 * R3_SH(12) * -3.f * 2.f * xz +
-                            R3_SH_C3_4 * R3_SH(13) * (-3.f * xx + 4.f * zz - yy) + R3_SH_C3_5 * R3_SH(14) * 2.f * xz +
-                            R3_SH_C3_6 * R3_SH(15) * 3.f * (xx - yy));
-                    dy_ += (R3_SH_C3_0 * R3_SH(9) * 3.f * (xx - yy) + R3_SH_C3_1 * R3_SH(10) * xz +
-                            R3_SH_C3_2 * R3_SH(11) * (-3.f * yy + 4.f * zz - xx) +
-                            R3_SH_C3_3 * R3_SH(12) * -3.f * 2.f * yz + R3_SH_C3_4 * R3_SH(13) * -2.f * xy +
-                            R3_SH_C3_5 * R3_SH(14) * -2.f * yz + R3_SH_C3_6 * R3_SH(15) * -3.f * 2.f * xy);
-                    dz_ += (R3_SH_C3_1 * R3_SH(10) * xy + R3_SH_C3_2 * R3_SH(11) * 4.f * 2.f * yz +
-                            R3_SH_C3_3 * R3_SH(12) * 3.f * (2.f * zz - xx - yy) +
-                            R3_SH_C3_4 * R3_SH(13) * 4.f * 2.f * xz + R3_SH_C3_5 * R3_SH(14) * (xx - yy));
-                }
-            }
-#undef R3_SH
-            ddir[0] += dx_ * dRGB[ch];
-            ddir[1] += dy_ * dRGB[ch];
-            ddir[2] += dz_ * dRGB[ch];
+            ddir[0] += d9[3 * ch] * dRGB[ch];
+            ddir[1] += d9[3 * ch + 1] * dRGB[ch];
+            ddir[2] += d9[3 * ch + 2] * dRGB[ch];
         }
     }
     // dL/dsh is written only now: `dsh` may alias the storage `sh` reads from (LDS staging row reused in place),
@@ -477,7 +507,7 @@ R3_HD void sh_backward(int deg, const ShRow& sh, const ShGrad& dsh, float mx, fl
     for (int k = 0; k < K; k++)
         for (int ch = 0; ch < 3; ch++) {
             float g = Y[k] * dRGB[ch];
-            if (k >= 1 && sparsity_mult != 0.f) g = g + sparsity_mult * sign_(sh.at(3 * k + ch));
+            if (!CACHED && k >= 1 && sparsity_mult != 0.f) g = g + sparsity_mult * sign_(sh.at(3 * k + ch));
             dsh.put(3 * k + ch, g);
         }
     // auxiliary.h:107-117 dnormvdv

@@ -267,13 +267,22 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
         if (need_sh) {
             const float campos[3] = {a.view.campos[0], a.view.campos[1], a.view.campos[2]};
             const float mx = a.in.means3D[3 * i], my = a.in.means3D[3 * i + 1], mz = a.in.means3D[3 * i + 2];
-            if (rows48) {
-                const ShRowLds<true> row{s_sh[wave] + 49 * lane, 0};
+            // the colour, and -- while the row is here -- its derivatives with respect to the view direction, which is all
+            // the backward wants from the row (GeomState::sh_ddir)
+            auto eval = [&](const auto& row) {
                 sh_to_rgb(deg, row, mx, my, mz, campos, rgb, &cbits);
-            } else {
-                const ShRowLds<false> row{s_sh[wave], roff};
-                sh_to_rgb(deg, row, mx, my, mz, campos, rgb, &cbits);
-            }
+                if (!RAGGED && a.sh_ddir && deg > 0) {
+                    float d9[9];
+                    sh_dir_derivs_at(deg, row, mx, my, mz, campos, d9);
+                    float* o = a.sh_ddir + 9 * (size_t)i;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) o[k] = d9[k];
+                }
+            };
+            if (rows48)
+                eval(ShRowLds<true>{s_sh[wave] + 49 * lane, 0});
+            else
+                eval(ShRowLds<false>{s_sh[wave], roff});
         } else {
             rgb[0] = a.in.colors_precomp[3 * i];
             rgb[1] = a.in.colors_precomp[3 * i + 1];

@@ -193,7 +193,9 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     const long span_first = 3L * M * wave_first;
     float* lds = s_sh[wave];
     const bool wave_vis = __ballot(vis) != 0ull;
-    if (has_sh && wave_vis) {
+    // the forward left the SH direction derivatives and there is no sparsity term: the SH rows are not read at all
+    const bool cached = has_sh && a.sh_ddir != nullptr && a.header->sh_cache != 0u;
+    if (has_sh && wave_vis && !cached) {
         const float* src = a.in.shs + span_first;
         if (((span_first | span_len) & 3) == 0) {   // 16-B aligned span (always for M = 16): dwordx4 loads, six in
             const float4* src4 = reinterpret_cast<const float4*>(src);   // flight before the first LDS store (twelve, as in
@@ -292,7 +294,15 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
             }
             const int deg = a.in.degrees[i];
             K = (deg + 1) * (deg + 1);
-            sh_backward(deg, row, row, mx, my, mz, cam.campos, r.width_clamp >> 16, dcol, mult, dmean);
+            if (cached) {
+                float d9[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++)   // (a Gaussian binned into no tile got no colour and left nothing: its dcol is 0)
+                    d9[k] = (deg > 0 && ntile > 0u) ? a.sh_ddir[9 * (size_t)i + k] : 0.f;
+                sh_backward<true>(deg, row, row, d9, mx, my, mz, cam.campos, r.width_clamp >> 16, dcol, 0.f, dmean);
+            } else {
+                sh_backward<false>(deg, row, row, nullptr, mx, my, mz, cam.campos, r.width_clamp >> 16, dcol, mult, dmean);
+            }
         }
         if (a.in.scales) cov3d_backward(sc, cam.scale_modifier, q, dcov6, dscale, dq);
         dop = opacity_backward(dop, r.op);

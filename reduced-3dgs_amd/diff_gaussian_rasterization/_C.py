@@ -58,6 +58,8 @@ _lib.r3dgs_pass_pairs.argtypes = [C.c_longlong, _i]
 _lib.r3dgs_forward_pairs.restype = _i
 _lib.r3dgs_set_tight_rects.restype = _i
 _lib.r3dgs_set_tight_rects.argtypes = [_i]
+_lib.r3dgs_set_sh_cache.restype = _i
+_lib.r3dgs_set_sh_cache.argtypes = [_i]
 _lib.r3dgs_set_tile_order.restype = _i
 _lib.r3dgs_set_tile_order.argtypes = [_i]
 _lib.r3dgs_export_tile_order.restype = _i
@@ -556,6 +558,16 @@ def set_tight_rects(on):
 
 def tight_rects():
     return bool(_lib.r3dgs_set_tight_rects(-1))
+
+
+def set_sh_cache(on):
+    """True (default): a backward without a sparsity term uses the SH direction derivatives the forward left instead of
+    reading the SH tensor again; False: it reads the rows.  Same gradients, bit for bit.  Returns the previous setting."""
+    return bool(_lib.r3dgs_set_sh_cache(int(bool(on))))
+
+
+def sh_cache():
+    return bool(_lib.r3dgs_set_sh_cache(-1))
 
 
 def set_tile_order(on):

@@ -295,6 +295,9 @@ void hc_truncated_colours(int P, int M, int nslots, const int* degs, const float
     }
 }
 
+static long g_cached_mismatches = 0;
+long hc_cached_sh_mismatches(void) { return g_cached_mismatches; }
+
 void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const int* radii, const float* shs,
                        const unsigned* clamp_bits, const float* scales, const float* rots, float mod,
                        const float* cov_pre, const float* view, const float* proj, const float* campos, int W, int H,
@@ -324,7 +327,23 @@ void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const 
         if (shs) {
             ShRowPlain row{shs + 3 * (size_t)M * i};
             ShGradPlain sink{dL_dsh + 3 * (size_t)M * i};
-            sh_backward(degs[i], row, sink, mx, my, mz, cam.campos, clamp_bits[i], dL_dcolor + 3 * i, mult, dmean);
+            if (mult == 0.f) {
+                // as the product does without a sparsity term: the direction derivatives come from the forward
+                // (sh_dir_derivs_at); must equal the direct form bit for bit
+                float d9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (degs[i] > 0) sh_dir_derivs_at(degs[i], row, mx, my, mz, cam.campos, d9);
+                float direct_dsh[48], direct_dmean[3] = {dmean[0], dmean[1], dmean[2]};
+                ShGradPlain direct_sink{direct_dsh};
+                sh_backward<false>(degs[i], row, direct_sink, nullptr, mx, my, mz, cam.campos, clamp_bits[i], dL_dcolor + 3 * i,
+                                   mult, direct_dmean);
+                sh_backward<true>(degs[i], row, sink, d9, mx, my, mz, cam.campos, clamp_bits[i], dL_dcolor + 3 * i, mult, dmean);
+                const int K = (degs[i] + 1) * (degs[i] + 1);
+                g_cached_mismatches += memcmp(direct_dmean, dmean, 12) != 0;
+                g_cached_mismatches += memcmp(direct_dsh, dL_dsh + 3 * (size_t)M * i, 12 * (size_t)K) != 0;
+            } else {
+                sh_backward<false>(degs[i], row, sink, nullptr, mx, my, mz, cam.campos, clamp_bits[i], dL_dcolor + 3 * i, mult,
+                                   dmean);
+            }
         }
         memcpy(dL_dmean3D + 3 * i, dmean, 12);
         if (!cov_pre) cov3d_backward(sc, mod, q, dL_dcov3D + 6 * i, dL_dscale + 3 * i, dL_drot + 4 * i);

@@ -307,6 +307,32 @@ def test_backward_tile_order_changes_no_bit(C_, kw):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02),
+    dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3", scale_mu=0.012),
+], ids=["20k_mixed", "metric_500k_1600x1062"])
+def test_sh_direction_derivatives_from_the_forward_change_no_bit(C_, kw):
+    """Without a sparsity term the backward does not read the SH tensor: the forward's colour stream left the nine
+    d(colour)/d(view direction) numbers of every visible Gaussian while it had the row staged (set_sh_cache, on by
+    default).  Same expressions on the same inputs: every gradient must equal the row-reading backward's bit for bit."""
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+    g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw["scale_mu"])
+    bg = np.array([0.3, 0.1, 0.2], np.float32)
+    dl = ss.upstream_grad(W, H, seed=6) * (W * H)
+    assert C_.sh_cache()
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    from_forward = hip_backward(C_, fargs, fout, dl, 0.0)
+    was = C_.set_sh_cache(False)
+    try:
+        from_rows = hip_backward(C_, fargs, fout, dl, 0.0)
+    finally:
+        C_.set_sh_cache(was)
+    for a, b in zip(from_forward, from_rows):
+        assert torch.equal(a, b)
+    assert float(from_forward[3].abs().max()) > 0 and float(from_forward[5].abs().max()) > 0   # means3D, sh: not all zero
+
+
 @pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])
 def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     """Depth-sort corner cases of the bucketed sort (binning.hip): `plane` puts 20k splats at ONE depth (a single

@@ -37,10 +37,11 @@ CASES = [
     dict(P=500, W=72, H=50, f=60.0, cam_seed=None, gseed=0, degree_mode="all3", lam=0.0, spread=1.0),
     dict(P=500, W=70, H=45, f=60.0, cam_seed=2, gseed=1, degree_mode="mixed", lam=0.1, spread=1.0),
     dict(P=400, W=64, H=64, f=50.0, cam_seed=4, gseed=2, degree_mode="all0", lam=0.0, spread=1.35),
+    dict(P=500, W=70, H=45, f=60.0, cam_seed=3, gseed=5, degree_mode="mixed", lam=0.0, spread=1.0),
 ]
 
 
-@pytest.mark.parametrize("kw", CASES, ids=["deg3", "mixed_sparsity", "deg0_clamp"])
+@pytest.mark.parametrize("kw", CASES, ids=["deg3", "mixed_sparsity", "deg0_clamp", "mixed"])
 @pytest.mark.parametrize("precomp", [False, True], ids=["sh_scale_rot", "precomp_colour_cov"])
 def test_device_math_on_host_matches_oracle(kw, precomp):
     L = _lib()
@@ -153,6 +154,9 @@ def test_device_math_on_host_matches_oracle(kw, precomp):
                         p(rots), C.c_float(1.0), p(cov), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
                         C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(dm2), p(st["conic_op"]), p(dcon), p(dcol),
                         C.c_float(kw["lam"]), p(d3), p(dcov), p(dsh), p(dsc), p(drot), p(dop))
+    # without a sparsity term the product takes the SH direction derivatives from the forward: same bits as the direct form
+    L.hc_cached_sh_mismatches.restype = C.c_long
+    assert L.hc_cached_sh_mismatches() == 0
     close("dmean3D", gr["dL_dmeans3D"], d3, 1e-5)
     close("dcov3D", gr["dL_dcov3D"], dcov, 1e-5)
     close("dopacity", gr["dL_dopacity"].reshape(-1), dop)
