@@ -37,20 +37,8 @@
 
 namespace r3 {
 
-// A pointer read out of a pass block in memory is a generic pointer to the compiler: every access through it is a FLAT
-// instruction, which also counts on lgkmcnt -- so each wait for an LDS read would wait for the global gather in flight.
-// The blocks only ever hold device-global addresses.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define R3_GLOBAL __attribute__((address_space(1)))
-#else
-#define R3_GLOBAL   // host pass: the kernels are only parsed
-#endif
-template <class T>
-__device__ __forceinline__ R3_GLOBAL T* global_ptr(T* p)
-{
-    return (R3_GLOBAL T*)p;
-}
-
+// (pointers out of a pass block go through global_ptr(), common.h: FLAT accesses would count on lgkmcnt and every wait for an
+// LDS read would wait for the global gather in flight)
 constexpr int kChunk = 64;
 
 // debug builds only (tools/bwd_timeline.py): when and where every workgroup of the backward (-DR3_TIMELINE) or of the

@@ -336,6 +336,20 @@ struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// Pointers in the pass blocks are plain (generic) pointers; a load through one is a FLAT load, which also counts on the LDS
+// counter -- every wait for an LDS result then drains the memory loads in flight.  Kernels that keep loads in flight across LDS
+// work cast to the global address space first.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R3_GLOBAL __attribute__((address_space(1)))
+#else
+#define R3_GLOBAL   // host pass: the kernels are only parsed
+#endif
+template <class T>
+__device__ __forceinline__ R3_GLOBAL T* global_ptr(T* p)
+{
+    return (R3_GLOBAL T*)p;
+}
+
 // Runs f, turning exceptions into (-1, r3dgs_last_error()); defined in capi.hip, shared by every extern "C" TU.
 int guarded_call(const std::function<int()>& f);
 
