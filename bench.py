@@ -70,8 +70,10 @@ STAGE_KERNELS = {
                      ("r3::radix_hist_kernel<r3::IoNarrow>", 1, False),
                      ("r3::tile_ranges_kernel<r3::IoNarrow>", 1, True)],
     "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
-    "blend_bwd": [("r3::blend_bwd_kernel<4, true>", 1, True), ("r3::pair_reduce_kernel", 1, False)],
-    "preprocess_bwd": [("r3::preprocess_bwd_kernel", 1, False)],
+    # (the one-workgroup kernel that orders the tiles heaviest first runs inside this stage's events too)
+    "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
+                  ("r3::tile_order_kernel", 1, False)],
+    "preprocess_bwd": [("r3::preprocess_bwd_kernel<true>", 1, False)],
 }
 
 

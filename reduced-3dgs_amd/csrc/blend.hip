@@ -619,13 +619,16 @@ extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 
 // Launch order of the backward blend's tiles: heaviest first.  All tiles are resident at once for the first half of the
 // kernel and each wave's duration is set by how many share its SIMD, so in row-major order the chip drains for the whole
-// second half (profiles/r03_bwd_timeline.txt: 20 resident waves per CU for five tenths of a CU's span, then 17, 12, 9, 6,
+// second half (profiles/r03_bwd_timeline_row_major.txt: 20 resident waves per CU for five tenths of a CU's span, then 17, 12, 9, 6,
 // 3); started by decreasing weight, the long walks are under way when the short ones fill the gaps (0.367 -> 0.313 ms on
 // the metric shape).  Weight = sum over the four quadrants of the deepest contributor (ImageState::quad_depth): the
 // entries the wave will visit.  One workgroup, counting sort over 1024 weight classes; the order inside a class is
 // whatever the LDS atomics make it -- every tile's arithmetic is its own, so the gradients do not depend on the order
 // (tests/test_gpu_parity.py compares the two orders bit for bit).  The hardware deals consecutive workgroups over the
-// eight XCDs, i.e. every XCD gets every eighth tile of the sorted list: equal work per XCD as well.
+// eight XCDs, i.e. every XCD gets every eighth tile of the sorted list: equal work per XCD as well -- and every XCD's L2
+// now sees every Gaussian's record (the kernel's FETCH_SIZE went from 62 to 150 MB; 1.6 TB/s in total, nowhere near a
+// bound).  Keeping each XCD on its band of the image and ordering inside the band only (FETCH_SIZE 74 MB) measured
+// 0.315 ms against 0.305 ms for the stage: balance between the XCDs is worth more here than the locality.
 constexpr int kOrderThreads = 1024, kOrderClasses = 1024;
 __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {

@@ -26,8 +26,9 @@ shutil.copy(os.path.join(G, "pmc_summary.json"), os.path.join(P, f"{R}_pmc_summa
 # the cold visit (profiles/r03_valu_rate.txt, GPU call of its own), whose rates bench.py's VALU_CYCLES are
 shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate_warm.txt"))
 shutil.copy(os.path.join(G, "other_workloads.jsonl"), os.path.join(P, f"{R}_other_workloads.jsonl"))
-if os.path.exists(os.path.join(G, "bwd_timeline.txt")):
-    shutil.copy(os.path.join(G, "bwd_timeline.txt"), os.path.join(P, f"{R}_bwd_timeline.txt"))
+for tl in ("bwd_timeline", "fwd_timeline"):
+    if os.path.exists(os.path.join(G, tl + ".txt")):
+        shutil.copy(os.path.join(G, tl + ".txt"), os.path.join(P, f"{R}_{tl}.txt"))
 open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-40:]) +
                                                        "\n" + open(os.path.join(G, "smoke.log")).read()[-1200:])
 for wl, short in (("garden_like_2M_1600x1062", "garden_like_2M"), ("train_like_6M_1920x1080", "train_like_6M")):

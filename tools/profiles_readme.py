@@ -37,7 +37,7 @@ ks = kstats(f"{R}_kernel_stats_bench_500k_1600x1062.csv")
 ks2 = kstats("r02_kernel_stats_bench_500k_1600x1062.csv")
 pmc = json.load(open(os.path.join(P, f"{R}_pmc_summary.json")))
 st = d50["stages"]
-BWD, FWD = "r3::blend_bwd_kernel<4, true>", "r3::blend_fwd_kernel<1, false>"
+BWD, FWD = "r3::blend_bwd_kernel<4, true, false>", "r3::blend_fwd_kernel<1, false>"
 
 import bench  # noqa: E402  (the calibrated VALU floor is computed by bench.py's own function)
 vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", ks[BWD] / 1e3)
@@ -122,8 +122,8 @@ kept for comparison.
 | depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f}, `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
 | tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f} [{ks2['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}], `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f} [{ks2['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}], `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} — real traffic ≈ 9× lower |
 | blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks[FWD]:.1f} [{ks2[FWD]:.1f}] | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
-| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true>` {ks[BWD]:.1f} [{ks2[BWD]:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}] | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
-| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel` {ks['r3::preprocess_bwd_kernel']:.1f} [{ks2['r3::preprocess_bwd_kernel']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
+| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true, false>` {ks[BWD]:.1f} [{ks2['r3::blend_bwd_kernel<4, true>']:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}], `tile_order` {ks['r3::tile_order_kernel']:.1f} | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
+| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel` {ks['r3::preprocess_bwd_kernel<true>']:.1f} [{ks2['r3::preprocess_bwd_kernel']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
 
 ## What the VALU costs on this chip (`{R}_valu_rate.txt`) and what that says about the blend kernels
 
@@ -162,7 +162,7 @@ spills (27–75 VGPRs).
 {row(FWD)}
 {row(BWD)}
 {row('r3::pair_reduce_kernel')}
-{row('r3::preprocess_bwd_kernel')}
+{row('r3::preprocess_bwd_kernel<true>')}
 {row('r3::depth_sort_color_kernel<2, false>')}
 {row('r3::emit_pairs_kernel<r3::IoNarrow>')}
 {row('r3::radix_scatter_kernel<r3::IoNarrow, 7>')}

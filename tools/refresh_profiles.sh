@@ -35,6 +35,9 @@ done
 if [ -f reduced-3dgs_amd/libr3dgs_hip_tl.so ]; then
   ( timeout 200 python tools/bwd_timeline.py ) > gpurun_out/bwd_timeline.txt 2>&1; echo "timeline rc=$?" >> $S
 fi
+if [ -f reduced-3dgs_amd/libr3dgs_hip_tlf.so ]; then
+  ( timeout 200 python tools/bwd_timeline.py fwd ) > gpurun_out/fwd_timeline.txt 2>&1; echo "fwd timeline rc=$?" >> $S
+fi
 ( timeout 120 tools/valu_rate ) > gpurun_out/valu_rate.txt 2>&1; echo "valu rc=$?" >> $S
 if [ "${TESTS:-1}" = "1" ]; then
   ( timeout 900 python -m pytest tests -m gpu -x -q -s ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/pytest_gpu.log)" >> $S
