@@ -163,6 +163,10 @@ int r3dgs_set_tile_order(int on);
  * per Gaussian for exactly these nine numbers).  0: the backward reads the rows, as with a sparsity term.  Bit-identical
  * gradients either way.  Returns the previous setting (a negative argument only queries).  Also R3DGS_SH_CACHE=0. */
 int r3dgs_set_sh_cache(int on);
+/* r3dgs_forward_hint(0): the forwards this thread issues from now on will not be followed by a backward (rendering under
+ * no_grad): they leave no SH direction derivatives (their header says so; a backward on such a state reads the SH rows).
+ * r3dgs_forward_hint(1), the initial state: they do. */
+void r3dgs_forward_hint(int will_backward);
 
 /* Debug accessor: the forward's per-quadrant depths ([tiles][4] uint32: quadrant q = (x half) + 2 * (y half) of the
  * 16x16 tile) and, after a backward with the order on, the launch order it used ([tiles] uint32); device arrays, either

@@ -64,6 +64,7 @@ using namespace r3;
 
 thread_local std::string g_last_error;
 thread_local int g_last_forward_pairs = 0;   // r3dgs_forward_pairs()
+thread_local int g_next_forward_trains = 1;  // r3dgs_forward_hint(): holds for this thread's forwards until set again
 
 // Opacity-aware tile rects (gauss_math.h tighten_rect) are the default; R3DGS_TIGHT_RECT=0 / r3dgs_set_tight_rects(0)
 // bins into the reference's 3-sigma squares (identical lists to the reference's: the bit-exact binning tests).
@@ -645,7 +646,8 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.pre.radii = radii;
     a.pre.color_blocks = (c.P + kPreBlockSize - 1) / kPreBlockSize;
     a.pre.tight = p.tight;
-    a.pre.sh_ddir = (!p.ragged && c.shs && !c.colors_precomp) ? g.sh_ddir : nullptr;
+    // (a forward that its caller knows no backward will follow -- r3dgs_forward_hint(0) -- leaves nothing; the header says so)
+    a.pre.sh_ddir = (g_next_forward_trains && !p.ragged && c.shs && !c.colors_precomp) ? g.sh_ddir : nullptr;
 
     a.header.parts = g.partials;
     a.header.n_parts = (int)pre_partials((size_t)c.P);
@@ -1154,6 +1156,8 @@ int r3dgs_set_tight_rects(int on)   // on < 0: query only
     if (on >= 0) g_tight_rects.store(on ? 1 : 0);
     return before;
 }
+
+void r3dgs_forward_hint(int will_backward) { g_next_forward_trains = will_backward ? 1 : 0; }
 
 int r3dgs_set_sh_cache(int on)   // on < 0: query only
 {

@@ -58,6 +58,8 @@ _lib.r3dgs_pass_pairs.argtypes = [C.c_longlong, _i]
 _lib.r3dgs_forward_pairs.restype = _i
 _lib.r3dgs_set_tight_rects.restype = _i
 _lib.r3dgs_set_tight_rects.argtypes = [_i]
+_lib.r3dgs_forward_hint.restype = None
+_lib.r3dgs_forward_hint.argtypes = [_i]
 _lib.r3dgs_set_sh_cache.restype = _i
 _lib.r3dgs_set_sh_cache.argtypes = [_i]
 _lib.r3dgs_set_tile_order.restype = _i
@@ -374,6 +376,10 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
     touched = transm = None
     if counters is not None:
         touched, transm = counters
+    global _next_forward_trains
+    trains = torch.is_grad_enabled() if _next_forward_trains is None else _next_forward_trains
+    _lib.r3dgs_forward_hint(int(trains))   # holds for the redo of an overflowed pass as well
+    _next_forward_trains = None
     with _on_device(dev):
         tail = (_ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot),
                 _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
@@ -558,6 +564,17 @@ def set_tight_rects(on):
 
 def tight_rects():
     return bool(_lib.r3dgs_set_tight_rects(-1))
+
+
+_next_forward_trains = None   # None: nobody said -- a forward issued under torch.no_grad() is taken as a rendering
+
+
+def hint_next_forward(will_backward):
+    """The autograd wrapper says whether any input of the forward it is about to issue needs a gradient.  A forward that
+    no backward will follow (rendering under no_grad) skips what it would only do for the backward's sake (the SH direction
+    derivatives, 36 B per visible Gaussian).  One-shot: the call after the next forward trains again."""
+    global _next_forward_trains
+    _next_forward_trains = bool(will_backward)
 
 
 def set_sh_cache(on):

@@ -68,6 +68,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, degrees,
                 rs.campos, rs.prefiltered, rs.debug)
+        _C.hint_next_forward(any(ctx.needs_input_grad))   # rendering under no_grad: nothing is kept for a backward's sake
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _call_native(
             _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump")
         ctx.raster_settings = rs
