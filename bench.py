@@ -36,6 +36,7 @@ import synth_scene as ss  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
 PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 VALU_RATE = os.path.join("profiles", "r03_valu_rate.txt")
+KERNEL_STATS = os.path.join("profiles", "r03_kernel_stats_bench_500k_1600x1062.csv")
 
 
 CLOCK_WARMUP_STEPS = 50   # untimed, ahead of the --warmup steps (see main())
@@ -104,10 +105,25 @@ VALU_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_I
                "SQ_INSTS_VALU_TRANS_F32": 8.1, "SQ_INSTS_VALU_INT32": 4.1, "SQ_INSTS_VALU_CVT": 4.1, "other": 4.1}
 
 
-def pmc_valu(stage, workload, kernel_ms, path=None, simds=1024, ghz=2.4):
+def committed_kernel_ms(kernel, path=None):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command, or None."""
+    import csv
+    path = path or os.path.join(ROOT, KERNEL_STATS)
+    if not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["Name"].replace("void ", "").split("(")[0] == kernel:
+            return float(r["AverageNs"]) / 1e6
+    return None
+
+
+def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):
     """VALU-issue view of the stage's first (main) kernel from the committed PMC passes: the two blend kernels are bound
     by VALU issue, which an HBM fraction cannot express.  floor_ms = the time 1024 SIMDs need to
-    issue the kernel's VALU instructions at the per-class rates measured by tools/valu_rate.hip; frac = floor / measured."""
+    issue the kernel's VALU instructions at the per-class rates measured by tools/valu_rate.hip.  The stage timer of this
+    run covers the stage's other kernels too (pair_reduce and the tile order for blend_bwd), so kernel_ms = this run's
+    stage time minus those kernels' committed averages (the committed average of the kernel itself is given beside it)
+    and frac = floor / kernel_ms; frac_of_stage = floor / the stage time as measured."""
     path = path or os.path.join(ROOT, PMC_SUMMARY)
     if workload != "metric_500k_1600x1062" or stage not in STAGE_KERNELS or not os.path.exists(path):
         return None
@@ -119,11 +135,16 @@ def pmc_valu(stage, workload, kernel_ms, path=None, simds=1024, ghz=2.4):
     other = max(0.0, c["SQ_INSTS_VALU"] - sum(classes.values()))
     cycles = sum(VALU_CYCLES[n] * v for n, v in classes.items()) + VALU_CYCLES["other"] * other
     floor_ms = cycles / simds / (ghz * 1e9) * 1e3
+    others = [committed_kernel_ms(n) for n, _, _ in STAGE_KERNELS[stage][1:]]
+    committed = committed_kernel_ms(k)
+    kernel_ms = stage_ms - sum(others) if (stage_ms and all(o is not None for o in others)) else stage_ms
     out = {"kernel": k, "insts": int(c["SQ_INSTS_VALU"]),
            "insts_by_class": {n.replace("SQ_INSTS_VALU_", "").lower(): int(v) for n, v in classes.items()} | {"other": int(other)},
            "cycles_per_class": {n.replace("SQ_INSTS_VALU_", "").lower(): v for n, v in VALU_CYCLES.items()},
-           "floor_ms": round(floor_ms, 4), "kernel_ms": round(kernel_ms, 4),
+           "floor_ms": round(floor_ms, 4), "stage_ms": round(stage_ms, 4), "kernel_ms": round(kernel_ms, 4),
+           "kernel_ms_committed_profile": round(committed, 4) if committed else None,
            "frac": round(floor_ms / kernel_ms, 3) if kernel_ms else None,
+           "frac_of_stage": round(floor_ms / stage_ms, 3) if stage_ms else None,
            "assumes": f"{simds} SIMDs at {ghz} GHz", "source": f"{PMC_SUMMARY}, {VALU_RATE}"}
     if "SQ_ACTIVE_INST_VALU" in c:   # what the SQ itself reports per instruction (quad-cycles, per wave: >= 4)
         out["sq_active_cycles_per_inst"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2)

@@ -331,6 +331,13 @@ def test_sh_direction_derivatives_from_the_forward_change_no_bit(C_, kw):
     for a, b in zip(from_forward, from_rows):
         assert torch.equal(a, b)
     assert float(from_forward[3].abs().max()) > 0 and float(from_forward[5].abs().max()) > 0   # means3D, sh: not all zero
+    # a forward issued as a rendering (under no_grad: r3dgs_forward_hint(0)) leaves no derivatives and says so in its
+    # header: a backward on its state must notice and read the rows
+    with torch.no_grad():
+        fargs_r, fout_r = hip_forward(C_, bg, g, cam, H, W)
+    assert torch.equal(fout_r[1], fout[1])
+    for a, b in zip(from_forward, hip_backward(C_, fargs_r, fout_r, dl, 0.0)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("mode", ["plane", "few_depths", "two_far_apart"])

@@ -40,8 +40,11 @@ st = d50["stages"]
 BWD, FWD = "r3::blend_bwd_kernel<4, true, false>", "r3::blend_fwd_kernel<1, false>"
 
 import bench  # noqa: E402  (the calibrated VALU floor is computed by bench.py's own function)
-vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", ks[BWD] / 1e3)
-vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", ks[FWD] / 1e3)
+vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", st["blend_bwd"]["avg_ms"])
+vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", st["blend_fwd"]["avg_ms"])
+for v_ in (vb, vf):   # this file prices the kernels of the committed kernel trace
+    v_["kernel_ms"] = v_["kernel_ms_committed_profile"]
+    v_["frac"] = round(v_["floor_ms"] / v_["kernel_ms"], 3)
 
 
 def row(k):
@@ -73,6 +76,9 @@ timeline = ""
 tl_path = os.path.join(P, f"{R}_bwd_timeline.txt")
 if os.path.exists(tl_path):
     timeline = "".join(l for l in open(tl_path) if not l.startswith("/opt"))
+fwd_timeline = ""
+if os.path.exists(os.path.join(P, f"{R}_fwd_timeline.txt")):
+    fwd_timeline = "".join(l for l in open(os.path.join(P, f"{R}_fwd_timeline.txt")) if not l.startswith("/opt"))
 
 new = f'''# profiles/ — measurements on MI355X (round 3)
 
@@ -94,7 +100,8 @@ kept for comparison.
 | `{R}_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
 | `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` and `roofline.valu` |
 | `{R}_valu_rate.txt`, `{R}_valu_rate_warm.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` (the first from a visit that ran nothing else, the second at the end of the refresh visit, on a warm chip: the wall-clock rates are ~10 % lower there, the clock having come down) |
-| `{R}_bwd_timeline.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran |
+| `{R}_bwd_timeline.txt`, `{R}_fwd_timeline.txt` | `tools/bwd_timeline.py [fwd]` (debug builds `-DR3_TIMELINE` / `-DR3_TIMELINE_FWD`): when and where every workgroup of the backward / forward blend ran |
+| `{R}_bwd_timeline_row_major.txt` | the same for the backward blend before its tiles were started heaviest first (mid-round build, 5 waves per SIMD) |
 | `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
 | `{R}_kernel_stats_garden_like_2M.csv`, `{R}_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads |
 | `{R}_gpu_tests.txt` | tail of `pytest tests -m gpu -s` (achieved gradient errors, the own-loop report) and the smoke line of that visit |
@@ -146,14 +153,24 @@ reductions are counted as `add_f32` here although they cost 4.2 cycles, so the f
 {timeline.strip()}
 ```
 
-i.e. a workgroup lives ~0.15 ms of the kernel's ~0.34 ms; five fit per SIMD (95 VGPRs), 6.5 exist: for the first half of a
-CU's span 20–22 are resident, then the residency decays to 3 (utilisation below 3 waves per SIMD falls off because a lone
-wave issues one VALU instruction per ~5 cycles), and CUs that happened to receive 29 workgroups instead of 26 finish ~15 %
-after the median.  Tried against that in this round, all measured on this workload (DESIGN.md §6): two waves per tile
-(13 400 half-tile waves, 6–7 per SIMD, the halves' sums joined per chunk in LDS): 0.373–0.383 ms for the stage against 0.378–0.381;
-`v_permlane16/32_swap` instead of the two `ds_bpermute` of the reduction: +2 %; hand-packed `v_pk_*_f32` x/y and r/g arithmetic:
-+4 % (forward) / +6 % (backward) — consistent with the rates above; no register prefetch / occupancy 6, 7, 8 by launch bounds:
-spills (27–75 VGPRs).
+i.e. with the tiles started heaviest first (`blend.hip tile_order_kernel`) a CU is full — 24 single-wave workgroups at 80
+registers — for seven tenths of its span and the CUs end within ~9 % of each other; the longest workgroup lives for the
+whole span of its CU, so the kernel is as long as its heaviest tile is slow.  In row-major order
+(`{R}_bwd_timeline_row_major.txt`, taken earlier in the round at 5 per SIMD) the residency decayed from the middle of the
+span on (20, 20, 20, 22, 22, 17, 12, 9, 6, 3) and the kernel took 0.340 ms instead of {ks[BWD] / 1e3:.3f}.  The forward
+blend's 26 800 one-wave workgroups (`{R}_fwd_timeline.txt`) show the same kind of tail, without a predictor to order by:
+
+```
+{fwd_timeline.strip()}
+```
+
+Tried against the backward's remaining tail, all measured on this workload (DESIGN.md §6): two waves for the heaviest tiles
+(0.348–0.352 ms for the stage against 0.305), `s_setprio` for the heaviest workgroups (no change), 16 / 20 resident
+workgroups per CU instead of 24 (0.343 / 0.329 ms), 28 / 32 by launch bounds (35 / 59 spilled registers: 0.327 / 0.343 ms),
+a banded order that keeps each XCD on its part of the image (0.315 ms, FETCH_SIZE 74 instead of 150 MB).  Earlier in the
+round, before the tile order: two waves per tile for every tile 0.373–0.383 against 0.378–0.381 ms; `v_permlane16/32_swap`
+instead of the two `ds_bpermute` of the reduction +2 %; hand-packed `v_pk_*_f32` x/y and r/g arithmetic +4 % (forward) /
++6 % (backward) — consistent with the rates above.
 
 ## PMC view (per launch; FETCH_SIZE raw, before the ×2 correction for 16-B/lane loads)
 
