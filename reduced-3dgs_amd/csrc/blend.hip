@@ -622,7 +622,8 @@ extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 // second half (profiles/r03_bwd_timeline_row_major.txt: 20 resident waves per CU for five tenths of a CU's span, then 17, 12, 9, 6,
 // 3); started by decreasing weight, the long walks are under way when the short ones fill the gaps (0.367 -> 0.313 ms on
 // the metric shape).  Weight = sum over the four quadrants of the deepest contributor (ImageState::quad_depth): the
-// entries the wave will visit.  One workgroup, counting sort over 1024 weight classes; the order inside a class is
+// entries the wave will visit.  One workgroup, counting sort over 1024 weight classes (64 classes: +2 us for the stage,
+// 16: +10, 4: +22); the order inside a class is
 // whatever the LDS atomics make it -- every tile's arithmetic is its own, so the gradients do not depend on the order
 // (tests/test_gpu_parity.py compares the two orders bit for bit).  The hardware deals consecutive workgroups over the
 // eight XCDs, i.e. every XCD gets every eighth tile of the sorted list: equal work per XCD as well -- and every XCD's L2
