@@ -48,7 +48,7 @@ def quat_to_R(q):
 
 def render(means3D, opacity_raw, scales, rotations, sh, degrees, viewmatrix, projmatrix, campos, bg,
            W, H, tan_fovx, tan_fovy, scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None,
-           lambda_sh_sparsity=0.0, tiled=False):
+           lambda_sh_sparsity=0.0, tiled=False, geo_out=None):
     """Returns (color[3,H,W], radii[P], sh_sparsity_loss).  All float tensors share one dtype
     (use float64 for gradient ground truth).  `viewmatrix`/`projmatrix` are the transposed
     (row-vector) matrices exactly as the reference passes them."""
@@ -132,6 +132,11 @@ def render(means3D, opacity_raw, scales, rotations, sh, degrees, viewmatrix, pro
     order = torch.sort(depth32, stable=True).indices
     order = order[vis[order]]
     geo = dict(mx=mx, my=my, cA=cA, cB=cB, cC=cC, o=o, rgb=rgb, rminx=rminx, rminy=rminy, rmaxx=rmaxx, rmaxy=rmaxy)
+    if geo_out is not None:   # this forward's per-Gaussian quantities (for oracle.backward_f64's pin test)
+        geo_out.update(xy=torch.stack([mx, my], 1).detach().numpy(),
+                       conic_op=torch.stack([cA, cB, cC, o], 1).detach().numpy(), colors=rgb.detach().numpy(),
+                       cov3D=torch.stack([Sigma[:, 0, 0], Sigma[:, 0, 1], Sigma[:, 0, 2], Sigma[:, 1, 1], Sigma[:, 1, 2],
+                                          Sigma[:, 2, 2]], 1).detach().numpy())
     if tiled:
         # Tile by tile, each tile against the Gaussians whose rect covers it (what the binning hands the blend kernel):
         # O(256 * n_tile) work per tile instead of O(N * P), which makes BASELINE.json configs[0] (10k Gaussians,

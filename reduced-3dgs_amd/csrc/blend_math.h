@@ -41,8 +41,11 @@ struct Splat {
 // q(d) = 0.5*(A dx^2 + C dy^2) + B dx dy, one exact minimisation of q over a pixel rectangle decides for the
 // whole rectangle.  The blend kernels run this once per (entry, 8x8 quadrant) -- one lane per entry, while the
 // entry is being staged -- and skip entries/quadrants that provably contribute nothing.  The skip is
-// conservative (2e-3 margin >> fp32 rounding of either evaluation), so every per-pixel decision, n_contrib and
-// the image are exactly what they are without it.
+// conservative: a 2e-3 margin, and on top of it the cancellation margin of gauss_math.h tighten_rect -- an anisotropic
+// splat seen at an angle has q = a small difference of large products, whose fp32 evaluation (the reference's, the
+// oracle's, this library's) is only good to a relative ~1.6e-6 kappa, kappa = AC / (AC - B^2); tau is divided by
+// 1 - 4e-6 kappa and a splat with kappa > 6e4 is never skipped.  So every per-pixel decision, n_contrib and the image
+// are exactly what they are without the pre-test.
 
 // min over pixels (px,py) in [X0,X1]x[Y0,Y1] of q(x-px, y-py); requires A > 0 and C > 0
 R3_HD float region_qmin(float x, float y, float A, float B, float C, float X0, float X1, float Y0, float Y1)
@@ -72,7 +75,10 @@ R3_HD bool region_may_contribute(const Splat& s, float X0, float X1, float Y0, f
     if (!(s.cA > 0.f) || !(s.cC > 0.f)) return true;  // degenerate conic: never skip
     const float tau = 0.6931471805599453f * R3_LOG2(255.0f * s.op);   // alpha >= 1/255  <=>  q <= tau
     const float qmin = region_qmin(s.x, s.y, s.cA, s.cB, s.cC, X0, X1, Y0, Y1);
-    return !(qmin > tau + 2e-3f * fabsf(tau) + 2e-3f);  // NaN anywhere => keep
+    const float ac = s.cA * s.cC, det = fmaf(-s.cB, s.cB, ac);
+    const float keep = 1.0f - 4e-6f * (ac * R3_RCP(det));             // 1 - r; det <= 0 or kappa > 6e4: never skip
+    if (!(det > 0.f) || !(keep > 0.75f)) return true;
+    return !(qmin * keep > tau + 2e-3f * fabsf(tau) + 2e-3f);  // NaN anywhere => keep
 }
 
 // The same 9 floats with the conic pre-scaled so that  log2(G) = qa*dx^2 + qb*dx*dy + qc*dy^2  (G = exp(power) of

@@ -277,20 +277,34 @@ struct PreOut {
 // the half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) (cov = conic^-1, the +0.3 low-pass included): tiles of the
 // reference's rect outside that box hold no pixel the Gaussian can touch, so leaving them out of the lists changes no
 // pixel decision, i.e. neither the image nor any gradient -- only the lists get shorter (35 % fewer pairs at the
-// benchmark shape).  Conservative on purpose: tau is taken 0.2 % + 2e-3 larger (the margin of the blend kernels' region
-// pre-test, blend_math.h), the box 0.2 % + half a pixel wider; a conic that is not positive definite, or any NaN, keeps the
-// reference's rect.  tests/test_gpu_parity.py checks every left-out (tile, Gaussian) pair pixel by pixel with the oracle.
+// benchmark shape).
+// Conservative against the REFERENCE's fp32 evaluation of q, not only against the exact one: the per-pixel
+// test forms q from three products that cancel for an anisotropic splat seen at an angle, sum |terms| <= 4 kappa q with
+// kappa = cov_xx cov_yy / det >= 1 (= AC / (AC - B^2) of the conic; 1 for an axis-aligned splat), and the conic itself
+// carries the rounding of det = ac - b^2 (relative 2 eps kappa, a common factor of q).  A pixel with exact q > tau can
+// therefore pass the fp32 test as long as q (1 - r) <= tau, r ~ 26 eps kappa = 1.6e-6 kappa (eps = 2^-24).  tau is taken
+// 0.2 % + 2e-3 larger as before (the margin of the blend kernels' region pre-test, blend_math.h) and then divided by
+// 1 - 4e-6 kappa; kappa > 6e4 (r > 0.25: a needle whose far pixels the fp32 test decides by rounding) keeps the
+// reference's rect.  The box is 0.2 % + half a pixel wider; a conic that is not positive definite, or any NaN, keeps the
+// reference's rect.  tests/test_gpu_parity.py checks every left-out (tile, Gaussian) pair pixel by pixel with the oracle,
+// tests/test_hostcheck.py does the same on the CPU with needle scenes (median radius 500 px).
+constexpr float kCancelMargin = 4e-6f;   // per unit of kappa; shared with blend_math.h region_may_contribute
+
 R3_HD void tighten_rect(float px, float py, float a, float b, float c, float opacity, int* rmin, int* rmax)
 {
-    if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return;
+    const float det = a * c - b * b;
+    if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return;
+    const float r = kCancelMargin * ((a * c) / det);
+    if (!(r < 0.25f)) return;
     float tau = logf(255.0f * opacity);
     tau = tau + 2e-3f * fabsf(tau) + 2e-3f;
     if (!(tau == tau)) return;
-    if (!(tau > 0.f)) {   // opacity below 1/255 (with margin): alpha < 1/255 everywhere
+    if (!(tau > 0.f)) {   // opacity below 1/255 (with margin): alpha <= opacity < 1/255 everywhere (power <= 0 where blended)
         rmax[0] = rmin[0];
         rmax[1] = rmin[1];
         return;
     }
+    tau = tau / (1.0f - r);
     const float hx = sqrtf(2.f * tau * a) * 1.002f + 0.5f, hy = sqrtf(2.f * tau * c) * 1.002f + 0.5f;
     if (!(hx == hx) || !(hy == hy)) return;
     // pixels are at integer coordinates: those with |px - x| <= hx lie in tiles floor((x - hx) / 16) .. floor((x + hx) / 16)

@@ -122,9 +122,8 @@ def check_forward(C_, fout, ref, H, W, P):
     return ok
 
 
-GRAD_REL_COV_CHAIN = 1.5e-4   # dL_dcov3D / dL_dscales / dL_drotations (see the module docstring); measured worst: 9.4e-5
 ELEM_OK_FRACTION = 0.999
-achieved = {}               # name -> largest (max-normalised error, fraction of elements outside the per-element bar) seen
+achieved = {}               # name -> [largest max-normalised error, fraction of elements outside the per-element bar, test id]
 
 
 def mask_ambiguous(dl, ref):
@@ -136,32 +135,55 @@ def mask_ambiguous(dl, ref):
     return d
 
 
-def grads_close(name, ref, got, rel=GRAD_REL, per_element=True):
-    got = got.cpu().numpy().reshape(ref.shape)
+def _note(name, err, bad):
+    a = achieved.get(name, [0.0, 0.0, ""])
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    achieved[name] = [max(a[0], err), max(a[1], bad), test if err > a[0] else a[2]]
+
+
+def grads_close(name, ref, got, rel=GRAD_REL, per_element=True, check=True):
+    got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+    got = got.reshape(ref.shape)
     scale = np.abs(ref).max() + 1e-30
     e = np.abs(ref - got)
     err = e.max() if e.size else 0.0
     bad = float((e > 1e-4 * np.abs(ref) + 1e-6 * scale).mean()) if e.size else 0.0
-    a = achieved.get(name, (0.0, 0.0))
-    achieved[name] = (max(a[0], float(err / scale)), max(a[1], bad))
+    _note(name, float(err / scale), bad)
+    if not check:
+        return float(err / scale)
     assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} ({err / scale:.2e} rel)"
     if per_element:
         assert 1.0 - bad >= ELEM_OK_FRACTION, f"{name}: {bad:.5f} of the elements outside 1e-4 |ref| + 1e-6 max|ref|"
+    return float(err / scale)
 
 
-def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True):
+def oracle_backward(ref, dl, lam):
+    """(fp32 restatement of backward.cu, the same gradients evaluated in double): oracle/raster_oracle.c follows the
+    reference's fp32 arithmetic term by term; oracle/backward_f64.c is the exact gradient of the function the forward
+    evaluated, derived independently and pinned to fp64 autograd at 1e-10 (tests/test_oracle_f64.py)."""
+    return orc.backward(ref["state"], dl, lam), orc.backward_f64(ref["state"], dl, lam)
+
+
+def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None):
+    """Every gradient tensor of the HIP path against the fp32 oracle `gr` AND, when given, against the double-precision
+    evaluation `gr64` -- both at north_star's 1e-4 of the tensor's maximum, plus the per-element criterion against the
+    fp32 oracle.  The fp32 oracle's own distance from the double evaluation is recorded next to it: two fp32 evaluations
+    may each sit on either side of the exact value."""
     (dm2, dcol, dop, dm3, dcov, dsh, dsc, drot, dconic) = bout
-    chain = max(rel, GRAD_REL_COV_CHAIN)
-    grads_close("dL_dmeans2D", gr["dL_dmeans2D"], dm2, rel, per_element)
-    grads_close("dL_dconic", gr["dL_dconic"][:, [0, 1, 3]], dconic.reshape(-1, 4)[:, [0, 1, 3]], rel, per_element)
-    grads_close("dL_dcolors", gr["dL_dcolors"], dcol, rel, per_element)
-    grads_close("dL_dopacity", gr["dL_dopacity"], dop, rel, per_element)
-    grads_close("dL_dmeans3D", gr["dL_dmeans3D"], dm3, rel, per_element)
-    grads_close("dL_dcov3D", gr["dL_dcov3D"], dcov, chain, per_element)
+    pairs = [("dL_dmeans2D", dm2, None), ("dL_dconic", dconic.reshape(-1, 4)[:, [0, 1, 3]], [0, 1, 3]), ("dL_dcolors", dcol, None),
+             ("dL_dopacity", dop, None), ("dL_dmeans3D", dm3, None), ("dL_dcov3D", dcov, None)]
     if M:
-        grads_close("dL_dsh", gr["dL_dsh"], dsh, rel, per_element)
-    grads_close("dL_dscales", gr["dL_dscales"], dsc, chain, per_element)
-    grads_close("dL_drotations", gr["dL_drotations"], drot, chain, per_element)
+        pairs.append(("dL_dsh", dsh, None))
+    pairs += [("dL_dscales", dsc, None), ("dL_drotations", drot, None)]
+    for name, got, cols in pairs:
+        r32 = gr[name] if cols is None else gr[name][:, cols]
+        grads_close(name, r32, got, rel, per_element)
+        if gr64 is not None:
+            r64 = gr64[name] if cols is None else gr64[name][:, cols]
+            r64 = r64.reshape(r32.shape)
+            grads_close(name + " [hip vs f64]", r64, got.double() if hasattr(got, "double") else got, max(rel, GRAD_REL),
+                        per_element=False)
+            grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
     for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):
@@ -184,8 +206,8 @@ def test_golden_cases_forward_backward(C_, golden_dir, name):
     fargs, fout = hip_forward(C_, bg, g, cam, H, W, debug=True)
     check_forward(C_, fout, ref, H, W, P)
     dlm = mask_ambiguous(dl, ref)
-    check_backward(hip_backward(C_, fargs, fout, dlm, kw["lam"], debug=True), orc.backward(ref["state"], dlm, kw["lam"]),
-                   ref["state"], 16)
+    gr, gr64 = oracle_backward(ref, dlm, kw["lam"])
+    check_backward(hip_backward(C_, fargs, fout, dlm, kw["lam"], debug=True), gr, ref["state"], 16, gr64=gr64)
     bout = hip_backward(C_, fargs, fout, dl, kw["lam"], debug=True)   # the committed fixture holds the unmasked gradients
     z = np.load(os.path.join(golden_dir, f"oracle_case_{name}.npz"))
     assert fout[0] == int(z["num_rendered"])
@@ -220,9 +242,9 @@ def test_oracle_parity_larger(C_, kw):
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=2) * (W * H), ref)
     fargs, fout = hip_forward(C_, bg, g, cam, H, W)
     check_forward(C_, fout, ref, H, W, P)
-    gr = orc.backward(ref["state"], dl, kw["lam"])
+    gr, gr64 = oracle_backward(ref, dl, kw["lam"])
     bout = hip_backward(C_, fargs, fout, dl, kw["lam"])
-    check_backward(bout, gr, ref["state"], 16)
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64)
 
 
 @pytest.mark.parametrize("kw", [
@@ -241,14 +263,14 @@ def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
     bg = np.array([0.1, 0.4, 0.9], np.float32)
     ref = oracle_forward(bg, g, cam, H, W)
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=2) * (W * H), ref)
-    gr = orc.backward(ref["state"], dl, kw["lam"])
+    gr, gr64 = oracle_backward(ref, dl, kw["lam"])
     was = C_.set_tight_rects(False)
     try:
         fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
         assert fout[0].pairs == int(fout[0]) == ref["num_rendered"]
         check_forward(C_, fout, ref, H, W, P)
         bout = hip_backward(C_, fargs, fout, dl, kw["lam"])
-        check_backward(bout, gr, ref["state"], 16)
+        check_backward(bout, gr, ref["state"], 16, gr64=gr64)
         _, fout_r = hip_forward(C_, bg, g, cam, H, W)          # reserved path, same mode
         assert fout_r[0].pairs == fout[0].pairs and torch.equal(fout_r[1], fout[1])
     finally:
@@ -263,7 +285,7 @@ def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
     # (and what comes out of the covariance chain amplifies that rounding, as everywhere)
     names = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations", "conic")
     for n, a, b in zip(names, bout, bout_t):
-        tol = GRAD_REL_COV_CHAIN if n in ("cov3D", "scales", "rotations") else 2e-5
+        tol = GRAD_REL if n in ("cov3D", "scales", "rotations") else 2e-5
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-30, n
 
 
@@ -364,9 +386,9 @@ def test_depth_sort_ties_and_bucket_overflow(C_, mode):
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=3) * (W * H), ref)
     fargs, fout = hip_forward(C_, bg, g, cam, H, W, debug=True)
     check_forward(C_, fout, ref, H, W, P)
-    gr = orc.backward(ref["state"], dl, 0.05)
+    gr, gr64 = oracle_backward(ref, dl, 0.05)
     bout = hip_backward(C_, fargs, fout, dl, 0.05, debug=True)
-    check_backward(bout, gr, ref["state"], 16)
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64)
     # the same through the asynchronous path (graph replay; the library may also route it through the generic sort
     # once it has seen the overflow hint): identical integers and image
     _, fout2 = hip_forward(C_, bg, g, cam, H, W)
@@ -393,9 +415,9 @@ def test_edge_sizes_long_lists_and_scale_modifier(C_, kw):
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=6) * (W * H), ref)
     fargs, fout = hip_forward(C_, bg, g, cam, H, W, mod=mod)
     check_forward(C_, fout, ref, H, W, P)
-    gr = orc.backward(ref["state"], dl, 0.02)
+    gr, gr64 = oracle_backward(ref, dl, 0.02)
     bout = hip_backward(C_, fargs, fout, dl, 0.02)
-    check_backward(bout, gr, ref["state"], 16)
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64)
     if kw["scale_mu"] > 1.0:
         rng_ = ref["state"]["ranges"].astype(np.int64)
         assert (rng_[:, 1] - rng_[:, 0]).max() > 1500  # really exercises multi-chunk lists
@@ -414,9 +436,9 @@ def test_precomputed_colour_and_covariance(C_):
     fargs, fout = hip_forward(C_, bg, g, cam, H, W, colors=colors, cov=cov, use_sh=False, use_sr=False)
     check_forward(C_, fout, ref, H, W, P)
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=4) * (W * H), ref)
-    gr = orc.backward(ref["state"], dl, 0.0)
+    gr, gr64 = oracle_backward(ref, dl, 0.0)
     bout = hip_backward(C_, fargs, fout, dl, 0.0)
-    check_backward(bout, gr, ref["state"], 0)
+    check_backward(bout, gr, ref["state"], 0, gr64=gr64)
     assert (bout[6] == 0).all() and (bout[7] == 0).all() and bout[5].shape == (P, 0, 3)
 
 
@@ -447,8 +469,8 @@ def test_autograd_wrapper_like_render(C_):
     grads_close("means3D", gr["dL_dmeans3D"], leaves["means3D"].grad)
     grads_close("means2D", gr["dL_dmeans2D"], means2D.grad)
     grads_close("opacity", gr["dL_dopacity"], leaves["opacity"].grad)
-    grads_close("scales", gr["dL_dscales"], leaves["scales"].grad, GRAD_REL_COV_CHAIN)
-    grads_close("rotations", gr["dL_drotations"], leaves["rotations"].grad, GRAD_REL_COV_CHAIN)
+    grads_close("scales", gr["dL_dscales"], leaves["scales"].grad)
+    grads_close("rotations", gr["dL_drotations"], leaves["rotations"].grad)
     grads_close("sh", gr["dL_dsh"], leaves["sh"].grad)
     vis = rast.markVisible(leaves["means3D"].detach())
     np.testing.assert_array_equal(vis.cpu().numpy(), orc.mark_visible(g["means3D"], cam.world_view_transform))
@@ -598,9 +620,9 @@ def test_full_size_elementwise_vs_oracle(C_, name):
     dl = mask_ambiguous(ss.upstream_grad(W, H, seed=1) * (W * H), ref)
     fargs, fout = hip_forward(C_, bg, g, cam, H, W)
     check_forward(C_, fout, ref, H, W, P)
-    gr = orc.backward(ref["state"], dl, 0.1)
+    gr, gr64 = oracle_backward(ref, dl, 0.1)
     bout = hip_backward(C_, fargs, fout, dl, 0.1)
-    check_backward(bout, gr, ref["state"], 16)
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64)
 
 
 def test_repeated_backward_and_pair_sort_path(C_):
@@ -625,7 +647,8 @@ def test_repeated_backward_and_pair_sort_path(C_):
     assert not torch.equal(b1[3], b2[3])
     ref = oracle_forward(bg, g, cam, H, W)
     dlm = mask_ambiguous(dl, ref)
-    check_backward(hip_backward(C_, fargs, fout, dlm, 0.1), orc.backward(ref["state"], dlm, 0.1), ref["state"], 16)
+    gr, gr64 = oracle_backward(ref, dlm, 0.1)
+    check_backward(hip_backward(C_, fargs, fout, dlm, 0.1), gr, ref["state"], 16, gr64=gr64)
     code = (
         "import sys, numpy as np, torch\n"
         "sys.path[:0] = [%r, %r]\n"
@@ -859,4 +882,5 @@ def test_graph_cache_eviction_keeps_results_right(C_):
 def test_zz_report_achieved_errors(C_):
     """Not a check of its own: prints the largest errors the gradient comparisons of this module reached (run with -s)."""
     for k in sorted(achieved):
-        print(f"  {k:<22s} max-normalised err {achieved[k][0]:.2e}   elements outside the per-element bar {achieved[k][1]:.2e}")
+        print(f"  {k:<38s} max-normalised err {achieved[k][0]:.2e}   elements outside the per-element bar "
+              f"{achieved[k][1]:.2e}   worst in {achieved[k][2]}")

@@ -225,3 +225,40 @@ def test_opacity_aware_rects_change_no_pixel_decision(kw):
     ga, gb = orc.backward(ref["state"], dl, 0.05), orc.backward(tight["state"], dl, 0.05)
     for k in ga:
         np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=20_000, W=640, H=360, f=800.0, seed=3),
+    dict(P=20_000, W=1280, H=720, f=900.0, seed=5),   # one pixel of a left-out tile passed the fp32 test before the margin
+], ids=["needles_640x360", "needles_1280x720"])
+def test_opacity_aware_rects_needle_scene(kw):
+    """20k needles (one scale 0.3..3, the other two 1e-4; median radius ~500 px).  For such a splat seen at an
+    angle the reference's fp32 evaluation of the conic form is a small difference of large products: a pixel whose exact
+    alpha is 20 % below 1/255 can pass the test.  The rect's margin scales with the conic's conditioning (gauss_math.h
+    kCancelMargin): no pixel of any left-out tile may pass the reference's (the oracle's fp32) per-pixel test, and the
+    rects must still remove a large part of the reference's pairs."""
+    L = _lib()
+    W, H, P = kw["W"], kw["H"], kw["P"]
+    cam = ss.make_camera(W, H, kw["f"], 3)
+    g = ss.make_gaussians(P, cam, seed=kw["seed"], degree_mode="all0", scale_mu=0.02)
+    rng = np.random.default_rng(kw["seed"])
+    g["scales"][:, 0] = rng.uniform(0.3, 3.0, P).astype(np.float32)
+    g["scales"][:, 1:] = 1e-4
+    bg = np.zeros(3, np.float32)
+    ref = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
+                      cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"],
+                      g["degrees"], cam.camera_center)
+    radii = np.zeros(P, np.int32)
+    rects = np.zeros((P, 4), np.uint16)
+    tiles = np.zeros(P, np.uint32)
+    tiles_ref = np.zeros(P, np.uint32)
+    view, proj, campos = (np.ascontiguousarray(a, np.float32) for a in
+                          (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+    L.hc_tight_rects(C.c_int(P), p(g["means3D"]), p(g["scales"]), C.c_float(1.0), p(g["rotations"]),
+                     p(np.ascontiguousarray(g["opacity"].reshape(-1))), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
+                     C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(radii), p(rects), p(tiles), p(tiles_ref))
+    np.testing.assert_array_equal(radii, ref["radii"])
+    assert np.median(radii[radii > 0]) > 400
+    bad, left = orc.culled_tile_violations(ref["state"], rects)
+    assert bad == 0, f"{bad} pixels of left-out tiles would have been blended by the reference"
+    assert left > 0.4 * ref["num_rendered"]
