@@ -268,14 +268,14 @@ def main():
     def cam_index(step):
         return (step * world + rank) % len(cams)
 
-    def train_step(step):
+    def train_step(step, lam=0.0):
         for t in leaves.values():
             t.grad = None
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0  # gaussian_renderer/__init__.py:27
         means2D.retain_grad()
         color, radii = dgr.rasterize_gaussians(leaves["means3D"], means2D, leaves["sh"], degrees, empty,
                                                leaves["opacity"], leaves["scales"], leaves["rotations"], empty,
-                                               settings[cam_index(step)], 0.0)
+                                               settings[cam_index(step)], lam)
         color.backward(dl)
         if exch is not None:
             grads = {k: v.grad for k, v in leaves.items()}
@@ -439,6 +439,36 @@ def main():
         torch.cuda.synchronize()
         render_s = time.perf_counter() - tr0
 
+    # The method's own configuration (full_eval.py:33,44: every paper run trains with --lambda_sh_sparsity=0.1): the same K
+    # steps with the SH L1 term on -- the per-Gaussian backward then reads the SH rows (signs of the coefficients) instead
+    # of the direction derivatives the forward left.  A second number; `value` stays lambda = 0,
+    # the default of arguments/__init__.py:94.
+    sparsity = None
+    if world == 1:
+        lam = 0.1
+        for i in range(5):
+            train_step(i, lam)
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for i in range(args.steps):
+            train_step(args.warmup + i, lam)
+        e1 = torch.cuda.Event()
+        e1.record()
+        while not e1.query():
+            time.sleep(5e-5)
+        torch.cuda.synchronize()
+        el_s = time.perf_counter() - ts0
+        _C.profile_enable(True)
+        _C.profile_read()
+        for i in range(min(args.steps, 20)):
+            train_step(args.warmup + i, lam)
+        torch.cuda.synchronize()
+        prof_s = _C.profile_read()
+        _C.profile_enable(False)
+        sparsity = {"lambda_sh_sparsity": lam, "value": round(args.steps / el_s, 2), "unit": "iters/s",
+                    "ms_per_step": round(1e3 * el_s / args.steps, 4),
+                    "stages_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in prof_s.items() if cnt}}
+
     used = [cam_index(args.warmup + i) for i in range(args.steps)]
     R_mean = float(np.mean([Rs[k] for k in used]))
     V_mean = float(np.mean([Vs[k] for k in used]))
@@ -465,6 +495,8 @@ def main():
     iters_per_s = args.steps * world / elapsed
     B_iter = P * (718 + 36 * Kbar) + R_mean * 280 + N * 40
     gpu_ms = sum(v["avg_ms"] for v in stages.values())
+    per_stage_traffic = [pmc_traffic(k, args.workload) for k in STAGE_KERNELS]
+    counter_bytes = int(sum(per_stage_traffic)) if all(t is not None for t in per_stage_traffic) else None
     hs = sorted(host_ms)
     host = {"cpus_visible": os.cpu_count(), "cpus_effective": ncpu,
             "loadavg": [round(x, 1) for x in os.getloadavg()],
@@ -485,7 +517,8 @@ def main():
         "value": round(iters_per_s, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload, "gaussians": P, "width": W, "height": H, "sh_degree": 3,
+        "config": {"workload": args.workload, "gaussians": P, "width": W, "height": H,
+                   "sh_degree": {"all3": 3, "all0": 0}.get(w["degree_mode"], "mixed 0-3"), "sh_coeffs_mean": round(Kbar, 2),
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
                    "pairs_binned_mean": round(pairs_mean), "tight_rects": _C.tight_rects(),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
@@ -515,8 +548,16 @@ def main():
         "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
         "render_fps": round(args.steps / render_s, 1),
         "roofline": roofline,
+        # frac_of_8TBps: SURVEY 8d's reference-algorithm bytes (work this library avoids counts in its favour) -- NOT HBM
+        # utilisation; frac_counter_traffic: the bytes the committed rocprofv3 counters saw move, per step, over the same time
         "iter_roofline": {"B_iter_bytes": int(B_iter), "achieved_GBps": round(B_iter * iters_per_s / world / 1e9, 1),
-                          "frac_of_8TBps": round(B_iter * iters_per_s / world / 8e12, 4)},
+                          "frac_of_8TBps": round(B_iter * iters_per_s / world / 8e12, 4),
+                          "counter_traffic_bytes": counter_bytes,
+                          "frac_counter_traffic": (round(counter_bytes * iters_per_s / world / 8e12, 4)
+                                                   if counter_bytes else None),
+                          "counter_traffic_source": PMC_SUMMARY if counter_bytes else None},
+        "value_sh_sparsity": sparsity["value"] if sparsity else None,
+        "sh_sparsity": sparsity,
         "stages": stages,
         "stages_note": f"{dom_stage}: HIP events inside the timed region; other stages: separate instrumented pass",
         "host": host,
@@ -569,7 +610,15 @@ def cpu_baseline(workload, W, H, g, cam, ncpu):
     tc1 = time.perf_counter()
     orc.backward(ref["state"], dl_np, 0.0)
     tc2 = time.perf_counter()
-    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": ncpu, "kind": "port",
+    cpu_model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": ncpu, "cpu_model": cpu_model, "kind": "port",
             "threads_effective": torch.get_num_threads(),
             "sample": f"configs[0] (10k Gaussians, 400x400, degree 0): fwd+bwd of the fp32 PyTorch restatement "
                       f"(oracle/torch_ref.py, tiled), torch.set_num_threads({torch.get_num_threads()}), median of 5 "

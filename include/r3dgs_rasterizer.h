@@ -54,8 +54,9 @@ int r3dgs_mark_visible(int P, const float* means3D, const float* viewmatrix, con
 
 /* Rasterizer::forward (rasterizer.h:31-56, rasterizer_impl.cu:359-504).
  * Returns num_rendered (>= 0) or a negative status.  Exact-size contract of the reference: the binning blob is
- * requested through the callback once the pair count is known (r3dgs_forward_pairs; == num_rendered unless the
- * opacity-aware rects left tiles out), i.e. this entry point waits for that one number
+ * requested through the callback once the pair count is known and is sized for the RETURNED num_rendered (the pairs
+ * actually binned, r3dgs_forward_pairs, are fewer when the opacity-aware rects left tiles out), so the returned value is
+ * the R r3dgs_backward / r3dgs_export_binning expect, as in the reference; i.e. this entry point waits for that one number
  * (the reference's cudaMemcpy at rasterizer_impl.cu:446) -- by polling host-mapped memory the pass writes, with a
  * deadline (R3DGS_SYNC_TIMEOUT_MS).  Training loops should use r3dgs_forward_reserved, which never waits.
  *   D        : per-Gaussian SH degree [P] (int32)
@@ -140,8 +141,8 @@ long long r3dgs_reserve_overflow_events(int* last_num_rendered, int* last_reserv
  * (opacity-aware rects, on by default: no pixel decision changes, so image and gradients are those of the full lists),
  * so pairs <= num_rendered.  The binning blob and R3DGS_PASS_TRUNCATED are about pairs.
  *   r3dgs_pass_pairs: pair count of a ticket (wait as for r3dgs_pass_query); negative on error.
- *   r3dgs_forward_pairs: pair count of the last r3dgs_forward / r3dgs_inference_forward call of this thread -- the
- *     capacity its binning callback was asked for, which is what r3dgs_backward / r3dgs_export_binning take as R.
+ *   r3dgs_forward_pairs: pair count of the last r3dgs_forward / r3dgs_inference_forward call of this thread
+ *     (informational: the binning blob of such a call is carved for the num_rendered it returned).
  *   r3dgs_set_tight_rects(0): bin into the reference's rects (lists identical to the reference's; pairs ==
  *     num_rendered); returns the previous setting (a negative argument only queries).  Also R3DGS_TIGHT_RECT=0.
  *   r3dgs_export_rects: debug accessor, the tile rect (x0, y0, x1, y1; exclusive maxima) each Gaussian was binned
@@ -163,6 +164,12 @@ int r3dgs_set_tile_order(int on);
  * per Gaussian for exactly these nine numbers).  0: the backward reads the rows, as with a sparsity term.  Bit-identical
  * gradients either way.  Returns the previous setting (a negative argument only queries).  Also R3DGS_SH_CACHE=0. */
 int r3dgs_set_sh_cache(int on);
+/* The per-Gaussian backward evaluates the covariance chain (conic -> cov2D -> cov3D -> scale / quaternion,
+ * backward.cu:228-306 and 311-374) in double from the same fp32 inputs and rounds once: the reference's fp32 evaluation of
+ * that chain is 2e-4 of max |dL_drotations| away from the exact value at the benchmark shape.
+ * r3dgs_set_f64_chain(0) selects the fp32 restatement of the reference's arithmetic; returns the previous setting (a
+ * negative argument only queries).  Also R3DGS_F64_CHAIN=0. */
+int r3dgs_set_f64_chain(int on);
 /* r3dgs_forward_hint(0): the forwards this thread issues from now on will not be followed by a backward (rendering under
  * no_grad): they leave no SH direction derivatives (their header says so; a backward on such a state reads the SH rows).
  * r3dgs_forward_hint(1), the initial state: they do. */
@@ -180,9 +187,9 @@ void r3dgs_reserve_forget(void);
 
 /* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
  * No host synchronisation; one hipGraph launch once the shape has been seen.  R is the pair capacity the forward
- * sized the binning blob with: r3dgs_forward_pairs() after r3dgs_forward (== the num_rendered it returned when the
- * opacity-aware rects are off), or the `reserve` passed to r3dgs_forward_reserved (r3dgs_binning_capacity recovers a
- * capacity with the same layout from the blob's size); the pair count itself is read from the device.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
+ * sized the binning blob with: the num_rendered r3dgs_forward returned (the reference's contract), or the `reserve`
+ * passed to r3dgs_forward_reserved (r3dgs_binning_capacity recovers a capacity with the same layout from the blob's
+ * size); the pair count itself is read from the device.  Takes lambda_sh_sparsity (the reference's public wrapper argument,
  * rasterize_points.cu:245; the multiplier lambda / (visible * 45) is formed on the device).
  * Every element of every output is written (zeros where the reference relies on zero-initialised
  * tensors), so outputs may be uninitialised.  dL_dconic ([P,2,2]) may be NULL.

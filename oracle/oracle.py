@@ -220,6 +220,34 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+def preprocess_bwd_f64(st, acc, lambda_sh_sparsity=0.0, fwd64=None, pure=False):
+    """The per-Gaussian half of `backward_f64` alone: `acc` [P,9] float64 = the 2D-stage sums per Gaussian (dmean2D.x, .y
+    in NDC units, dL/dconic A, HALF B, C, dL/d(activated opacity), dL/dcolour[3]) -> the chain's outputs in double."""
+    L = lib()
+    L.orc_f64_set_pure(C.c_int(1 if pure else 0))
+    P, M, W, H = st["P"], st["M"], st["W"], st["H"]
+    fw = fwd64 or {}
+    acc = np.ascontiguousarray(acc, dtype=np.float64)
+    conic_op = _f64(fw.get("conic_op", st["conic_op"]))
+    cov = _f64(fw.get("cov3D", st["cov3D_precomp"] if st["cov3D_precomp"] is not None else st["cov3D"]))
+    dmean3D, dcov3D = np.zeros((P, 3), np.float64), np.zeros((P, 6), np.float64)
+    dsh, dscale, drot = np.zeros((P, M, 3), np.float64), np.zeros((P, 3), np.float64), np.zeros((P, 4), np.float64)
+    dopac = np.zeros((P, 1), np.float64)
+    if P:
+        L.orc_preprocess_bwd_f64(C.c_int(P), C.c_int(M), _p(st["degrees"]), _p(st["means3D"]), _p(st["radii"]),
+                                 _p(st["sh"]), _p(st["clamped"]), _p(st["scales"]), _p(st["rotations"]),
+                                 C.c_float(st["mod"]), _p(cov), _p(st["vm"]), _p(st["pm"]), _p(st["campos"]),
+                                 C.c_int(W), C.c_int(H), C.c_float(st["tan_fovx"]), C.c_float(st["tan_fovy"]),
+                                 _p(conic_op), _p(acc), _p(dmean3D), _p(dcov3D), _p(dsh), _p(dscale), _p(drot),
+                                 _p(dopac), C.c_float(lambda_sh_sparsity))
+    return dict(dL_dopacity=dopac, dL_dmeans3D=dmean3D, dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale,
+                dL_drotations=drot)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
 def backward_f64(st, dL_dout_color, lambda_sh_sparsity=0.0, fwd64=None, pure=False):
     """The same gradients as `backward`, evaluated in DOUBLE (oracle/backward_f64.c): the exact gradient of the function
     the forward evaluated, given the forward's fp32 state and its discrete decisions.  An independent statement (matrix
@@ -229,32 +257,22 @@ def backward_f64(st, dL_dout_color, lambda_sh_sparsity=0.0, fwd64=None, pure=Fal
     pure (pin test only): the pure derivative of the forward instead of the reference's conventions (fp32 focal lengths
     and clamp limits, 1 / (det^2 + 1e-7)); see backward_f64.c."""
     L = lib()
-    L.orc_f64_set_pure(C.c_int(1 if pure else 0))
-    P, M, W, H = st["P"], st["M"], st["W"], st["H"]
+    P, W, H = st["P"], st["W"], st["H"]
     g = _f32(dL_dout_color)
     acc = np.zeros((P, 9), np.float64)
-    dmean3D, dcov3D = np.zeros((P, 3), np.float64), np.zeros((P, 6), np.float64)
-    dsh, dscale, drot = np.zeros((P, M, 3), np.float64), np.zeros((P, 3), np.float64), np.zeros((P, 4), np.float64)
-    dopac = np.zeros((P, 1), np.float64)
     if P:
         fw = fwd64 or {}
         feat = _f64(fw.get("colors", st["colors_precomp"] if st["colors_precomp"] is not None else st["rgb"]))
         xy, conic_op = _f64(fw.get("xy", st["xy"])), _f64(fw.get("conic_op", st["conic_op"]))
         L.orc_blend_bwd_f64(C.c_int(P), C.c_int(W), C.c_int(H), _p(st["ranges"]), _p(st["point_list"]), _p(st["bg"]),
                             _p(xy), _p(conic_op), _p(feat), _p(st["n_contrib"]), _p(g), _p(acc))
-        cov = _f64(fw.get("cov3D", st["cov3D_precomp"] if st["cov3D_precomp"] is not None else st["cov3D"]))
-        L.orc_preprocess_bwd_f64(C.c_int(P), C.c_int(M), _p(st["degrees"]), _p(st["means3D"]), _p(st["radii"]),
-                                 _p(st["sh"]), _p(st["clamped"]), _p(st["scales"]), _p(st["rotations"]),
-                                 C.c_float(st["mod"]), _p(cov), _p(st["vm"]), _p(st["pm"]), _p(st["campos"]),
-                                 C.c_int(W), C.c_int(H), C.c_float(st["tan_fovx"]), C.c_float(st["tan_fovy"]),
-                                 _p(conic_op), _p(acc), _p(dmean3D), _p(dcov3D), _p(dsh), _p(dscale), _p(drot),
-                                 _p(dopac), C.c_float(lambda_sh_sparsity))
+    out = preprocess_bwd_f64(st, acc, lambda_sh_sparsity, fwd64, pure)
     dmean2D = np.zeros((P, 3), np.float64)
     dmean2D[:, :2] = acc[:, 0:2]
     dconic = np.zeros((P, 4), np.float64)
     dconic[:, [0, 1, 3]] = acc[:, 2:5]
-    return dict(dL_dmeans2D=dmean2D, dL_dcolors=acc[:, 6:9].copy(), dL_dopacity=dopac, dL_dmeans3D=dmean3D,
-                dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale, dL_drotations=drot, dL_dconic=dconic)
+    out.update(dL_dmeans2D=dmean2D, dL_dcolors=acc[:, 6:9].copy(), dL_dconic=dconic)
+    return out
 
 
 def sh_backward(means3D, sh, degrees, campos, clamped, dL_dcolor):

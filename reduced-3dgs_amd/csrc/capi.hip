@@ -105,6 +105,19 @@ int sh_derivative_cache()
     return v;
 }
 
+// The per-Gaussian backward evaluates the covariance chain (backward.cu:228-306, 311-374) in double and rounds once
+// (gauss_math.h); R3DGS_F64_CHAIN=0 / r3dgs_set_f64_chain(0): the reference's fp32 arithmetic (A/B runs).
+std::atomic<int> g_f64_chain{-1};
+int f64_chain()
+{
+    int v = g_f64_chain.load();
+    if (v < 0) {
+        v = env_int("R3DGS_F64_CHAIN", 1, 0, 1);
+        g_f64_chain.store(v);
+    }
+    return v;
+}
+
 bool env_is(const char* name, const char* value)
 {
     const char* v = getenv(name);
@@ -837,8 +850,11 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     const uint32_t R = info->pairs, R_ref = info->num_rendered;
     if (R > 0x7fffffffu || R_ref > 0x7fffffffu) throw Error("num_rendered exceeds 2^31-1");
     g_last_forward_pairs = (int)R;
-    plan.reserve = R ? R : 1u;
-    plan.grid_pairs = plan.reserve;   // exact size: one block per chunk
+    // The blob is carved for the count this entry point RETURNS (the reference's num_rendered, >= the pairs binned with the
+    // opacity-aware rects): a caller that follows the reference's contract hands that number to r3dgs_backward /
+    // r3dgs_export_binning as R, and both carve the blob with it.  Grids are sized by the pairs.
+    plan.reserve = R_ref ? R_ref : 1u;
+    plan.grid_pairs = R ? R : 1u;     // exact size: one block per chunk
     char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy), binning_user);
     if (!bptr) throw Error("binning allocator returned NULL");
     BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
@@ -846,6 +862,7 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     launch_write_args(d_args, args, s);   // the completed block (binning pointers, pair capacity)
     issue_forward(plan, d_args, args, s, 2, hooks, &geom);
     return (int)R_ref;   // what the reference returns: the tile count of ITS rects (== R with the tight rects off)
+                         // == the capacity the binning blob was carved with
 }
 
 // Reserved forward: caller-provided blobs, no host wait.  Returns the pass ticket.
@@ -1170,6 +1187,13 @@ int r3dgs_set_sh_cache(int on)   // on < 0: query only
     return before;
 }
 
+int r3dgs_set_f64_chain(int on)   // on < 0: query only
+{
+    const int before = f64_chain();
+    if (on >= 0) g_f64_chain.store(on ? 1 : 0);
+    return before;
+}
+
 int r3dgs_set_tile_order(int on)   // on < 0: query only
 {
     const int before = heaviest_tiles_first();
@@ -1241,6 +1265,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         plan.reserve = R > 0 ? (uint32_t)R : 1u;
         plan.grid_pairs = grid_pairs_for(plan.reserve);
         plan.has_pairs = binning_buffer != nullptr ? 1 : 0;
+        plan.f64_chain = f64_chain();
         const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)plan.gx * plan.gy);
@@ -1333,7 +1358,8 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
             issue_backward(plan, d_args, a, s, hooks);
         } else {
             const uint32_t flags = (uint32_t)plan.bwd_ppl | ((uint32_t)plan.has_pairs << 3) | ((uint32_t)plan.layout.wide << 4) |
-                                   ((uint32_t)(a.blend.tile_order != nullptr) << 6);   // one more kernel in the chain
+                                   ((uint32_t)(a.blend.tile_order != nullptr) << 6) |   // one more kernel in the chain
+                                   ((uint32_t)plan.f64_chain << 7);
             const CtxKey key{dev, 1, s, P, M, width, height, plan.reserve, flags};
             launch_graph(key, plan, a, s, [](const BwdPlan& p, BwdPassArgs* d, const BwdPassArgs& v, hipStream_t cs) {
                 NoHooks nh;

@@ -618,6 +618,7 @@ struct BwdPlan {
     PairLayout layout;
     int bwd_ppl;
     int has_pairs;         // 0: the forward ran with an empty reservation (P > 0, no binning blob)
+    int f64_chain;         // the per-Gaussian backward evaluates the covariance chain in double (gauss_math.h; default)
 };
 
 // stage ids of the optional per-stage timers (capi.hip)

@@ -168,7 +168,8 @@ void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s)
     hipLaunchKernelGGL(pair_reduce_kernel, dim3((p.grid_pairs + per - 1u) / per), dim3(256), 0, s, a);
 }
 
-template <bool ROWS48>
+// F64: the covariance chain in double (gauss_math.h cov2d_backward_f64 / cov3d_backward_f64; the default)
+template <bool ROWS48, bool F64>
 __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdArgs* __restrict__ ap)
 {
     __shared__ float s_sh[kBwdBlock / 64][kBwdWaveShFloats];
@@ -285,7 +286,14 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
             for (int k = 0; k < 4; k++) q[k] = a.in.rotations[4 * i + k];
             cov3d_from_scale_rot(sc, cam.scale_modifier, q, c6);  // recomputed, not stored by the forward
         }
-        cov2d_backward(cam, mx, my, mz, c6, gcon[0], gcon[1], gcon[2], dcov6, dmean);
+        double dcov6d[6];
+        if (F64) {
+            cov2d_backward_f64(cam, mx, my, mz, c6, gcon[0], gcon[1], gcon[2], dcov6d, dmean);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov6[k] = (float)dcov6d[k];
+        } else {
+            cov2d_backward(cam, mx, my, mz, c6, gcon[0], gcon[1], gcon[2], dcov6, dmean);
+        }
         project_backward(cam, mx, my, mz, g2x, g2y, dmean);
         if (has_sh) {
             float mult = 0.f;
@@ -305,7 +313,12 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
                 sh_backward<false>(deg, row, row, nullptr, mx, my, mz, cam.campos, r.width_clamp >> 16, dcol, mult, dmean);
             }
         }
-        if (a.in.scales) cov3d_backward(sc, cam.scale_modifier, q, dcov6, dscale, dq);
+        if (a.in.scales) {
+            if (F64)
+                cov3d_backward_f64(sc, cam.scale_modifier, q, dcov6d, dscale, dq);
+            else
+                cov3d_backward(sc, cam.scale_modifier, q, dcov6, dscale, dq);
+        }
         dop = opacity_backward(dop, r.op);
     }
     if (has_sh && valid) {
@@ -379,10 +392,17 @@ void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_
 {
     const int blocks = (p.P + kBwdBlock - 1) / kBwdBlock;
     static const int lds_pad = env_int("R3DGS_PREBWD_LDS_PAD", 0, 0, 65536);
-    if (p.M == 16)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+    if (p.M == 16) {
+        if (p.f64_chain)
+            hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+        else
+            hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+    } else {
+        if (p.f64_chain)
+            hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+        else
+            hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), dim3(blocks), dim3(kBwdBlock), lds_pad, s, a);
+    }
 }
 
 }  // namespace r3

@@ -62,6 +62,8 @@ _lib.r3dgs_forward_hint.restype = None
 _lib.r3dgs_forward_hint.argtypes = [_i]
 _lib.r3dgs_set_sh_cache.restype = _i
 _lib.r3dgs_set_sh_cache.argtypes = [_i]
+_lib.r3dgs_set_f64_chain.restype = _i
+_lib.r3dgs_set_f64_chain.argtypes = [_i]
 _lib.r3dgs_set_tile_order.restype = _i
 _lib.r3dgs_set_tile_order.argtypes = [_i]
 _lib.r3dgs_export_tile_order.restype = _i
@@ -427,8 +429,8 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
             raise blob.error
     _check(rendered, "rasterize_gaussians")
     _stats["exact_passes"] += 1
-    pairs = int(_lib.r3dgs_forward_pairs())   # what the binning blob was sized for (<= num_rendered)
-    return NumRendered(0, max(pairs, 1), rendered, pairs), out_color, radii, geom.tensor, binning.tensor, img.tensor
+    pairs = int(_lib.r3dgs_forward_pairs())   # pairs actually binned (<= num_rendered, what the blob was carved for)
+    return NumRendered(0, max(int(rendered), 1), rendered, pairs), out_color, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -585,6 +587,16 @@ def set_sh_cache(on):
 
 def sh_cache():
     return bool(_lib.r3dgs_set_sh_cache(-1))
+
+
+def set_f64_chain(on):
+    """True (default): the per-Gaussian backward evaluates the covariance chain (backward.cu:228-306, 311-374) in double and
+    rounds once; False: in fp32, as the reference does.  Returns the previous setting."""
+    return bool(_lib.r3dgs_set_f64_chain(int(bool(on))))
+
+
+def f64_chain():
+    return bool(_lib.r3dgs_set_f64_chain(-1))
 
 
 def set_tile_order(on):

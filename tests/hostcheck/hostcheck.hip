@@ -298,6 +298,10 @@ void hc_truncated_colours(int P, int M, int nslots, const int* degs, const float
 static long g_cached_mismatches = 0;
 long hc_cached_sh_mismatches(void) { return g_cached_mismatches; }
 
+static int g_f64_chain = 0;
+// 1: the covariance chain in double (the product's default, gauss_math.h cov2d_backward_f64 / cov3d_backward_f64)
+void hc_set_f64_chain(int on) { g_f64_chain = on; }
+
 void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const int* radii, const float* shs,
                        const unsigned* clamp_bits, const float* scales, const float* rots, float mod,
                        const float* cov_pre, const float* view, const float* proj, const float* campos, int W, int H,
@@ -321,8 +325,14 @@ void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const 
             cov3d_from_scale_rot(sc, mod, q, c6);
         }
         float dmean[3];
-        cov2d_backward(cam, mx, my, mz, c6, dL_dconic[4 * i], dL_dconic[4 * i + 1], dL_dconic[4 * i + 3],
-                       dL_dcov3D + 6 * i, dmean);
+        double dcov6d[6];
+        if (g_f64_chain) {
+            cov2d_backward_f64(cam, mx, my, mz, c6, dL_dconic[4 * i], dL_dconic[4 * i + 1], dL_dconic[4 * i + 3], dcov6d, dmean);
+            for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = (float)dcov6d[k];
+        } else {
+            cov2d_backward(cam, mx, my, mz, c6, dL_dconic[4 * i], dL_dconic[4 * i + 1], dL_dconic[4 * i + 3],
+                           dL_dcov3D + 6 * i, dmean);
+        }
         project_backward(cam, mx, my, mz, dL_dmean2D[3 * i], dL_dmean2D[3 * i + 1], dmean);
         if (shs) {
             ShRowPlain row{shs + 3 * (size_t)M * i};
@@ -346,7 +356,12 @@ void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const 
             }
         }
         memcpy(dL_dmean3D + 3 * i, dmean, 12);
-        if (!cov_pre) cov3d_backward(sc, mod, q, dL_dcov3D + 6 * i, dL_dscale + 3 * i, dL_drot + 4 * i);
+        if (!cov_pre) {
+            if (g_f64_chain)
+                cov3d_backward_f64(sc, mod, q, dcov6d, dL_dscale + 3 * i, dL_drot + 4 * i);
+            else
+                cov3d_backward(sc, mod, q, dL_dcov3D + 6 * i, dL_dscale + 3 * i, dL_drot + 4 * i);
+        }
         dL_dopacity[i] = opacity_backward(dL_dopacity[i], conic_op[4 * i + 3]);
     }
 }

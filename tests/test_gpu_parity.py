@@ -12,11 +12,15 @@ Bars (BASELINE.json north_star), exactly as asserted below:
     0.02-0.05 %), image checks run on the others, and `mask_ambiguous` removes them from the upstream gradient of BOTH
     sides of a gradient comparison (a flipped decision changes gradients at O(1), not at rounding level);
   * rendered RGB and final T: <= 1e-5 abs on the non-ambiguous pixels;
-  * gradients (check_backward): every tensor max |err| <= 1e-4 * max |ref| (GRAD_REL; 1.5e-4 allowed for the three
-    tensors that come out of the cancellation-heavy covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- whose
-    fp32 evaluation amplifies the rounding of the per-Gaussian sums, as the reference's own float atomics do; measured
-    worst case over every test of this module: 9.4e-5 for dL_drotations, <= 1.9e-5 for all others), AND per element
-    |err| <= 1e-4 * |ref| + 1e-6 * max |ref| on >= 99.9 % of the elements (measured: >= 99.997 %).
+  * gradients (check_backward): every tensor max |err| <= 1e-4 * max |ref| (GRAD_REL) AND per element
+    |err| <= 1e-4 * |ref| + 1e-6 * max |ref| on >= 99.9 % of the elements, against TWO references: the fp32 oracle
+    (raster_oracle.c: the reference's arithmetic) and the double evaluation (backward_f64.c: the exact gradient of the
+    function the forward evaluated, derived independently and pinned to fp64 autograd at 1e-10).  The three tensors that
+    come out of the covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- are held to the double evaluation only:
+    the reference's fp32 arithmetic for that chain is itself 2e-4 (dL_drotations) / 5e-5 (dL_dscales) of the maximum away
+    from the exact value at the benchmark shape, so the library evaluates the chain in double (full-rate on CDNA4, the
+    stage is HBM-bound) and two fp32 evaluations are not compared with each other there.  test_zz_report prints every
+    distance measured: HIP vs fp32 oracle, HIP vs f64, fp32 oracle vs f64.
 """
 import os
 
@@ -164,12 +168,21 @@ def oracle_backward(ref, dl, lam):
     return orc.backward(ref["state"], dl, lam), orc.backward_f64(ref["state"], dl, lam)
 
 
+CHAIN = ("dL_dcov3D", "dL_dscales", "dL_drotations")   # what comes out of the covariance chain (backward.cu:228-306, 311-374)
+
+
 def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None):
-    """Every gradient tensor of the HIP path against the fp32 oracle `gr` AND, when given, against the double-precision
-    evaluation `gr64` -- both at north_star's 1e-4 of the tensor's maximum, plus the per-element criterion against the
-    fp32 oracle.  The fp32 oracle's own distance from the double evaluation is recorded next to it: two fp32 evaluations
-    may each sit on either side of the exact value."""
+    """Every gradient tensor of the HIP path at north_star's bar -- max |err| <= 1e-4 max |ref|, and per element
+    |err| <= 1e-4 |ref| + 1e-6 max |ref| on >= 99.9 % of the elements -- against
+      * the fp32 oracle `gr` (raster_oracle.c, the reference's arithmetic term by term) AND the double evaluation `gr64`
+        (backward_f64.c, the exact gradient) for everything the reference's fp32 arithmetic determines to that accuracy;
+      * `gr64` alone for the three tensors of the covariance chain: the library evaluates that chain in double
+        (gauss_math.h), because the reference's fp32 evaluation of it is itself up to 2e-4 of the maximum away from the
+        exact value (recorded next to it as "[fp32 oracle vs f64]": two fp32 evaluations of an ill-conditioned quadratic
+        form need not agree with each other to 1e-4, each can only be held to the exact value).  The HIP-vs-fp32-oracle
+        distance of those three is recorded, not asserted."""
     (dm2, dcol, dop, dm3, dcov, dsh, dsc, drot, dconic) = bout
+    assert gr64 is not None, "check_backward needs the double evaluation (oracle_backward)"
     pairs = [("dL_dmeans2D", dm2, None), ("dL_dconic", dconic.reshape(-1, 4)[:, [0, 1, 3]], [0, 1, 3]), ("dL_dcolors", dcol, None),
              ("dL_dopacity", dop, None), ("dL_dmeans3D", dm3, None), ("dL_dcov3D", dcov, None)]
     if M:
@@ -177,13 +190,10 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None):
     pairs += [("dL_dscales", dsc, None), ("dL_drotations", drot, None)]
     for name, got, cols in pairs:
         r32 = gr[name] if cols is None else gr[name][:, cols]
-        grads_close(name, r32, got, rel, per_element)
-        if gr64 is not None:
-            r64 = gr64[name] if cols is None else gr64[name][:, cols]
-            r64 = r64.reshape(r32.shape)
-            grads_close(name + " [hip vs f64]", r64, got.double() if hasattr(got, "double") else got, max(rel, GRAD_REL),
-                        per_element=False)
-            grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
+        r64 = (gr64[name] if cols is None else gr64[name][:, cols]).reshape(r32.shape)
+        grads_close(name, r32, got, rel, per_element, check=name not in CHAIN)
+        grads_close(name + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
+        grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
     for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):
@@ -509,6 +519,70 @@ def test_ragged_sh_inference_and_counters(C_):
     np.testing.assert_allclose(transm, refc["transmittance"], rtol=1e-4, atol=1e-3 + namb)
 
 
+def ragged_inputs(g):
+    """Degree-sorted copy of a scene and its ragged SH store, as scene/gaussian_model.py keeps it after cull_sh_bands
+    (gaussian_model.py:728-760): rows sorted by degree, each holding only its (degree + 1)^2 coefficients."""
+    order = np.argsort(g["degrees"].reshape(-1), kind="stable")
+    g = {k: np.ascontiguousarray(v[order]) for k, v in g.items()}
+    deg = g["degrees"].reshape(-1)
+    per_band = np.array([(deg == d).sum() for d in range(4)], np.int32)
+    cumsum = np.cumsum(per_band).astype(np.int32)
+    coeffs = np.array([1, 4, 9, 16], np.int32)
+    flat = np.concatenate([g["sh"][deg == d][:, :(d + 1) ** 2].reshape(-1) for d in range(4)]).astype(np.float32)
+    return g, flat, per_band, cumsum, coeffs
+
+
+def hip_forward_ragged(C_, bg, g, flat, per_band, cumsum, coeffs, cam, H, W, exact=False):
+    """rasterize_gaussians_variableSH_bands' path (render.py:43-72), on the exact-size or the path the library picks."""
+    out = C_._forward_common((dev(coeffs), dev(per_band), dev(cumsum)), dev(bg), dev(g["means3D"]), torch.Tensor([]),
+                             dev(g["opacity"]), dev(g["scales"]), dev(g["rotations"]), 1.0, torch.Tensor([]),
+                             dev(cam.world_view_transform), dev(cam.full_proj_transform), cam.tanfovx, cam.tanfovy, H, W,
+                             dev(flat), dev(g["degrees"]), dev(cam.camera_center), False, False, exact=exact)
+    assert not out[0].truncated
+    return out
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=9000, W=352, H=208, f=260.0, scale_mu=0.03),
+    dict(P=70_000, W=1000, H=40, f=500.0, scale_mu=0.01),
+    dict(name="garden_like_2M_1600x1062"),
+    dict(name="train_like_6M_1920x1080"),
+], ids=["9k", "strip_70k", "garden_like_2M", "train_like_6M_1080p"])
+def test_ragged_inference_path_reserved_equals_exact_equals_dense(C_, kw):
+    """render.py's FPS path for every paper config (rasterize_gaussians_variableSH_bands over the degree-sorted ragged SH
+    store), at small shapes and at the 2 M / 6 M mixed-degree stand-ins of BASELINE.json configs[2] / [4]:
+    the asynchronous reserved path (graph replay included) against the exact-size path, and both against the dense
+    training-path forward of the same Gaussians -- num_rendered, radii, image, sorted keys, point list, ranges, n_contrib
+    and final T bit for bit; plus the size-independent list properties on the ragged pass itself."""
+    if "name" in kw:
+        w, cam, g = ss.make_workload(kw["name"])
+        W, H, P = w["W"], w["H"], w["P"]
+    else:
+        W, H, P = kw["W"], kw["H"], kw["P"]
+        cam = ss.make_camera(W, H, kw["f"], 13)
+        g = ss.make_gaussians(P, cam, seed=17, degree_mode="mixed", scale_mu=kw["scale_mu"])
+    g, flat, per_band, cumsum, coeffs = ragged_inputs(g)
+    assert flat.size < 0.6 * g["sh"].size and (per_band > 0).all()
+    bg = np.array([0.2, 0.3, 0.4], np.float32)
+    _, dense = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    exd = C_.export_binning(P, dense[0], H, W, dense[3], dense[4], dense[5])
+    rex = hip_forward_ragged(C_, bg, g, flat, per_band, cumsum, coeffs, cam, H, W, exact=True)
+    assert rex[0].ticket == 0
+    outs = [rex] + [hip_forward_ragged(C_, bg, g, flat, per_band, cumsum, coeffs, cam, H, W) for _ in range(3)]
+    assert sum(1 for o in outs if o[0].ticket) >= 2          # the reserved path (and its graph replay) was taken
+    for o in outs:
+        assert int(o[0]) == int(dense[0]) and o[0].pairs == dense[0].pairs
+        assert torch.equal(o[1], dense[1]) and torch.equal(o[2], dense[2])
+        ex = C_.export_binning(P, o[0], H, W, o[3], o[4], o[5])
+        for k in ("keys", "point_list", "ranges", "n_contrib", "final_T", "tiles_touched"):
+            assert torch.equal(ex[k], exd[k]), k
+    keys, R = ex["keys"], outs[-1][0].pairs
+    assert bool((keys[1:] >= keys[:-1]).all())
+    rng_ = ex["ranges"].to(torch.int64)
+    assert int((rng_[:, 1] - rng_[:, 0]).sum()) == R == int(ex["tiles_touched"].to(torch.int64).sum())
+    assert float(outs[-1][1].min()) >= 0.0 and bool(torch.isfinite(outs[-1][1]).all())
+
+
 def test_empty_and_all_culled(C_):
     cam = ss.make_camera(64, 48, 50.0, None)
     bg = np.array([0.25, 0.5, 0.75], np.float32)
@@ -663,7 +737,8 @@ def test_repeated_backward_and_pair_sort_path(C_):
         "fargs, fout = t.hip_forward(_C, bg, g, cam, 240, 320)\n"
         "t.check_forward(_C, fout, ref, 240, 320, 6000)\n"
         "dl = t.mask_ambiguous(dl, ref)\n"
-        "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), t.orc.backward(ref['state'], dl, 0.1), ref['state'], 16)\n"
+        "gr, gr64 = t.oracle_backward(ref, dl, 0.1)\n"
+        "t.check_backward(t.hip_backward(_C, fargs, fout, dl, 0.1), gr, ref['state'], 16, gr64=gr64)\n"
         "print('pairs-path-ok')\n") % (ROOT, os.path.join(ROOT, "reduced-3dgs_amd"))
     # wide: 64-bit words; split: 16-bit tile keys + 32-bit ids in two arrays (what scenes of more than 2^19 Gaussians use);
     # last: the backward redoing the region pre-test instead of loading the forward's masks (the other kernel instance)
@@ -821,6 +896,30 @@ def test_num_rendered_is_lazy_and_queryable(C_):
     torch.cuda.synchronize()
     assert nr.ready() and int(nr) == int(first[0]) and f"{nr}" == str(int(first[0]))
     assert list(range(10))[:nr] == list(range(10))[:int(nr)]            # usable as an index
+
+
+def test_exact_forward_returns_the_capacity_of_its_binning_blob(C_):
+    """The reference's contract (rasterize_points.cu:202-305): the int the forward returns is the R the backward takes.
+    With the opacity-aware rects the pairs binned are fewer than num_rendered; the exact-size forward must still carve its
+    binning blob for the value it RETURNS, so that a C caller who passes that value on reads the blob with the layout it
+    was written with (it was carved for the pair count)."""
+    W, H, P = 320, 208, 7000
+    cam = ss.make_camera(W, H, 230.0, 5)
+    g = ss.make_gaussians(P, cam, seed=60, degree_mode="mixed", scale_mu=0.04)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    dl = ss.upstream_grad(W, H, seed=3) * (W * H)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    R, binning = fout[0], fout[4]
+    assert R.pairs < int(R) and R.capacity == int(R)
+    assert C_._lib.r3dgs_binning_bytes(P, W, H, int(R)) == binning.numel()
+    want = hip_backward(C_, fargs, fout, dl, 0.05)
+    plain = (int(R),) + tuple(fout[1:])                      # what a caller of the reference's API holds: a plain int
+    got = hip_backward(C_, fargs, plain, dl, 0.05)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    ex_a = C_.export_binning(P, R, H, W, fout[3], fout[4], fout[5])
+    ex_b = C_.export_binning(P, int(R), H, W, fout[3], fout[4], fout[5])
+    assert torch.equal(ex_a["point_list"], ex_b["point_list"][:R.pairs]) and torch.equal(ex_a["ranges"], ex_b["ranges"])
 
 
 @pytest.mark.parametrize("kw", [

@@ -165,6 +165,34 @@ def test_device_math_on_host_matches_oracle(kw, precomp):
         close("dscale", gr["dL_dscales"], dsc, 1e-5)
         close("drot", gr["dL_drotations"], drot, 1e-5)
 
+    # ---- the product's default: the covariance chain in DOUBLE (gauss_math.h cov2d_backward_f64 / cov3d_backward_f64),
+    # against oracle/backward_f64.c's independently derived chain fed the SAME fp32 2D-stage gradients: what is left is the
+    # one rounding of each output to fp32 (and of the covariance part of dL/dmean before the fp32 projection / SH parts
+    # are added to it)
+    acc_in = np.zeros((P, 9), np.float64)
+    acc_in[:, 0:2] = dm2[:, :2]
+    acc_in[:, 2:5] = dcon[:, [0, 1, 3]]
+    acc_in[:, 5] = acc[:, 5].astype(np.float32)
+    acc_in[:, 6:9] = dcol
+    want = orc.preprocess_bwd_f64(st, acc_in, kw["lam"])
+    d3b, dcovb, dshb = np.zeros_like(d3), np.zeros_like(dcov), np.zeros_like(dsh)
+    dscb, drotb = np.zeros_like(dsc), np.zeros_like(drot)
+    dopb = acc[:, 5].astype(np.float32).copy()
+    L.hc_set_f64_chain(C.c_int(1))
+    try:
+        L.hc_preprocess_bwd(C.c_int(P), C.c_int(M), p(deg), p(g["means3D"]), p(radii), p(sh), p(cbits), p(scales),
+                            p(rots), C.c_float(1.0), p(cov), p(view), p(proj), p(campos), C.c_int(W), C.c_int(H),
+                            C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), p(dm2), p(st["conic_op"]), p(dcon), p(dcol),
+                            C.c_float(kw["lam"]), p(d3b), p(dcovb), p(dshb), p(dscb), p(drotb), p(dopb))
+    finally:
+        L.hc_set_f64_chain(C.c_int(0))
+    close("f64 chain dcov3D", want["dL_dcov3D"], dcovb, 2e-7)
+    close("f64 chain dmean3D", want["dL_dmeans3D"], d3b, 1e-6)
+    if not precomp:
+        close("f64 chain dscale", want["dL_dscales"], dscb, 2e-7)
+        close("f64 chain drot", want["dL_drotations"], drotb, 2e-7)
+        np.testing.assert_array_equal(dshb, dsh)      # the SH part is untouched by the switch
+
 
 def test_region_pretest_is_conservative_fuzz():
     """2M random splats (eigenvalue ratios up to 1e5, opacities down to 1e-4) x one 8x8 block: the kernels'

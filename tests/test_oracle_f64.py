@@ -138,3 +138,49 @@ def test_fp32_oracle_against_f64(kw):
     print("fp32 oracle vs f64:", {k: f"{v:.1e}" for k, v in errs.items()})
     for k, v in errs.items():
         assert v <= 1e-4, f"{k}: {v:.2e}"
+
+
+def test_configs0_three_parties_fp64_autograd_f64_oracle_fp32_oracle():
+    """BASELINE.json configs[0] (10k Gaussians, 400x400, degree 0) by three independent parties: the tile-by-tile fp64
+    autograd statement (oracle/torch_ref.py -- the only statement of the EWA projection / blend maths that shares no
+    expression with the product), the C oracle's fp32 forward + backward (raster_oracle.c), and the double backward
+    (backward_f64.c).  Radii equal; colour within 2e-5 (5e-6 on 99.5 %) of the pixels that are not threshold-ambiguous; the fp32 oracle's
+    gradients within 3e-4 of autograd's (relative to each tensor's maximum); the double backward's within 1e-9 when it is fed
+    the fp64 forward's per-Gaussian numbers (same function, two derivations) and within 1e-4 on the fp32 forward's state
+    (measured ~1e-5: what rounding the stored pixel means / conics to fp32 is worth once the zero-mean upstream gradient
+    has cancelled the sums -- a property of the reference's fp32 forward buffers, the same for every backward)."""
+    w = ss.WORKLOADS["cfg0_10k_400"]
+    W, H, P = w["W"], w["H"], w["P"]
+    cam = ss.make_camera(W, H, w["f"], None)
+    g = ss.make_gaussians(P, cam, seed=0, degree_mode=w["degree_mode"])
+    bg = np.array([0.1, 0.4, 0.9], np.float32)
+    out = oracle_fwd(cam, g, bg, W, H, ambig_rel=1e-4)
+    ok = out["ambig"].reshape(-1) == 0
+    assert ok.mean() > 0.995
+    dl = ss.upstream_grad(W, H, seed=2) * (W * H)
+    dl.reshape(3, -1)[:, ~ok] = 0.0
+    lv = dict(m3=T(g["means3D"]), op=T(g["opacity"]), sc=T(g["scales"]), rot=T(g["rotations"]), sh=T(g["sh"]))
+    for v in lv.values():
+        v.requires_grad_()
+    geo = {}
+    col, radii, _ = tr.render(lv["m3"], lv["op"], lv["sc"], lv["rot"], lv["sh"], torch.tensor(g["degrees"]),
+                              T(cam.world_view_transform), T(cam.full_proj_transform), T(cam.camera_center), T(bg), W, H,
+                              f32(cam.tanfovx), f32(cam.tanfovy), tiled=True, geo_out=geo)
+    np.testing.assert_array_equal(out["radii"], radii.numpy())
+    cerr = np.abs(col.detach().numpy().reshape(3, -1) - out["color"].reshape(3, -1))[:, ok].max()
+    assert cerr <= 2e-5, cerr   # fp32 rounding of the oracle's forward over ~30 blended entries (measured 1.3e-5), no flipped decision
+    assert (np.abs(col.detach().numpy().reshape(3, -1) - out["color"].reshape(3, -1))[:, ok].max(0) > 5e-6).mean() < 5e-3
+    (col * T(dl)).sum().backward()
+    g32 = orc.backward(out["state"], dl, 0.0)
+    g64 = orc.backward_f64(out["state"], dl, 0.0)
+    g64p = orc.backward_f64(out["state"], dl, 0.0, fwd64=geo, pure=True)
+    rows = []
+    for name, ref, key in (("means3D", lv["m3"].grad, "dL_dmeans3D"), ("opacity", lv["op"].grad, "dL_dopacity"),
+                           ("scales", lv["sc"].grad, "dL_dscales"), ("rotations", lv["rot"].grad, "dL_drotations"),
+                           ("sh", lv["sh"].grad, "dL_dsh")):
+        e32, e64, e64p = relerr(ref.numpy(), g32[key]), relerr(ref.numpy(), g64[key]), relerr(ref.numpy(), g64p[key])
+        rows.append(f"{name} fp32 {e32:.1e} f64-on-fp32-state {e64:.1e} f64-on-fp64-state {e64p:.1e}")
+        assert e32 <= 3e-4, f"{name}: fp32 oracle vs autograd {e32:.2e}"
+        assert e64 <= 1e-4, f"{name}: f64 oracle on the fp32 forward state vs autograd {e64:.2e}"
+        assert e64p <= 1e-9, f"{name}: f64 oracle on the fp64 forward state vs autograd {e64p:.2e}"
+    print("configs[0] vs fp64 autograd:", f"colour {cerr:.1e};", "; ".join(rows))
