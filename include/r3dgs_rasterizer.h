@@ -41,8 +41,12 @@ const char* r3dgs_last_error(void);
  * (`reserve`: num_rendered for an exact-size pass, the reservation for r3dgs_forward_reserved); its layout also
  * depends on (P, width, height) -- 64-bit pair words once tile bits + log2(P) exceed 32.
  * r3dgs_binning_capacity inverts r3dgs_binning_bytes: the largest capacity whose layout fits `bytes` (it
- * reproduces the carve of the pass that sized the blob), 0 if none fits, negative on error. */
+ * reproduces the carve of the pass that sized the blob), 0 if none fits, negative on error.
+ * r3dgs_geometry_bytes_lean: the geometry blob of a forward that leaves no SH direction derivatives for a backward --
+ * r3dgs_inference_forward*, precomputed colours, or a forward announced with r3dgs_forward_hint(0): 36 bytes per Gaussian
+ * less (the array is the blob's last one; the pass header says whether it was written, nothing else reads it). */
 size_t r3dgs_geometry_bytes(int P);
+size_t r3dgs_geometry_bytes_lean(int P);
 size_t r3dgs_binning_bytes(int P, int width, int height, int reserve);
 size_t r3dgs_image_bytes(int width, int height);
 int r3dgs_binning_capacity(int P, int width, int height, size_t bytes);
@@ -184,6 +188,11 @@ int r3dgs_export_tile_order(int width, int height, char* image_buffer, unsigned 
 /* Forget every pair count learnt so far (a new scene is about to be loaded; tests): the next pass of each image size
  * takes the exact-size path again. */
 void r3dgs_reserve_forget(void);
+/* Per-camera pair counts are remembered under the device address of the camera's view matrix (r3dgs_reserve_hint_view).
+ * A caller that frees a view matrix should say so, or the allocator may hand the address to another camera whose first
+ * pass then inherits a stranger's count (harmless in strict mode -- the pass is redone exactly -- but it costs that redo;
+ * the hint is also never taken below 0.3 x the largest recent count of the image size). */
+void r3dgs_reserve_forget_view(const float* viewmatrix);
 
 /* Rasterizer::backward (rasterizer.h:58-87, rasterizer_impl.cu:508-630).  Returns 0 or a negative status.
  * No host synchronisation; one hipGraph launch once the shape has been seen.  R is the pair capacity the forward
@@ -193,6 +202,10 @@ void r3dgs_reserve_forget(void);
  * rasterize_points.cu:245; the multiplier lambda / (visible * 45) is formed on the device).
  * Every element of every output is written (zeros where the reference relies on zero-initialised
  * tensors), so outputs may be uninitialised.  dL_dconic ([P,2,2]) may be NULL.
+ * The three state blobs are NOT read-only here: the per-pair gradient slab, its flags, the per-Gaussian sums and the tile
+ * launch order are scratch areas inside them (the reference's backward allocates nothing either).  Several backward passes
+ * over one forward state (retain_graph) are fine one after the other -- each leaves the scratch as it found it -- but
+ * must not run concurrently on different streams.
  * Shapes: dL_dpix [3,H,W]; dL_dmean2D [P,3]; dL_dopacity [P]; dL_dcolor [P,3]; dL_dmean3D [P,3];
  * dL_dcov3D [P,6]; dL_dsh [P,M,3]; dL_dscale [P,3]; dL_drot [P,4]. */
 int r3dgs_backward(int P, const int* D, int M, int R, const float* background, int width, int height,

@@ -570,10 +570,17 @@ void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s)
 template <class IO>
 __global__ __launch_bounds__(256) void export_keys_kernel(int R, uint32_t cap, int rank_bits, const char* __restrict__ sorted,
                                                           const uint32_t* __restrict__ point_list,
-                                                          const uint32_t* __restrict__ depth_key, uint64_t* keys)
+                                                          const uint32_t* __restrict__ depth_key, const GeomHeader* hdr,
+                                                          uint64_t* keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
+    // a caller holding only the reference's num_rendered may ask for more entries than the pass binned (opacity-aware
+    // rects): what lies behind the list is not a list entry
+    if ((uint32_t)i >= hdr->num_pairs) {
+        keys[i] = ~(uint64_t)0;
+        return;
+    }
     keys[i] = ((uint64_t)IO::tile_at(sorted, cap, (uint32_t)i, rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
 }
 
@@ -594,13 +601,13 @@ void launch_export_keys(int P, int R, int cap, size_t n_tiles, const BinState& b
     const dim3 grid((R + 255) / 256), block(256);
     if (l.wide == 2)
         hipLaunchKernelGGL(export_keys_kernel<IoSplit>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted, b.point_list,
-                           g.depth_key, keys_out);
+                           g.depth_key, g.header, keys_out);
     else if (l.wide == 1)
         hipLaunchKernelGGL(export_keys_kernel<IoWide>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted, b.point_list,
-                           g.depth_key, keys_out);
+                           g.depth_key, g.header, keys_out);
     else
         hipLaunchKernelGGL(export_keys_kernel<IoNarrow>, grid, block, 0, s, R, (uint32_t)cap, l.rank_bits, sorted,
-                           b.point_list, g.depth_key, keys_out);
+                           b.point_list, g.depth_key, g.header, keys_out);
 }
 
 }  // namespace r3

@@ -368,10 +368,15 @@ uint32_t reserve_hint(int dev, int P, int W, int H, uintptr_t cam)
     auto scaled = [P](int p0, uint32_t pairs) { return p0 > 0 ? (double)pairs * ((double)P / (double)p0) : (double)pairs; };
     double base = 0.0;
     auto c = cam ? v.cams.find(cam) : v.cams.end();
+    double recent_max = 0.0;
+    for (auto& e : v.recent) recent_max = std::max(recent_max, scaled(e.first, e.second));
     if (c != v.cams.end()) {
-        base = scaled(c->second.P, c->second.pairs);
+        // never far below what this image size has needed lately: a camera entry can be stale (a caller that reuses one
+        // device buffer for every camera's matrix; an address the allocator handed to another camera -- the host layer
+        // reports freed matrices through r3dgs_reserve_forget_view, a C caller may not)
+        base = std::max(scaled(c->second.P, c->second.pairs), 0.3 * recent_max);
     } else {
-        for (auto& e : v.recent) base = std::max(base, scaled(e.first, e.second));
+        base = recent_max;
     }
     return quantize_reserve(base * slack + 65536.0);
 }
@@ -807,6 +812,12 @@ bool take_prefer_generic(int dev, const FwdCall& c)
     return true;
 }
 
+size_t geometry_blob_bytes(size_t P, size_t depth_temp, bool lean)
+{
+    const GeomState g = GeomState::carve(nullptr, P, depth_temp);
+    return (size_t)reinterpret_cast<uintptr_t>(lean ? g.lean_end : g.end) + kAlign;
+}
+
 // Exact-size forward (the reference's contract): allocator callbacks, returns num_rendered.
 int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_alloc_fn binningBuffer, void* binning_user,
                   r3dgs_alloc_fn imageBuffer, void* image_user, const FwdCall& c)
@@ -821,7 +832,8 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     if (!plan.generic_depth_sort && take_prefer_generic(dev, c)) plan.generic_depth_sort = 1;
     prepare_depth_bucket_sort(plan.nb);
     const size_t depth_temp = cached_depth_temp((size_t)c.P);
-    char* gptr = geometryBuffer(required_bytes<GeomState>((size_t)c.P, depth_temp), geometry_user);
+    const bool lean = !(g_next_forward_trains && !plan.ragged && c.shs && !c.colors_precomp);   // no sh_ddir will be written
+    char* gptr = geometryBuffer(geometry_blob_bytes((size_t)c.P, depth_temp, lean), geometry_user);
     if (!gptr) throw Error("geometry allocator returned NULL");
     GeomState geom = GeomState::carve(gptr, (size_t)c.P, depth_temp);
     const size_t N = (size_t)c.width * c.height, Tn = (size_t)plan.gx * plan.gy;
@@ -998,6 +1010,16 @@ size_t r3dgs_geometry_bytes(int P)
         return 0;
     }
 }
+size_t r3dgs_geometry_bytes_lean(int P)
+{
+    try {
+        g_last_error.clear();
+        return geometry_blob_bytes((size_t)P, cached_depth_temp((size_t)(P > 0 ? P : 1)), true);
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return 0;
+    }
+}
 size_t r3dgs_binning_bytes(int P, int width, int height, int reserve)
 {
     try {
@@ -1091,6 +1113,16 @@ int r3dgs_reserve_hint(int P, int width, int height)
 int r3dgs_reserve_hint_view(int P, int width, int height, const float* viewmatrix)
 {
     return guarded([&]() { return (int)reserve_hint(current_device(), P, width, height, reinterpret_cast<uintptr_t>(viewmatrix)); });
+}
+
+void r3dgs_reserve_forget_view(const float* viewmatrix)
+{
+    const uintptr_t cam = reinterpret_cast<uintptr_t>(viewmatrix);
+    std::lock_guard<std::mutex> lk(g_adv.mu);
+    for (auto& v : g_adv.views) v.second.cams.erase(cam);
+    // passes of that camera still in flight must not re-enter it when they are harvested
+    for (auto& p : g_adv.pending)
+        if (p.cam == cam) p.cam = 0;
 }
 
 long long r3dgs_forward_reserved(char* geom_buffer, char* binning_buffer, char* image_buffer, int reserve, int P,

@@ -176,14 +176,19 @@ struct GeomState {
         g.order = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.radii_internal = c.take<int>(P);
-        g.sh_ddir = c.take<float>(P * 9);
         g.ovf_key = c.take<uint32_t>(P);
         g.ovf_id = c.take<uint32_t>(P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
+        // LAST, so that a blob without it is a valid blob: a forward that will not leave the derivatives (inference /
+        // ragged SH / precomputed colours / r3dgs_forward_hint(0)) may be given a blob of lean_end's size (36 B per
+        // Gaussian less: 216 MB at 6 M Gaussians); the pass header says whether they are there, nothing else looks
+        g.lean_end = c.p;
+        g.sh_ddir = c.take<float>(P * 9);
         g.end = c.p;
         return g;
     }
+    char* lean_end;
     char* end;
 };
 

@@ -8,6 +8,7 @@ only here: device memory (outputs + the three opaque state blobs), the current H
 There is NO fallback: if the HIP library is missing or fails to load, importing this module raises.
 """
 import ctypes as C
+import weakref
 import os
 
 import torch
@@ -29,6 +30,8 @@ _lib.r3dgs_version.restype = C.c_char_p
 _lib.r3dgs_last_error.restype = C.c_char_p
 _lib.r3dgs_geometry_bytes.restype = C.c_size_t
 _lib.r3dgs_geometry_bytes.argtypes = [_i]
+_lib.r3dgs_geometry_bytes_lean.restype = C.c_size_t
+_lib.r3dgs_geometry_bytes_lean.argtypes = [_i]
 _lib.r3dgs_binning_bytes.restype = C.c_size_t
 _lib.r3dgs_binning_bytes.argtypes = [_i, _i, _i, _i]
 _lib.r3dgs_image_bytes.restype = C.c_size_t
@@ -62,6 +65,8 @@ _lib.r3dgs_forward_hint.restype = None
 _lib.r3dgs_forward_hint.argtypes = [_i]
 _lib.r3dgs_set_sh_cache.restype = _i
 _lib.r3dgs_set_sh_cache.argtypes = [_i]
+_lib.r3dgs_reserve_forget_view.restype = None
+_lib.r3dgs_reserve_forget_view.argtypes = [C.c_void_p]
 _lib.r3dgs_set_f64_chain.restype = _i
 _lib.r3dgs_set_f64_chain.argtypes = [_i]
 _lib.r3dgs_set_tile_order.restype = _i
@@ -283,6 +288,8 @@ def _blob_bytes(kind, *key):
     if v is None:
         if kind == "geom":
             v = _lib.r3dgs_geometry_bytes(*key)
+        elif kind == "geom_lean":
+            v = _lib.r3dgs_geometry_bytes_lean(*key)
         elif kind == "bin":
             v = _lib.r3dgs_binning_bytes(*key)
         else:
@@ -353,6 +360,35 @@ def _watch_overflow():
                       RuntimeWarning)
 
 
+_tracked_views = {}   # device address of a view matrix -> weakref of the tensor that owns it
+
+
+def _track_view(vm):
+    """The library remembers pair counts per camera under the device address of its view matrix.  When that tensor dies
+    the address may be handed to another camera: tell the library to forget it.  Every scene/cameras.py Camera
+    owns its matrix for the whole run, so this registers once per camera; a matrix that is a temporary (uploaded per
+    iteration, a converted copy) is forgotten as soon as it is freed and its passes use the image size's largest recent
+    count instead."""
+    ptr = vm.data_ptr()
+    ref = _tracked_views.get(ptr)
+    if ref is not None and ref() is vm:
+        return
+    if len(_tracked_views) > 65536:
+        _tracked_views.clear()
+    _tracked_views[ptr] = weakref.ref(vm)
+    weakref.finalize(vm, _forget_view, ptr, id(vm))
+
+
+def _forget_view(ptr, ident):
+    ref = _tracked_views.get(ptr)
+    if ref is not None and ref() is None:
+        del _tracked_views[ptr]
+    try:
+        _lib.r3dgs_reserve_forget_view(ptr)
+    except Exception:   # interpreter shutdown
+        pass
+
+
 def _forward_common(ragged, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                     viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degrees, campos,
                     prefiltered, debug, counters=None, exact=False, _reserve=None, _strict_override=None):
@@ -398,12 +434,16 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
         # Asynchronous path: blobs sized up front from a pair reservation, one graph launch, no wait for the pass.  The
         # exact-size path (allocator callbacks, one wait in the middle) runs when nothing is known about this view size
         # yet, in debug mode, when asked for -- and to redo a pass that overflowed its reservation (strict mode).
+        if vm is not None:
+            _track_view(vm)
         reserve = 0 if (exact or debug) else _lib.r3dgs_reserve_hint_view(P, W, H, _ptr(vm))
         if _reserve is not None:   # tests: a chosen reservation
             reserve = int(_reserve)
         strict = _strict if _strict_override is None else bool(_strict_override)
         if reserve > 0:
-            geom = torch.empty(_blob_bytes("geom", P), **u8)
+            # no SH direction derivatives will be left (render-only / ragged SH / precomputed colours): the lean blob
+            lean = not trains or ragged is not None or shc is None or col is not None
+            geom = torch.empty(_blob_bytes("geom_lean" if lean else "geom", P), **u8)
             binning = torch.empty(_blob_bytes("bin", P, W, H, reserve), **u8)
             img = torch.empty(_blob_bytes("img", W, H), **u8)
             ticket = fn_reserved(geom.data_ptr(), binning.data_ptr(), img.data_ptr(), reserve, *head, *tail)
