@@ -76,7 +76,42 @@ def build(force=False, verbose=True):
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in UNITS]
     if jobs or force or not os.path.exists(OUT):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    if not tag:
+        build_torch_binding(force=force, verbose=verbose)
     return OUT
+
+
+TORCH_EXT_SRC = os.path.join(HERE, "csrc_torch", "r3dgs_torch.cpp")
+TORCH_EXT_OUT = os.path.join(HERE, "diff_gaussian_rasterization", "_r3dgs_torch.so")
+
+
+def build_torch_binding(force=False, verbose=True):
+    """The compiled torch binding of the hot calls (csrc_torch/r3dgs_torch.cpp -> diff_gaussian_rasterization/
+    _r3dgs_torch.so): a pybind module compiled with the host compiler against torch's own headers -- it contains no device
+    code and does not link against libr3dgs_hip.so (it is handed the library's entry points at import), so no hipify pass
+    and no hipcc are involved.  ~30 s."""
+    import sysconfig
+
+    import torch
+    hdr = os.path.join(HERE, "..", "include", "r3dgs_rasterizer.h")
+    if not force and os.path.exists(TORCH_EXT_OUT) and os.path.getmtime(TORCH_EXT_OUT) >= max(
+            os.path.getmtime(TORCH_EXT_SRC), os.path.getmtime(hdr), os.path.getmtime(torch.__file__)):
+        return TORCH_EXT_OUT
+    tdir = os.path.dirname(torch.__file__)
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", TORCH_EXT_OUT, TORCH_EXT_SRC,
+           "-I", os.path.join(HERE, "..", "include"), "-I", os.path.join(tdir, "include"),
+           "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", sysconfig.get_paths()["include"],
+           "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_r3dgs_torch",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           "-L", os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+           "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wno-deprecated-declarations"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        if verbose:
+            print(r.stdout + r.stderr)
+        raise RuntimeError("building the torch binding failed")
+    return TORCH_EXT_OUT
 
 
 if __name__ == "__main__":

@@ -106,6 +106,57 @@ _lib.r3dgs_profile_read.argtypes = [_vp, _vp]
 
 LIBRARY_PATH = _LIB_PATH
 
+# ---- compiled torch binding of the two hot calls (csrc_torch/r3dgs_torch.cpp; the reference's layer is a torch C++
+# extension too, DGR/ext.cpp:16-25).  It is handed the entry points of the library loaded above, so both bindings drive
+# ONE library instance.  R3DGS_BINDING = auto (default: compiled if it was built, else ctypes) | torch (required) | ctypes.
+_EXT_FUNCS = ("r3dgs_last_error", "r3dgs_version", "r3dgs_geometry_bytes", "r3dgs_geometry_bytes_lean", "r3dgs_binning_bytes",
+              "r3dgs_image_bytes", "r3dgs_forward_hint", "r3dgs_reserve_hint_view", "r3dgs_forward_reserved",
+              "r3dgs_pass_query", "r3dgs_backward", "r3dgs_mark_visible")
+_ext = None
+_ext_loaded = None
+_binding_request = os.environ.get("R3DGS_BINDING", "auto")
+if _binding_request not in ("auto", "torch", "ctypes"):
+    raise ImportError(f"R3DGS_BINDING={_binding_request!r}: expected auto, torch or ctypes")
+if _binding_request != "ctypes":
+    try:
+        from . import _r3dgs_torch as _ext_loaded
+        _ext_loaded.bind({n: C.cast(getattr(_lib, n), C.c_void_p).value for n in _EXT_FUNCS})
+        _ext = _ext_loaded
+    except ImportError:
+        if _binding_request == "torch":
+            raise
+        _ext_loaded = None
+
+
+def binding():
+    """'torch': rasterize_gaussians / rasterize_gaussians_backward / mark_visible go through the compiled torch extension
+    (diff_gaussian_rasterization/_r3dgs_torch.so); 'ctypes': through this module's ctypes marshalling.  Same library, same
+    kernels, same results bit for bit (tests/test_gpu_parity.py runs both)."""
+    return "torch" if _ext is not None else "ctypes"
+
+
+def set_binding(name):
+    """'torch' | 'ctypes' -> the previous setting.  'torch' needs the extension to have been built (build.py)."""
+    global _ext
+    before = binding()
+    if name == "torch":
+        if _ext_loaded is None:
+            raise RuntimeError("the compiled torch binding is not built (reduced-3dgs_amd/build.py) or R3DGS_BINDING=ctypes")
+        _ext = _ext_loaded
+    elif name == "ctypes":
+        _ext = None
+    else:
+        raise ValueError(name)
+    return before
+
+
+_NO_TENSOR = torch.Tensor([])
+
+
+def _t(x):
+    return _NO_TENSOR if x is None else x
+
+
 
 def profile_enable(on, only=None):
     """Per-stage HIP-event timing inside the library (include/r3dgs_rasterizer.h r3dgs_profile_*).
@@ -404,6 +455,30 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
         radii = torch.zeros((0,), dtype=torch.int32, device=dev)
         e = torch.empty(0, **u8)
         return NumRendered(0, 0, 0, 0), out_color, radii, e, e.clone(), e.clone()
+    global _next_forward_trains
+    trains = torch.is_grad_enabled() if _next_forward_trains is None else _next_forward_trains
+    _next_forward_trains = None
+    if _ext is not None and ragged is None and counters is None and not exact and not debug and _reserve is None:
+        # the hot call: compiled marshalling (csrc_torch/r3dgs_torch.cpp), same library entry points as below
+        strict = _strict if _strict_override is None else bool(_strict_override)
+        if viewmatrix is not None and viewmatrix.is_contiguous() and viewmatrix.dtype == torch.float32:
+            _track_view(viewmatrix)
+        ticket, reserve, rendered, flags, out_color, radii, geom, binning, img = _ext.forward_reserved(
+            _t(background), means3D, _t(colors), _t(opacity), _t(scales), _t(rotations), float(scale_modifier),
+            _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), float(tan_fovx), float(tan_fovy), H, W, _t(sh), _t(degrees),
+            _t(campos), bool(prefiltered), bool(trains), strict)
+        if ticket:
+            _stats["reserved_passes"] += 1
+            nr = NumRendered(ticket, reserve, rendered if rendered >= 0 else None)
+            nr._flags = flags
+            if not strict:
+                _watch_overflow()
+                return nr, out_color, radii, geom, binning, img
+            if not nr.truncated:
+                return nr, out_color, radii, geom, binning, img
+            _stats["redone_passes"] += 1   # the reservation did not hold: redo on the exact-size path below
+            del geom, binning, img
+        exact = True   # (ticket == 0: nothing known about this view size yet)
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     bg = _dev_f32(background, dev)
@@ -414,10 +489,7 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
     touched = transm = None
     if counters is not None:
         touched, transm = counters
-    global _next_forward_trains
-    trains = torch.is_grad_enabled() if _next_forward_trains is None else _next_forward_trains
     _lib.r3dgs_forward_hint(int(trains))   # holds for the redo of an overflowed pass as well
-    _next_forward_trains = None
     with _on_device(dev):
         tail = (_ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot),
                 _ptr(cov), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
@@ -521,6 +593,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P == 0:
         z = lambda *s: torch.zeros(s, **opts)
         return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+    if _ext is not None and _grad_arena is None:
+        if isinstance(R, NumRendered):
+            cap = R.capacity
+        else:
+            cap = _lib.r3dgs_binning_capacity(P, W, H, int(binningBuffer.numel())) if binningBuffer.numel() else 0
+        return tuple(_ext.backward(_t(background), means3D, _t(radii), _t(colors), _t(scales), _t(rotations),
+                                   float(scale_modifier), _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), float(tan_fovx),
+                                   float(tan_fovy), dL_dout_color, _t(sh), _t(degrees), _t(campos), geomBuffer, int(cap),
+                                   binningBuffer, imageBuffer, float(lambda_sh_sparsity), bool(debug), bool(_want_conic)))
+
     def e(name, *s):  # every element is written by the library
         if _grad_arena is not None:
             t = _grad_arena(name, s)
@@ -555,6 +637,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible (rasterize_points.cu:307-326): bool[P], view-space z > 0.2."""
+    if _ext is not None:
+        return _ext.mark_visible(means3D, _t(viewmatrix), _t(projmatrix))
     dev = means3D.device
     P = int(means3D.size(0))
     present = torch.zeros((P,), dtype=torch.bool, device=dev)

@@ -96,3 +96,34 @@ def test_python_surface_mirrors_the_reference(lib):
                                torch.ones(4, 3), torch.zeros(4, 4), 1.0, torch.Tensor([]), torch.eye(4), torch.eye(4),
                                1.0, 1.0, 16, 16, torch.zeros(4, 16, 3), torch.zeros(4, 1, dtype=torch.int32),
                                torch.zeros(3), False, False)
+
+
+def test_both_bindings_are_built_and_drive_one_library(lib):
+    """The compiled torch binding (csrc_torch/r3dgs_torch.cpp -> _r3dgs_torch.so; the reference's layer is a torch C++
+    extension, ext.cpp:16-25) and the ctypes module: the extension is built, is bound to the entry points of the SAME
+    loaded libr3dgs_hip.so, refuses host tensors with the same message, and R3DGS_BINDING selects between them."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    assert os.path.exists(os.path.join(PKG, "diff_gaussian_rasterization", "_r3dgs_torch.so")), "build.py did not build it"
+    assert _C._ext_loaded is not None and _C.binding() == "torch"
+    assert _C._ext_loaded.library_version() == _C.version()
+    for name in ("forward_reserved", "backward", "mark_visible", "bind"):
+        assert callable(getattr(_C._ext_loaded, name))
+    args = (torch.zeros(3), torch.zeros(4, 3), torch.Tensor([]), torch.zeros(4, 1), torch.ones(4, 3), torch.zeros(4, 4), 1.0,
+            torch.Tensor([]), torch.eye(4), torch.eye(4), 1.0, 1.0, 16, 16, torch.zeros(4, 16, 3),
+            torch.zeros(4, 1, dtype=torch.int32), torch.zeros(3), False, False)
+    was = _C.set_binding("ctypes")
+    try:
+        assert _C.binding() == "ctypes"
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            _C.rasterize_gaussians(*args)
+    finally:
+        _C.set_binding(was)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _C.rasterize_gaussians(*args)
+    with pytest.raises(RuntimeError, match="dimensions"):
+        _C.rasterize_gaussians(args[0], torch.zeros(5, 4, device="cpu"), *args[2:])
+    env = dict(os.environ, R3DGS_BINDING="ctypes", PYTHONPATH=PKG)
+    out = subprocess.run([sys.executable, "-c", "from diff_gaussian_rasterization import _C; print(_C.binding(), _C._ext_loaded)"],
+                         env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.stdout.split() == ["ctypes", "None"], out.stdout + out.stderr

@@ -898,6 +898,45 @@ def test_num_rendered_is_lazy_and_queryable(C_):
     assert list(range(10))[:nr] == list(range(10))[:int(nr)]            # usable as an index
 
 
+def test_compiled_and_ctypes_bindings_agree_bit_for_bit(C_):
+    """The compiled torch binding (default when built) and the ctypes marshalling call the same library entry points:
+    forward + backward of the same inputs must agree bit for bit, in strict mode and with the check off, through the
+    autograd wrapper as well; mark_visible likewise."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    assert C_.binding() == "torch", "the compiled binding was not built (reduced-3dgs_amd/build.py)"
+    W, H, P = 304, 192, 8000
+    cam = ss.make_camera(W, H, 220.0, 4)
+    g = ss.make_gaussians(P, cam, seed=70, degree_mode="mixed", scale_mu=0.04)
+    bg = np.array([0.3, 0.2, 0.5], np.float32)
+    dl = ss.upstream_grad(W, H, seed=4) * (W * H)
+    hip_forward(C_, bg, g, cam, H, W, exact=True)      # teaches the advisor this view: both bindings then take the reserved path
+    results = {}
+    for name in ("torch", "ctypes"):
+        was = C_.set_binding(name)
+        try:
+            assert C_.binding() == name
+            fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+            assert fout[0].ticket > 0 and not fout[0].truncated
+            bout = hip_backward(C_, fargs, fout, dl, 0.05)
+            vis = C_.mark_visible(fargs[1], fargs[8], fargs[9])
+            leaves = {k: dev(g[k]).requires_grad_() for k in ("means3D", "opacity", "scales", "rotations", "sh")}
+            means2D = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0
+            means2D.retain_grad()
+            rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, dev(bg), 1.0, dev(cam.world_view_transform),
+                                               dev(cam.full_proj_transform), 3, dev(cam.camera_center), False, False)
+            color, radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=means2D, shs=leaves["sh"],
+                                                  degrees=dev(g["degrees"]), opacities=leaves["opacity"],
+                                                  scales=leaves["scales"], rotations=leaves["rotations"],
+                                                  lambda_sh_sparsity=0.05)
+            (color * dev(dl)).sum().backward()
+            results[name] = [int(fout[0]), fout[0].pairs, fout[1], fout[2], vis, color.detach(), radii, means2D.grad] + \
+                list(bout) + [v.grad for v in leaves.values()]
+        finally:
+            C_.set_binding(was)
+    for a, b in zip(results["torch"], results["ctypes"]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
 def test_exact_forward_returns_the_capacity_of_its_binning_blob(C_):
     """The reference's contract (rasterize_points.cu:202-305): the int the forward returns is the R the backward takes.
     With the opacity-aware rects the pairs binned are fewer than num_rendered; the exact-size forward must still carve its
