@@ -18,8 +18,10 @@
 // headers are used directly).
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm presents its HIP devices under the device type "cuda": the guard and stream accessors that accept that
+// type are the *MasqueradingAsCUDA ones (the plain c10::hip::HIPGuard insists on DeviceType::HIP and throws)
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <map>
 #include <mutex>
@@ -152,7 +154,7 @@ std::tuple<long long, int, int, int, Tensor, Tensor, Tensor, Tensor, Tensor> for
     const Tensor op = dev_f32(opacity, dev), sc = dev_f32(scales, dev), rot = dev_f32(rotations, dev);
     const Tensor cov = dev_f32(cov3D_precomp, dev), vm = dev_f32(viewmatrix, dev), pm = dev_f32(projmatrix, dev);
     const Tensor cp = dev_f32(campos, dev), shc = dev_f32(sh, dev), deg = dev_i32(degrees, dev);
-    const c10::hip::HIPGuard guard(dev);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     api.r3dgs_forward_hint(trains ? 1 : 0);
     const int reserve = api.r3dgs_reserve_hint_view(P, W, H, opt_ptr<float>(vm));
     if (reserve < 0) fail("rasterize_gaussians");
@@ -164,7 +166,7 @@ std::tuple<long long, int, int, int, Tensor, Tensor, Tensor, Tensor, Tensor> for
     Tensor geom = at::empty({(int64_t)blob_bytes(lean ? 1 : 0, P)}, u8);
     Tensor binning = at::empty({(int64_t)blob_bytes(2, P, W, H, reserve)}, u8);
     Tensor img = at::empty({(int64_t)blob_bytes(3, W, H)}, u8);
-    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     const int M = shc.defined() ? (int)shc.size(1) : 0;
     const long long ticket = api.r3dgs_forward_reserved(
         reinterpret_cast<char*>(geom.data_ptr()), reinterpret_cast<char*>(binning.data_ptr()),
@@ -213,8 +215,8 @@ std::vector<Tensor> backward(const Tensor& background, const Tensor& means3D, co
     const Tensor sc = dev_f32(scales, dev), rot = dev_f32(rotations, dev), cov = dev_f32(cov3D_precomp, dev);
     const Tensor vm = dev_f32(viewmatrix, dev), pm = dev_f32(projmatrix, dev), cp = dev_f32(campos, dev);
     const Tensor g = dev_f32(dL_dout_color, dev), shc = dev_f32(sh, dev), deg = dev_i32(degrees, dev), rad = dev_i32(radii, dev);
-    const c10::hip::HIPGuard guard(dev);
-    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     auto blob = [](const Tensor& t) { return t.defined() && t.numel() != 0 ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; };
     const int st = api.r3dgs_backward(
         P, opt_ptr<int>(deg), M, (int)capacity, opt_ptr<float>(bg), W, H, opt_ptr<float>(m3), opt_ptr<float>(shc),
@@ -240,10 +242,10 @@ Tensor mark_visible(const Tensor& means3D, const Tensor& viewmatrix, const Tenso
     Tensor present = at::zeros({P}, at::TensorOptions().dtype(at::kBool).device(dev));
     if (P) {
         const Tensor m3 = dev_f32(means3D, dev), vm = dev_f32(viewmatrix, dev), pm = dev_f32(projmatrix, dev);
-        const c10::hip::HIPGuard guard(dev);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         if (api.r3dgs_mark_visible(P, opt_ptr<float>(m3), opt_ptr<float>(vm), opt_ptr<float>(pm),
                                reinterpret_cast<unsigned char*>(present.data_ptr()),
-                               c10::hip::getCurrentHIPStream(dev.index()).stream()) < 0)
+                               c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream()) < 0)
             fail("mark_visible");
     }
     return present;
