@@ -9,6 +9,7 @@
  *   r3dgs_min_redundancy                 Reduced3DGS::assignFinalRedundancyValue  reduced_3dgs.cu:268-287
  *   r3dgs_kmeans                         Reduced3DGS::kmeans                  reduced_3dgs.cu:290-340
  *   r3dgs_knn                            SimpleKNN::knn / knn_index2          simple-knn/simple_knn.h:17-21, simple_knn.cu:179, :468
+ *   r3dgs_knn_query                      SimpleKNN::knn_indexQ                simple_knn.cu:523-660
  */
 #ifndef R3DGS_REDUCTION_H
 #define R3DGS_REDUCTION_H
@@ -64,6 +65,17 @@ int r3dgs_knn_max_k(void);
 size_t r3dgs_knn_workspace_bytes(int P);
 int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, float* mean_dist3, char* workspace,
               void* stream);
+
+/* SimpleKNN::knn_indexQ (simple-knn/simple_knn.h:22, simple_knn.cu:523-660; distIndexQ of spatial.cu:43-58): for each of
+ * the Q query points points[q_indices[q]], the K nearest (squared Euclidean distance) among the points whose index occurs
+ * in n_indices[0..N) -- a set: duplicates count once --, the query point itself excluded by index.  dists / indices:
+ * [Q,K], ascending by (distance, index); unfilled slots hold FLT_MAX / -1 (the reference leaves its slots in traversal
+ * order and the unfilled ones at FLT_MAX / -1).  A query or candidate index outside [0, P) is ignored (its row stays
+ * unfilled).  1 <= K <= 4096.  Exact, O(Q * N): the operator has no caller in the reference tree.
+ * workspace: r3dgs_knn_query_workspace_bytes(P) bytes of device scratch. */
+size_t r3dgs_knn_query_workspace_bytes(int P);
+int r3dgs_knn_query(int P, int K, const float* points, int Q, const int* q_indices, int N, const int* n_indices, float* dists,
+                    int* indices, char* workspace, void* stream);
 
 /* Per-view densification statistics of a view-parallel training step (no reference equivalent: the reference is
  * single-GPU; this is what train.py:134 and scene/gaussian_model.py:693-695 accumulate per view), fused into one launch:

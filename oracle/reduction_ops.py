@@ -7,6 +7,7 @@ matrix products, GLM itself is an un-vendored submodule of the reference):
   sphere_ellipsoid_intersection  reduced_3dgs.cu:205-238 + redundancy_score.cu:121-159, :185-207
   min_redundancy                 reduced_3dgs.cu:268-287 + redundancy_score.cu:6-27
   kmeans                         reduced_3dgs.cu:290-340 + reduced_3dgs/kmeans.cu:5-53, :73-105
+  knn_query_bruteforce           what simple_knn.cu:523-660 knn_indexQ computes (K nearest of a candidate subset for a query subset)
   knn_bruteforce                 what submodules/simple-knn/simple_knn.cu:143-191 (mean of 3) and :393-466
                                  (K nearest, excluding the query itself) compute; the reference's slot ORDER is an
                                  artefact of its box traversal, the neighbour SET and the distances are the contract.
@@ -176,6 +177,29 @@ def knn_bruteforce(points, K, block=2048):
         order = np.lexsort((part, pd), axis=1)
         d2o[s:s + block, :kk] = np.take_along_axis(pd, order, 1)
         ido[s:s + block, :kk] = np.take_along_axis(part, order, 1)
+    return d2o, ido
+
+
+def knn_query_bruteforce(points, q_indices, n_indices, K):
+    """distIndexQ (simple-knn/spatial.cu:43-58, simple_knn.cu:523-660): for query q = points[q_indices[q]], the K nearest
+    among the SET of points whose index is in n_indices (the reference marks them in a bool mask, so duplicates count
+    once), the query's own index excluded.  -> (d2 fp32[Q,K], idx int32[Q,K]) ascending by (distance, index); unfilled
+    slots FLT_MAX / -1; indices outside [0, P) are ignored."""
+    p = points.astype(F)
+    P = p.shape[0]
+    Q = len(q_indices)
+    d2o = np.full((Q, K), np.finfo(F).max, F)
+    ido = np.full((Q, K), -1, np.int32)
+    cand = np.unique(np.asarray([n for n in n_indices if 0 <= n < P], np.int64))
+    for r, qi in enumerate(q_indices):
+        if not (0 <= qi < P) or cand.size == 0:
+            continue
+        c = cand[cand != qi]
+        dx, dy, dz = p[c, 0] - p[qi, 0], p[c, 1] - p[qi, 1], p[c, 2] - p[qi, 2]
+        d2 = ((dx * dx + dy * dy) + dz * dz).astype(F)
+        order = np.lexsort((c, d2))[:K]
+        d2o[r, :order.size] = d2[order]
+        ido[r, :order.size] = c[order]
     return d2o, ido
 
 

@@ -16,6 +16,7 @@
 // The result is canonical: ascending by (distance, index), ties at the K-th place resolved by the smaller index.
 // Compiled without FMA contraction so that the box lower bounds (monotone in every rounding step) can never exceed
 // a contained point's distance computed by the same expression: the search is exact in fp32.
+#include <algorithm>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -378,6 +379,97 @@ __global__ __launch_bounds__(kWave) void knn_kernel(int P, int K, const float4* 
     if (MEAN3) mean3[my_id] = ((out_d[0] + out_d[1]) + out_d[2]) / 3.0f;
 }
 
+
+// ---- distIndexQ: K nearest among a CANDIDATE subset for a QUERY subset (SimpleKNN::knn_indexQ, simple_knn.cu:523-660) ----
+// The reference walks its Morton boxes from the query outward and filters by an is_neighbour mask.  This operator has no
+// caller in the reference tree, so it is built for exactness and simplicity, not for the million-point case: one lane per
+// query, the candidate list streamed through LDS in tiles that every lane scans with broadcast reads (O(Q * N) distance
+// evaluations, ~8 flops each).  A query's K-best list lives in ITS output row, kept ascending by (distance, index); an
+// insertion shifts the tail (rare once the list is warm).  Duplicate candidate indices count once (the reference's mask):
+// the first kernel elects one owner per distinct index.  The point itself is excluded by index, as in the reference.
+constexpr int kQTile = 1024;
+
+__global__ __launch_bounds__(256) void knnq_owner_init_kernel(int P, int* __restrict__ owner)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) owner[i] = 0x7fffffff;
+}
+
+__global__ __launch_bounds__(256) void knnq_owner_kernel(int P, int N, const int* __restrict__ n_indices, int* __restrict__ owner)
+{
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) {
+        const int n = n_indices[j];
+        if (n >= 0 && n < P) atomicMin(&owner[n], j);   // lowest position wins: deterministic
+    }
+}
+
+__global__ __launch_bounds__(256) void knnq_kernel(int P, int K, const float* __restrict__ pts, int Q,
+                                                   const int* __restrict__ q_indices, int N, const int* __restrict__ n_indices,
+                                                   const int* __restrict__ owner, float* __restrict__ dists,
+                                                   int* __restrict__ indices)
+{
+    __shared__ float4 s_c[kQTile];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < Q;
+    int qi = live ? q_indices[q] : -1;
+    const bool ok = qi >= 0 && qi < P;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (ok) {
+        qx = pts[3 * qi];
+        qy = pts[3 * qi + 1];
+        qz = pts[3 * qi + 2];
+    }
+    float* const bd = dists + (size_t)(live ? q : 0) * K;
+    int* const bi = indices + (size_t)(live ? q : 0) * K;
+    if (live)
+        for (int j = 0; j < K; j++) {
+            bd[j] = kFltMax;
+            bi[j] = -1;
+        }
+    int filled = 0;
+    float wd = kFltMax;       // the list's last entry (worst kept): (wd, wi)
+    int wi = 0x7fffffff;
+    for (int base = 0; base < N; base += kQTile) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < kQTile; t += 256) {
+            const int j = base + t;
+            float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (j < N) {
+                const int n = n_indices[j];
+                if (n >= 0 && n < P && owner[n] == j) c = make_float4(pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], __int_as_float(n));
+            }
+            s_c[t] = c;
+        }
+        __syncthreads();
+        if (!live || !ok) continue;
+        const int cnt = min(kQTile, N - base);
+        for (int t = 0; t < cnt; t++) {
+            const float4 c = s_c[t];
+            const int n = __float_as_int(c.w);
+            if (n < 0 || n == qi) continue;
+            const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (filled == K && !(d < wd || (d == wd && n < wi))) continue;
+            // insert (d, n) into the ascending row; the tail moves one slot down, the last entry drops out when full
+            int pos = filled < K ? filled : K - 1;
+            while (pos > 0) {
+                const float pd = bd[pos - 1];
+                const int pi = bi[pos - 1];
+                if (pd < d || (pd == d && pi < n)) break;
+                bd[pos] = pd;
+                bi[pos] = pi;
+                pos--;
+            }
+            bd[pos] = d;
+            bi[pos] = n;
+            if (filled < K) filled++;
+            if (filled == K) {
+                wd = bd[K - 1];
+                wi = bi[K - 1];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -423,6 +515,27 @@ int r3dgs_knn(int P, int K, const float* points, float* dists, int* indices, flo
         else
             knn_kernel<false><<<nb, kWave, lds, s>>>(P, K, w.sorted, w.box_min, w.box_max, dists, indices, nullptr);
         r3::check_launch("knn", s, false);
+        return 0;
+    });
+}
+
+size_t r3dgs_knn_query_workspace_bytes(int P) { return P > 0 ? 4 * (size_t)P + 256 : 256; }
+
+int r3dgs_knn_query(int P, int K, const float* points, int Q, const int* q_indices, int N, const int* n_indices, float* dists,
+                    int* indices, char* workspace, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (Q <= 0) return 0;
+        if (K < 1 || K > 4096) throw r3::Error("K must be in [1, 4096]");
+        if (P < 0 || N < 0) throw r3::Error("negative size");
+        if (!q_indices || !dists || !indices || !workspace || (P > 0 && !points) || (N > 0 && !n_indices))
+            throw r3::Error("a required pointer is NULL");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        int* owner = reinterpret_cast<int*>(workspace);
+        if (P > 0) knnq_owner_init_kernel<<<std::min((P + 255) / 256, 1024), 256, 0, s>>>(P, owner);
+        if (N > 0) knnq_owner_kernel<<<std::min((N + 255) / 256, 1024), 256, 0, s>>>(P, N, n_indices, owner);
+        knnq_kernel<<<(Q + 255) / 256, 256, 0, s>>>(P, K, points, Q, q_indices, N, n_indices, owner, dists, indices);
+        r3::check_launch("knn_query", s, false);
         return 0;
     });
 }

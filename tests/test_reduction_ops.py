@@ -258,6 +258,41 @@ def test_gpu_knn_exact(P, K):
     _check_knn(pts, K)
 
 
+def test_oracle_knn_query_is_knn_on_the_full_sets():
+    """knn_query_bruteforce with every point as query and candidate is knn_bruteforce."""
+    rng = np.random.default_rng(3)
+    p = rng.normal(0, 1, (300, 3)).astype(np.float32)
+    p[10] = p[11]                                    # a duplicate position: tie decided by index
+    allidx = np.arange(300, dtype=np.int32)
+    d, i = ro.knn_query_bruteforce(p, allidx, allidx, 7)
+    d0, i0 = ro.knn_bruteforce(p, 7)
+    assert np.array_equal(d, d0) and np.array_equal(i, i0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,Q,N,K", [(5000, 700, 1800, 12), (3000, 3000, 3000, 5), (513, 40, 3, 8), (2000, 257, 1025, 1),
+                                      (100, 10, 0, 4)])
+def test_gpu_knn_query_exact(P, Q, N, K):
+    """simple_knn._C.distIndexQ (spatial.cu:43-58): bit-exact against the brute force, including duplicate candidate
+    indices (a set), queries that are candidates themselves (excluded by index), fewer candidates than K, out-of-range
+    indices and an empty candidate list."""
+    from simple_knn._C import distIndexQ
+    rng = np.random.default_rng(P + Q + N + K)
+    pts = (rng.normal(0, 1, (P, 3)) * np.array([2.0, 1.0, 0.3])).astype(np.float32)
+    pts[5] = pts[6]
+    qi = rng.integers(0, P, Q).astype(np.int32)
+    ni = rng.integers(0, P, N).astype(np.int32)      # with repetitions
+    if N > 10:
+        ni[:5] = qi[:5]                              # queries among their own candidates
+        ni[7] = -3                                   # ignored
+        qi[-1] = P + 9                               # ignored: row stays unfilled
+    d, i = distIndexQ(_dev(pts), _dev(qi), _dev(ni), K)
+    assert tuple(d.shape) == (Q * K,) and tuple(i.shape) == (Q * K,) and i.dtype == torch.int32
+    want_d, want_i = ro.knn_query_bruteforce(pts, qi, ni, K)
+    assert np.array_equal(d.view(Q, K).cpu().numpy(), want_d)
+    assert np.array_equal(i.view(Q, K).cpu().numpy(), want_i)
+
+
 @pytest.mark.gpu
 def test_gpu_knn_duplicates_and_clusters():
     rng = np.random.default_rng(4)
