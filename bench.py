@@ -34,9 +34,9 @@ import torch.distributed as dist  # noqa: E402
 import synth_scene as ss  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
 VALU_RATE = os.path.join("profiles", "r03_valu_rate.txt")
-KERNEL_STATS = os.path.join("profiles", "r03_kernel_stats_bench_500k_1600x1062.csv")
+KERNEL_STATS = os.path.join("profiles", "r04_kernel_stats_bench_500k_1600x1062.csv")
 
 
 CLOCK_WARMUP_STEPS = 50   # untimed, ahead of the --warmup steps (see main())
@@ -74,7 +74,7 @@ STAGE_KERNELS = {
     # (the one-workgroup kernel that orders the tiles heaviest first runs inside this stage's events too)
     "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
                   ("r3::tile_order_kernel", 1, False)],
-    "preprocess_bwd": [("r3::preprocess_bwd_kernel<true>", 1, False)],
+    "preprocess_bwd": [("r3::preprocess_bwd_kernel<true, true>", 1, False)],   # <dense degree-3 rows, covariance chain in double>
 }
 
 
@@ -521,6 +521,7 @@ def main():
                    "sh_degree": {"all3": 3, "all0": 0}.get(w["degree_mode"], "mixed 0-3"), "sh_coeffs_mean": round(Kbar, 2),
                    "views_per_step": world, "visible_mean": round(V_mean), "num_rendered_mean": round(R_mean),
                    "pairs_binned_mean": round(pairs_mean), "tight_rects": _C.tight_rects(),
+                   "binding": _C.binding(), "f64_covariance_chain": _C.f64_chain(),
                    "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                    "exchange": ("all-to-all + local SUM/MAX combine + all-gather of one flat buffer (59 fp32 grads + 2 "
                                 "stats + radii per Gaussian) after every step's backward, complete before the next step "

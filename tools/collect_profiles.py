@@ -1,4 +1,4 @@
-"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r03_* and regenerates profiles/README.md."""
+"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r04_* and regenerates profiles/README.md."""
 import os
 import shutil
 import subprocess
@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-R = "r03"
+R = "r04"
 
 
 def last_line(src, dst, mode="w"):
@@ -23,14 +23,16 @@ last_line("bench_burner64_b.log", f"{R}_bench_n1_cpu_burner64.jsonl", "a")
 shutil.copy(os.path.join(G, "prof", "r_kernel_stats.csv"), os.path.join(P, f"{R}_kernel_stats_bench_500k_1600x1062.csv"))
 shutil.copy(os.path.join(G, "pmc_summary.json"), os.path.join(P, f"{R}_pmc_summary.json"))
 # the refresh visit runs the rate loops after the benches, i.e. on a warm chip (lower clock): kept apart from the table of
-# the cold visit (profiles/r03_valu_rate.txt, GPU call of its own), whose rates bench.py's VALU_CYCLES are
+# the cold visit (profiles/r03_valu_rate.txt, GPU call of its own, round 3), whose rates bench.py's VALU_CYCLES are
 shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate_warm.txt"))
 shutil.copy(os.path.join(G, "other_workloads.jsonl"), os.path.join(P, f"{R}_other_workloads.jsonl"))
 for tl in ("bwd_timeline", "fwd_timeline"):
     if os.path.exists(os.path.join(G, tl + ".txt")):
         shutil.copy(os.path.join(G, tl + ".txt"), os.path.join(P, f"{R}_{tl}.txt"))
-open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-40:]) +
-                                                       "\n" + open(os.path.join(G, "smoke.log")).read()[-1200:])
+open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write(open(os.path.join(G, "pytest_gpu.log")).read() +
+                                                       "\n" + open(os.path.join(G, "smoke.log")).read()[-1600:])
+if os.path.exists(os.path.join(G, "host_bound.log")):
+    shutil.copy(os.path.join(G, "host_bound.log"), os.path.join(P, f"{R}_host_bound_bindings.txt"))
 for wl, short in (("garden_like_2M_1600x1062", "garden_like_2M"), ("train_like_6M_1920x1080", "train_like_6M")):
     shutil.copy(os.path.join(G, f"prof_{wl}", "r_kernel_stats.csv"), os.path.join(P, f"{R}_kernel_stats_{short}.csv"))
 sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "profiles_readme.py")]))

@@ -1,4 +1,4 @@
-"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r03_*).
+"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r04_*).
 
     python tools/profiles_readme.py
 
@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-R = "r03"
+R = "r04"
+PREV = "r03"   # bracketed numbers; also where the (unchanged) blend-kernel timelines and the VALU calibration live
 
 
 def jl(name):
@@ -32,9 +33,9 @@ d50 = jl(f"{R}_bench_n1_default.json")[0]
 ab = jl(f"{R}_bench_n1_ab.jsonl")
 burn = jl(f"{R}_bench_n1_cpu_burner64.jsonl")
 others = jl(f"{R}_other_workloads.jsonl")
-old_others = {o["config"]["workload"]: o for o in jl("r02_other_workloads.jsonl")}
+old_others = {o["config"]["workload"]: o for o in jl(f"{PREV}_other_workloads.jsonl")}
 ks = kstats(f"{R}_kernel_stats_bench_500k_1600x1062.csv")
-ks2 = kstats("r02_kernel_stats_bench_500k_1600x1062.csv")
+ks2 = kstats(f"{PREV}_kernel_stats_bench_500k_1600x1062.csv")
 pmc = json.load(open(os.path.join(P, f"{R}_pmc_summary.json")))
 st = d50["stages"]
 BWD, FWD = "r3::blend_bwd_kernel<4, true, false>", "r3::blend_fwd_kernel<1, false>"
@@ -62,7 +63,7 @@ def stages_of(d):
                                                      "preprocess_bwd"))
 
 
-valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if " 8 waves/SIMD" in l]
+valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{PREV}_valu_rate.txt")) if " 8 waves/SIMD" in l]
 
 
 def rate(prefix):
@@ -73,23 +74,24 @@ def rate(prefix):
 
 
 timeline = ""
-tl_path = os.path.join(P, f"{R}_bwd_timeline.txt")
+tl_path = os.path.join(P, f"{PREV}_bwd_timeline.txt")
 if os.path.exists(tl_path):
     timeline = "".join(l for l in open(tl_path) if not l.startswith("/opt"))
 fwd_timeline = ""
-if os.path.exists(os.path.join(P, f"{R}_fwd_timeline.txt")):
-    fwd_timeline = "".join(l for l in open(os.path.join(P, f"{R}_fwd_timeline.txt")) if not l.startswith("/opt"))
+if os.path.exists(os.path.join(P, f"{PREV}_fwd_timeline.txt")):
+    fwd_timeline = "".join(l for l in open(os.path.join(P, f"{PREV}_fwd_timeline.txt")) if not l.startswith("/opt"))
 
-new = f'''# profiles/ — measurements on MI355X (round 3)
+new = f'''# profiles/ — measurements on MI355X (round 4)
 
-All `r03_*` files come from ONE visit of `tools/refresh_profiles.sh` (`tools/collect_profiles.py` copies the results here
+All `r04_bench_*`, `r04_kernel_stats_*`, `r04_pmc_summary.json` and `r04_valu_rate_warm.txt` files come from ONE visit of `tools/refresh_profiles.sh` (`tools/collect_profiles.py` copies the results here
 and runs `tools/profiles_readme.py`, which generates this file from them) to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch
 2.10+rocm7.0; 256 visible CPUs, **cgroup CPU quota 16**).  The command profiled is always `python bench.py` (workload
 `metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe, 8 cameras; V̄ =
 {d50['config']['visible_mean'] / 1e3:.0f}k visible, `num_rendered` R̄ = {d50['config']['num_rendered_mean'] / 1e6:.2f} M — the reference's count, which the byte
 formulas are written in — of which {d50['config']['pairs_binned_mean'] / 1e6:.2f} M (tile, Gaussian) pairs are binned (opacity-aware rects), N = 1.70 Mpix).
-These are this build's own visits; **the number of record is the driver's `BENCH_r03.json`**.  `r01_*` / `r02_*` files are
-kept for comparison.
+These are this build's own visits; **the number of record is the driver's `BENCH_r04.json`**.  `r01_*` … `r03_*` files are
+kept for comparison; the blend kernels did not change this round, so their workgroup timelines and the VALU-rate
+calibration are round 3's (`r03_bwd_timeline*.txt`, `r03_fwd_timeline.txt`, `r03_valu_rate.txt`).
 
 | file | what |
 |---|---|
@@ -99,12 +101,15 @@ kept for comparison.
 | `{R}_bench_n1_cpu_burner64.jsonl` | the driver's form twice while `tools/cpu_burn.py 64` exhausts the container's CPU quota |
 | `{R}_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
 | `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` and `roofline.valu` |
-| `{R}_valu_rate.txt`, `{R}_valu_rate_warm.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` (the first from a visit that ran nothing else, the second at the end of the refresh visit, on a warm chip: the wall-clock rates are ~10 % lower there, the clock having come down) |
-| `{R}_bwd_timeline.txt`, `{R}_fwd_timeline.txt` | `tools/bwd_timeline.py [fwd]` (debug builds `-DR3_TIMELINE` / `-DR3_TIMELINE_FWD`): when and where every workgroup of the backward / forward blend ran |
-| `{R}_bwd_timeline_row_major.txt` | the same for the backward blend before its tiles were started heaviest first (mid-round build, 5 waves per SIMD) |
+| `{PREV}_valu_rate.txt`, `{R}_valu_rate_warm.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` (the first from a visit that ran nothing else, the second at the end of the refresh visit, on a warm chip: the wall-clock rates are ~10 % lower there, the clock having come down) |
+| `{PREV}_bwd_timeline.txt`, `{PREV}_fwd_timeline.txt` | `tools/bwd_timeline.py [fwd]` (debug builds `-DR3_TIMELINE` / `-DR3_TIMELINE_FWD`): when and where every workgroup of the backward / forward blend ran |
+| `{PREV}_bwd_timeline_row_major.txt` | the same for the backward blend before its tiles were started heaviest first (mid-round build, 5 waves per SIMD) |
 | `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
 | `{R}_kernel_stats_garden_like_2M.csv`, `{R}_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads |
-| `{R}_gpu_tests.txt` | tail of `pytest tests -m gpu -s` (achieved gradient errors, the own-loop report) and the smoke line of that visit |
+| `{R}_gpu_tests.txt` | `pytest tests -m gpu -s`: every gradient distance measured (HIP vs the fp32 oracle, HIP vs the double evaluation, fp32 oracle vs the double evaluation, with the test each worst case came from), the own-loop report |
+| `{R}_host_bound_bindings.txt` | `tools/host_bound_bench.py`: steps/s of the 10k and 300k workloads through the ctypes marshalling and through the compiled torch binding (strict mode) |
+| `{R}_sweep_6M_depth_sort_colour.txt` | 6 M Gaussians @1920×1080: bucketed depth sort with the colour stream inside (default) against the generic rocPRIM sort + a standalone colour kernel, colour grid sizes, bucket loads, colour splits |
+| `{R}_bwd_tail_model.txt` | `tools/bwd_tail_model.py`: processor-sharing model of the backward blend's schedule on the real tile weights — what splitting tiles along their lists could buy |
 
 ## Headline (N = 1)
 
@@ -113,15 +118,16 @@ kept for comparison.
 | training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, **strict**: every forward checks its pair count before returning), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) |
 | the driver's form, 20 steps / 5 warm-up | **{d20['value']} it/s** ({d20['ms_per_step']} ms/step = {d20['host']['step_over_gpu_stage_sum']} × Σ stage ms); passes in the timed region: {d20['config']['passes_in_timed_region']} |
 | same, strict mode off (round-2 behaviour) | {ab[0]['value']} it/s — the check costs nothing measurable: the pass publishes its numbers ~40 µs after it starts and the GPU has the rest of the forward to work on while the host goes on |
+| the method's own configuration, `lambda_sh_sparsity = 0.1` (full_eval.py:33,44; the backward then reads the SH rows) | {d50['value_sh_sparsity']} it/s ({d50['sh_sparsity']['ms_per_step']} ms/step; `preprocess_bwd` {d50['sh_sparsity']['stages_ms']['preprocess_bwd']} ms against {st['preprocess_bwd']['avg_ms']}) |
 | same, reference rects (`R3DGS_TIGHT_RECT=0`) | {ab[1]['value']} it/s, stages {stages_of(ab[1])} ms against {stages_of(d20)} ms |
 | render-only (forward, `render.py`'s FPS path) | **{d50['render_fps']} FPS = {d50['render_mpix_per_s'] / 1000:.2f} Gpix/s** |
-| whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %) |
+| whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes, SURVEY 8d) → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %); bytes the counters saw move per step: {(d50['iter_roofline'].get('counter_traffic_bytes') or 0) / 1e9:.2f} GB = {100 * (d50['iter_roofline'].get('frac_counter_traffic') or 0):.1f} % — that one is HBM utilisation, the first is not |
 | dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), `roofline.valu.frac` {d50['roofline']['valu']['frac'] if d50['roofline'].get('valu') else 'n/a'} (calibrated VALU issue floor / stage time) |
 | CPU baseline (SURVEY 8d) | configs[0] PyTorch restatement, {d50['cpu_baseline']['threads_effective']} threads: {d50['cpu_baseline']['value']} it/s; the bench workload by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
 | host under `tools/cpu_burn.py 64` | {burn[0]['value']} / {burn[1]['value']} it/s (throttled periods inside the timed region: {burn[0]['host']['cgroup']['throttled_periods_in_timed_region']} / {burn[1]['host']['cgroup']['throttled_periods_in_timed_region']}) |
 | BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are VALU-bound: see below) |
 
-## Where the {d50['ms_per_step']} ms go (HIP-event stage timers; kernel times from rocprofv3, round 2 in brackets)
+## Where the {d50['ms_per_step']} ms go (HIP-event stage timers; kernel times from rocprofv3, round 3 in brackets)
 
 | stage | avg ms | kernels (rocprofv3 avg µs) | algorithmic bytes (SURVEY 8d) | GB/s vs 8 TB/s |
 |---|---|---|---|---|
@@ -129,10 +135,10 @@ kept for comparison.
 | depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f}, `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
 | tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f} [{ks2['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}], `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f} [{ks2['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}], `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} — real traffic ≈ 9× lower |
 | blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks[FWD]:.1f} [{ks2[FWD]:.1f}] | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
-| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true, false>` {ks[BWD]:.1f} [{ks2['r3::blend_bwd_kernel<4, true>']:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}], `tile_order` {ks['r3::tile_order_kernel']:.1f} | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
-| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel` {ks['r3::preprocess_bwd_kernel<true>']:.1f} [{ks2['r3::preprocess_bwd_kernel']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
+| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true, false>` {ks[BWD]:.1f} [{ks2[BWD]:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}], `tile_order` {ks['r3::tile_order_kernel']:.1f} | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
+| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel<true, true>` (covariance chain in double) {ks['r3::preprocess_bwd_kernel<true, true>']:.1f} [{ks2['r3::preprocess_bwd_kernel<true>']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
 
-## What the VALU costs on this chip (`{R}_valu_rate.txt`) and what that says about the blend kernels
+## What the VALU costs on this chip (`{PREV}_valu_rate.txt`) and what that says about the blend kernels
 
 Cycles per wave64 instruction and SIMD at 8 waves per SIMD, from the wall-clock rate at 2.4 GHz: `v_add_f32` {rate('v_add_f32 ')},
 `v_mul_f32` {rate('v_mul_f32')}, `v_mov_b32` {rate('v_mov_b32')}, `v_fmac_f32` {rate('v_fmac_f32')}, `v_fma_f32` {rate('v_fma_f32  ')} — with one SGPR source
@@ -156,9 +162,9 @@ reductions are counted as `add_f32` here although they cost 4.2 cycles, so the f
 i.e. with the tiles started heaviest first (`blend.hip tile_order_kernel`) a CU is full — 24 single-wave workgroups at 80
 registers — for seven tenths of its span and the CUs end within ~9 % of each other; the longest workgroup lives for the
 whole span of its CU, so the kernel is as long as its heaviest tile is slow.  In row-major order
-(`{R}_bwd_timeline_row_major.txt`, taken earlier in the round at 5 per SIMD) the residency decayed from the middle of the
+(`{PREV}_bwd_timeline_row_major.txt`, round 3, 5 per SIMD) the residency decayed from the middle of the
 span on (20, 20, 20, 22, 22, 17, 12, 9, 6, 3) and the kernel took 0.340 ms instead of {ks[BWD] / 1e3:.3f}.  The forward
-blend's 26 800 one-wave workgroups (`{R}_fwd_timeline.txt`) show the same kind of tail, without a predictor to order by:
+blend's 26 800 one-wave workgroups (`{PREV}_fwd_timeline.txt`) show the same kind of tail, without a predictor to order by:
 
 ```
 {fwd_timeline.strip()}
@@ -179,12 +185,12 @@ instead of the two `ds_bpermute` of the reduction +2 %; hand-packed `v_pk_*_f32`
 {row(FWD)}
 {row(BWD)}
 {row('r3::pair_reduce_kernel')}
-{row('r3::preprocess_bwd_kernel<true>')}
+{row('r3::preprocess_bwd_kernel<true, true>')}
 {row('r3::depth_sort_color_kernel<2, false>')}
 {row('r3::emit_pairs_kernel<r3::IoNarrow>')}
 {row('r3::radix_scatter_kernel<r3::IoNarrow, 7>')}
 
-## Other workloads (`{R}_other_workloads.jsonl`, 20 steps, 4 cameras; round 2 in brackets)
+## Other workloads (`{R}_other_workloads.jsonl`, 20 steps, 4 cameras; round 3 in brackets)
 
 | workload | it/s | ms/step | R̄ (reference) / pairs binned | stage ms (pre / depth+colour / binning / blend fwd / blend bwd / pre bwd) | render FPS |
 |---|---|---|---|---|---|
@@ -196,8 +202,8 @@ for o in others:
             f"{o['config'].get('pairs_binned_mean', 0) / 1e6:.2f} M | {stages_of(o)} | {o['render_fps']} [{prev['render_fps'] if prev else '-'}] |\n")
 new += '''
 The per-Gaussian stages dominate above 2 M Gaussians (6 M: geometry + depth sort + binning + per-Gaussian backward are two
-thirds of the step).  Of VERDICT r2's bars for these shapes the one at 2 M (>= 750 it/s) is met, the one at 6 M (>= 360 it/s)
-is not; what it would need is listed in DESIGN.md section 11.
+thirds of the step).  VERDICT r3's bars for these shapes (6 M >= 360 it/s, 5 M >= 430) are not met; the sweep of
+`r04_sweep_6M_depth_sort_colour.txt` and DESIGN.md section 11 say what was tried and what it would need.
 '''
 open(os.path.join(P, "README.md"), "w").write(new)
 print("wrote profiles/README.md,", len(new.splitlines()), "lines")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit that regenerates everything under profiles/r03_* (run through gpurun; results land in gpurun_out/,
+# One GPU-box visit that regenerates everything under profiles/r04_* (run through gpurun; results land in gpurun_out/,
 # tools/collect_profiles.py copies them into profiles/ and regenerates profiles/README.md).
 set -u
 export PYTHONPATH=$PWD:$PWD/reduced-3dgs_amd TMPDIR=/tmp
@@ -28,6 +28,7 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_
   i=$((i+1))
 done
 python tools/pmc_summary.py > gpurun_out/pmc_summary.log 2>&1
+( timeout 300 python tools/host_bound_bench.py 500 ) > gpurun_out/host_bound.log 2>&1; echo "host_bound rc=$? $(tail -1 gpurun_out/host_bound.log)" >> $S
 bash tools/other_workloads.sh > gpurun_out/other.log 2>&1
 for wl in garden_like_2M_1600x1062 train_like_6M_1920x1080; do
   ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$wl -o r -- python $ROOT/bench.py --workload $wl --steps 10 --warmup 3 --cameras 4 --no-cpu-baseline ) > gpurun_out/prof_$wl.log 2>&1
