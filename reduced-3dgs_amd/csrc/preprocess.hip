@@ -202,8 +202,10 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
 // workgroups no room -- the depth scatter kernel took 46 us instead of 14 us beside it.
 constexpr size_t kColorLds = sizeof(float) * (kPreBlock / 64) * kWaveShFloats;
 
-// chunks [first + wg, last) in steps of n_wg, 256 Gaussians each; smem: kColorLds bytes
-template <bool RAGGED>
+// chunks [first + wg, last) in steps of n_wg, BLOCK Gaussians each (BLOCK = workgroup size); smem: BLOCK / 64 wave windows.
+// BLOCK = 64 (standalone kernel only): single-wave workgroups -- 12 per CU instead of 3 of four waves: no barrier couples
+// the waves' load / evaluate phases, so they drift apart and one wave's loads fly while another evaluates.
+template <bool RAGGED, int BLOCK = kPreBlock>
 __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int first, int last, int wg, int n_wg)
 {
     float(*s_sh)[kWaveShFloats] = reinterpret_cast<float(*)[kWaveShFloats]>(smem);
@@ -211,9 +213,9 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
     const int P = a.in.P, M = a.in.M;
     const bool rows48 = !RAGGED && M == 16;   // dense degree-3 tensor (wave-uniform)
   for (int blk = first + wg; blk < last; blk += n_wg) {
-    const int i = blk * kPreBlock + tid;
+    const int i = blk * BLOCK + tid;
     const bool valid = i < P;
-    const int wave_first = blk * kPreBlock + wave * 64;
+    const int wave_first = blk * BLOCK + wave * 64;
     const bool vis = valid && a.tiles[i] > 0;
     const bool need_sh = vis && (a.in.colors_precomp == nullptr);
 
@@ -299,12 +301,12 @@ __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int fir
 }
 
 // standalone colour kernel (generic depth sort path, R3DGS_COLOR_FUSE=0): small persistent grid
-template <bool RAGGED>
-__global__ __launch_bounds__(kPreBlock) void preprocess_color_kernel(const PreArgs* __restrict__ ap)
+template <bool RAGGED, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void preprocess_color_kernel(const PreArgs* __restrict__ ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PreArgs a = *ap;
-    color_role<RAGGED>(a, smem, 0, a.color_blocks, (int)blockIdx.x, (int)gridDim.x);
+    color_role<RAGGED, BLOCK>(a, smem, 0, (a.in.P + BLOCK - 1) / BLOCK, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- depth-sort kernels carrying a share of the colour stream in extra workgroups -------------------------------
@@ -344,12 +346,21 @@ void issue_preprocess_geom(const FwdPlan& p, FwdPassArgs* dst, const FwdPassArgs
 
 void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s)
 {
-    const int blocks = (p.P + kPreBlock - 1) / kPreBlock;   // == a->color_blocks
-    const int grid = p.color_grid > 0 && blocks > p.color_grid ? p.color_grid : blocks;
-    if (p.ragged)
-        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(grid), dim3(kPreBlock), kColorLds, s, a);
-    else
-        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(grid), dim3(kPreBlock), kColorLds, s, a);
+    static const int block = env_int("R3DGS_COLOR_BLOCK", 256, 64, 256) == 64 ? 64 : 256;   // workgroup size of THIS kernel
+    const int blocks = (p.P + block - 1) / block;
+    const int want = p.color_grid > 0 ? p.color_grid * (kPreBlock / block) : blocks;
+    const int grid = blocks > want ? want : blocks;
+    const size_t lds = kColorLds / (kPreBlock / block);
+    if (block == 64) {
+        if (p.ragged)
+            hipLaunchKernelGGL((preprocess_color_kernel<true, 64>), dim3(grid), dim3(64), lds, s, a);
+        else
+            hipLaunchKernelGGL((preprocess_color_kernel<false, 64>), dim3(grid), dim3(64), lds, s, a);
+    } else if (p.ragged) {
+        hipLaunchKernelGGL((preprocess_color_kernel<true, kPreBlock>), dim3(grid), dim3(kPreBlock), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((preprocess_color_kernel<false, kPreBlock>), dim3(grid), dim3(kPreBlock), lds, s, a);
+    }
 }
 
 template <int STEP, bool RAGGED>
@@ -389,9 +400,9 @@ void prepare_depth_bucket_sort(int nb)
     opt_in_lds<2, false>(bs);
     opt_in_lds<2, true>(bs);
     if (kColorLds > 48 * 1024) {
-        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<false>),
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<false, kPreBlock>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
-        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<true>),
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<true, kPreBlock>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
     }
     prepared_nb = nb;

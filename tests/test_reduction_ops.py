@@ -276,6 +276,7 @@ def test_gpu_knn_query_exact(P, Q, N, K):
     """simple_knn._C.distIndexQ (spatial.cu:43-58): bit-exact against the brute force, including duplicate candidate
     indices (a set), queries that are candidates themselves (excluded by index), fewer candidates than K, out-of-range
     indices and an empty candidate list."""
+    import torch
     from simple_knn._C import distIndexQ
     rng = np.random.default_rng(P + Q + N + K)
     pts = (rng.normal(0, 1, (P, 3)) * np.array([2.0, 1.0, 0.3])).astype(np.float32)

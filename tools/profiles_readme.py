@@ -48,6 +48,9 @@ for v_ in (vb, vf):   # this file prices the kernels of the committed kernel tra
     v_["frac"] = round(v_["floor_ms"] / v_["kernel_ms"], 3)
 
 
+CTR_BYTES = sum(bench.pmc_traffic(k_, "metric_500k_1600x1062") for k_ in bench.STAGE_KERNELS)
+
+
 def row(k):
     v = pmc[k]
     wc = v["SQ_WAVE_CYCLES"]
@@ -121,8 +124,8 @@ calibration are round 3's (`r03_bwd_timeline*.txt`, `r03_fwd_timeline.txt`, `r03
 | the method's own configuration, `lambda_sh_sparsity = 0.1` (full_eval.py:33,44; the backward then reads the SH rows) | {d50['value_sh_sparsity']} it/s ({d50['sh_sparsity']['ms_per_step']} ms/step; `preprocess_bwd` {d50['sh_sparsity']['stages_ms']['preprocess_bwd']} ms against {st['preprocess_bwd']['avg_ms']}) |
 | same, reference rects (`R3DGS_TIGHT_RECT=0`) | {ab[1]['value']} it/s, stages {stages_of(ab[1])} ms against {stages_of(d20)} ms |
 | render-only (forward, `render.py`'s FPS path) | **{d50['render_fps']} FPS = {d50['render_mpix_per_s'] / 1000:.2f} Gpix/s** |
-| whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes, SURVEY 8d) → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %); bytes the counters saw move per step: {(d50['iter_roofline'].get('counter_traffic_bytes') or 0) / 1e9:.2f} GB = {100 * (d50['iter_roofline'].get('frac_counter_traffic') or 0):.1f} % — that one is HBM utilisation, the first is not |
-| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), `roofline.valu.frac` {d50['roofline']['valu']['frac'] if d50['roofline'].get('valu') else 'n/a'} (calibrated VALU issue floor / stage time) |
+| whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes, SURVEY 8d) → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %); bytes the counters saw move per step (`{R}_pmc_summary.json`, ×2 on the wide-load kernels' FETCH_SIZE): {CTR_BYTES / 1e9:.2f} GB = {100 * CTR_BYTES * d50['value'] / 8e12:.1f} % — that one is HBM utilisation, the first is not |
+| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), calibrated VALU issue floor / kernel time {vb['frac']} (the bench lines of this visit were taken before its counter passes existed, so their own `roofline.traffic` / `roofline.valu` are null; the driver's line cites the committed counters) |
 | CPU baseline (SURVEY 8d) | configs[0] PyTorch restatement, {d50['cpu_baseline']['threads_effective']} threads: {d50['cpu_baseline']['value']} it/s; the bench workload by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
 | host under `tools/cpu_burn.py 64` | {burn[0]['value']} / {burn[1]['value']} it/s (throttled periods inside the timed region: {burn[0]['host']['cgroup']['throttled_periods_in_timed_region']} / {burn[1]['host']['cgroup']['throttled_periods_in_timed_region']}) |
 | BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are VALU-bound: see below) |
