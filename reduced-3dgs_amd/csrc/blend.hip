@@ -446,7 +446,28 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
+#ifdef R3_SPLIT_EMU
+    // TIMING EMULATION ONLY (gradients are WRONG in this build): what would it buy to walk the deep and the shallow half of a
+    // heavy tile's list in two workgroups?  Twice the grid.  Units [0, n): the SHALLOW halves of the split tiles, in the
+    // heaviest-first order (the split tiles are the first of that order, so these come first; the unit of an unsplit tile
+    // leaves after one 16-byte load); units [n, 2n): every tile in heaviest-first order -- its deep half if it is split, the
+    // whole walk if not.  The shallow half starts from garbage pixel state: same instructions, same traffic minus the
+    // checkpoint a real split would load.
+    const uint32_t emu_n = a.nblocks;
+    const uint32_t emu_half = blockIdx.x < emu_n ? 1u : 0u;
+    const uint32_t emu_rank = emu_half ? blockIdx.x : blockIdx.x - emu_n;
+    const uint32_t wg = a.tile_order ? a.tile_order[emu_rank] : xcd_remap(emu_rank, a.nblocks);
+    uint32_t emu_mid = 0u;
+    {
+        const uint32_t* qd = a.quad_depth + 4u * wg;
+        const uint32_t deepest =
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(qd[0], qd[1]), max(qd[2], qd[3])));
+        if (deepest > (uint32_t)R3_SPLIT_EMU) emu_mid = ((deepest / 2u + 63u) / 64u) * 64u;
+        if (emu_half && emu_mid == 0u) return;
+    }
+#else
     const uint32_t wg = a.tile_order ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, a.nblocks);
+#endif
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
@@ -492,6 +513,15 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         R3_TL_END(0)
         return;
     }
+#ifdef R3_SPLIT_EMU
+    int emu_lo = 0;
+    if (emu_mid != 0u && emu_mid < lmax) {
+        if (emu_half)
+            lmax = emu_mid;           // shallow half: entries [0, mid)
+        else
+            emu_lo = (int)emu_mid;    // deep half: entries [mid, lmax)
+    }
+#endif
 
     const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
     float4 nxa, nxb, nxc;
@@ -516,7 +546,11 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     float* const s_grad_slot = s_grad + reduce9_component(lane);
     SplatSums sg;   // zero whenever an entry starts: cleared after every reduction, untouched by entries without a hit
     sg.sx = sg.sy = sg.sxx = sg.sxy = sg.syy = sg.sm = sg.r = sg.g = sg.b = 0.f;
+#ifdef R3_SPLIT_EMU
+    for (int cbase = cfirst; cbase >= emu_lo; cbase -= kChunk) {
+#else
     for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
+#endif
         __syncthreads();
         stage_entry(s_rec[lane], nxa, nxb, nxc);
         unsigned long long qmask[PPL], anymask = 0ull;
@@ -711,7 +745,11 @@ static void launch_bwd(uint32_t nblocks, BwdPassArgs* dst, const BwdPassArgs& v,
     if (v.blend.tile_order) {
         static const int lds_pad = env_int("R3DGS_BWD_LDS_PAD", 0, 0, 65536);
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
+#ifdef R3_SPLIT_EMU
+        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(2 * nblocks), dim3(64), lds_pad, s, dst, v);
+#else
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(nblocks), dim3(64), lds_pad, s, dst, v);
+#endif
     } else {
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
     }

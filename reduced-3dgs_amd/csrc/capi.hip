@@ -469,7 +469,7 @@ void issue_forward(const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& args, hi
         else
             issue_depth_sort_and_color(p, d, s);   // the SH -> RGB stream rides in spare workgroups of these kernels
         h.end(kDepthSort, "depth sort + scan", s);
-        if (p.generic_depth_sort) {
+        if (p.generic_depth_sort && !p.color_in_geom) {
             h.begin(kColor, s);
             issue_preprocess_color(p, &d->pre, s);
             h.end(kColor, "SH colours", s);
@@ -627,6 +627,9 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     p.color_split[1] = split0 + split1 > 100 ? 100 - split0 : split1;
     p.color_split[2] = 100 - p.color_split[0] - p.color_split[1];
     p.generic_depth_sort = (generic_env || c.P >= (1 << 24)) ? 1 : 0;   // the bucket histogram packs the count in 24 bits
+    static const int in_geom_env = env_int("R3DGS_COLOR_IN_GEOM", -1, -1, 1);
+    p.color_in_geom = in_geom_env > 0 ? 1 : 0;
+    if (p.color_in_geom) p.color_fuse = 0;
     p.tight = tight_rects();
     return p;
 }
@@ -782,7 +785,7 @@ uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
 {
     return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
            ((uint32_t)p.layout.wide << 8) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7) |
-           ((uint32_t)p.tight << 10);
+           ((uint32_t)p.tight << 10) | ((uint32_t)p.color_in_geom << 11);
 }
 
 int current_device()

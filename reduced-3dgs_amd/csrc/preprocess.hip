@@ -95,12 +95,20 @@ __device__ __forceinline__ int ragged_offset(int idx, const int* coeffs, const i
     return off + (idx - cumsum[2]) * coeffs[3];
 }
 
+template <bool RAGGED, int BLOCK>
+__device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int first, int last, int wg, int n_wg);
+
 // ---- kernel 1: geometry ---------------------------------------------------------------------------
 // cull, projection, conic, radius, tile rect, depth key, per-view counters.  Reads 44 B per Gaussian.  Its
 // outputs are everything the depth sort / binning needs, so the SH -> RGB kernel below can run on a side
 // stream underneath the (launch-latency-bound) sort.
+// COLOR != 0 (large scenes, FwdPlan::color_in_geom): the workgroup goes on to colour its own 256 Gaussians (color_role
+// below; COLOR 2 = ragged SH) while their records are still in the L2 -- the separate colour stream otherwise re-opens every
+// 48-byte record for a 16-byte partial write, which HBM pays as a read-modify-write of the whole line.
+template <int COLOR>
 __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs* dst, FwdPassArgs v)
 {
+    extern __shared__ __attribute__((aligned(16))) char geom_smem[];
     // first kernel of the forward: it gets the pass block by value, installs it for the kernels behind it ...
     if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)threadIdx.x, kPreBlock);
     const PreArgs a = v.pre;   // ... and reads its own arguments from the kernarg segment (scalar loads)
@@ -191,6 +199,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_geom_kernel(FwdPassArgs*
         }
         a.partials[blockIdx.x] = pp;
     }
+    if (COLOR) {
+        __syncthreads();
+        if (COLOR == 2)
+            color_role<true, kPreBlock>(a, geom_smem, (int)blockIdx.x, (int)blockIdx.x + 1, 0, 1);
+        else
+            color_role<false, kPreBlock>(a, geom_smem, (int)blockIdx.x, (int)blockIdx.x + 1, 0, 1);
+    }
 }
 
 // ---- kernel 2: colour -------------------------------------------------------------------------------
@@ -205,7 +220,7 @@ constexpr size_t kColorLds = sizeof(float) * (kPreBlock / 64) * kWaveShFloats;
 // chunks [first + wg, last) in steps of n_wg, BLOCK Gaussians each (BLOCK = workgroup size); smem: BLOCK / 64 wave windows.
 // BLOCK = 64 (standalone kernel only): single-wave workgroups -- 12 per CU instead of 3 of four waves: no barrier couples
 // the waves' load / evaluate phases, so they drift apart and one wave's loads fly while another evaluates.
-template <bool RAGGED, int BLOCK = kPreBlock>
+template <bool RAGGED, int BLOCK>
 __device__ __forceinline__ void color_role(const PreArgs& a, char* smem, int first, int last, int wg, int n_wg)
 {
     float(*s_sh)[kWaveShFloats] = reinterpret_cast<float(*)[kWaveShFloats]>(smem);
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(kPreBlock) void depth_sort_color_kernel(const FwdPa
             depth_bucket_group_role(d, smem, wg);
     } else {
         const PreArgs a = pa->pre;
-        color_role<RAGGED>(a, smem, c0, c1, wg - n_sort, (int)gridDim.x - n_sort);
+        color_role<RAGGED, kPreBlock>(a, smem, c0, c1, wg - n_sort, (int)gridDim.x - n_sort);
     }
 }
 
@@ -341,7 +356,12 @@ __global__ __launch_bounds__(64 * kColWaves) void depth_colscan_kernel(const Dep
 void issue_preprocess_geom(const FwdPlan& p, FwdPassArgs* dst, const FwdPassArgs& v, hipStream_t s)
 {
     const int blocks = (p.P + kPreBlock - 1) / kPreBlock;
-    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(kPreBlock), 0, s, dst, v);
+    if (p.color_in_geom && p.ragged)
+        hipLaunchKernelGGL(preprocess_geom_kernel<2>, dim3(blocks), dim3(kPreBlock), kColorLds, s, dst, v);
+    else if (p.color_in_geom)
+        hipLaunchKernelGGL(preprocess_geom_kernel<1>, dim3(blocks), dim3(kPreBlock), kColorLds, s, dst, v);
+    else
+        hipLaunchKernelGGL(preprocess_geom_kernel<0>, dim3(blocks), dim3(kPreBlock), 0, s, dst, v);
 }
 
 void issue_preprocess_color(const FwdPlan& p, const PreArgs* a, hipStream_t s)
@@ -400,6 +420,10 @@ void prepare_depth_bucket_sort(int nb)
     opt_in_lds<2, false>(bs);
     opt_in_lds<2, true>(bs);
     if (kColorLds > 48 * 1024) {
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_geom_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
+        R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_geom_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
         R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<false, kPreBlock>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColorLds));
         R3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_color_kernel<true, kPreBlock>),
@@ -439,7 +463,7 @@ void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* pa, hipStre
         launch_sort_color<1, false>(pa, rows, n_color(1), c[1], c[2], lds1, s);
         launch_sort_color<2, false>(pa, (nb + kBucketsPerGroup - 1) / kBucketsPerGroup, n_color(2), c[2], c[3], lds2, s);
     }
-    if (!p.color_fuse) issue_preprocess_color(p, &pa->pre, s);
+    if (!p.color_fuse && !p.color_in_geom) issue_preprocess_color(p, &pa->pre, s);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2
