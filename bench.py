@@ -78,6 +78,28 @@ STAGE_KERNELS = {
 }
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources (reduced-3dgs_amd/csrc/*): tools/pmc_summary.py stores it next to the counters it
+    summarises, so that a bench line can say whether the counters it cites were collected on THIS build's kernels."""
+    import hashlib
+    d = os.path.join(ROOT, "reduced-3dgs_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_matches_build(path=None):
+    """True / False: the committed PMC summary was collected on the kernel sources of this tree; None: it does not say."""
+    path = path or os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    meta = json.load(open(path)).get("_meta", {})
+    return meta.get("sources_sha16") == kernel_sources_sha16() if "sources_sha16" in meta else None
+
+
 def pmc_traffic(stage, workload, path=None):
     """HBM bytes per launch of the stage's own kernels from the committed rocprofv3 PMC passes of this same
     command (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, unit KiB).  gfx950 correction of
@@ -490,6 +512,7 @@ def main():
                     "frac": round(A / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": (PMC_SUMMARY + " (committed rocprofv3 --pmc passes of this command; not "
                                        "collected in this run)") if traffic is not None else None,
+                    "traffic_collected_on_this_build": pmc_matches_build() if traffic is not None else None,
                     "duration_source": "HIP events around the stage on its stream, inside the timed region",
                     "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
     iters_per_s = args.steps * world / elapsed

@@ -8,6 +8,7 @@ only here: device memory (outputs + the three opaque state blobs), the current H
 There is NO fallback: if the HIP library is missing or fails to load, importing this module raises.
 """
 import ctypes as C
+import threading
 import weakref
 import os
 
@@ -455,9 +456,9 @@ def _forward_common(ragged, background, means3D, colors, opacity, scales, rotati
         radii = torch.zeros((0,), dtype=torch.int32, device=dev)
         e = torch.empty(0, **u8)
         return NumRendered(0, 0, 0, 0), out_color, radii, e, e.clone(), e.clone()
-    global _next_forward_trains
-    trains = torch.is_grad_enabled() if _next_forward_trains is None else _next_forward_trains
-    _next_forward_trains = None
+    hint = getattr(_tls, "next_forward_trains", None)   # per thread, like the library's own r3dgs_forward_hint state
+    trains = torch.is_grad_enabled() if hint is None else hint
+    _tls.next_forward_trains = None
     if _ext is not None and ragged is None and counters is None and not exact and not debug and _reserve is None:
         # the hot call: compiled marshalling (csrc_torch/r3dgs_torch.cpp), same library entry points as below
         strict = _strict if _strict_override is None else bool(_strict_override)
@@ -692,15 +693,14 @@ def tight_rects():
     return bool(_lib.r3dgs_set_tight_rects(-1))
 
 
-_next_forward_trains = None   # None: nobody said -- a forward issued under torch.no_grad() is taken as a rendering
+_tls = threading.local()   # .next_forward_trains: None / absent = nobody said -- a forward under torch.no_grad() is a rendering
 
 
 def hint_next_forward(will_backward):
     """The autograd wrapper says whether any input of the forward it is about to issue needs a gradient.  A forward that
     no backward will follow (rendering under no_grad) skips what it would only do for the backward's sake (the SH direction
     derivatives, 36 B per visible Gaussian).  One-shot: the call after the next forward trains again."""
-    global _next_forward_trains
-    _next_forward_trains = bool(will_backward)
+    _tls.next_forward_trains = bool(will_backward)
 
 
 def set_sh_cache(on):

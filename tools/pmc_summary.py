@@ -50,8 +50,13 @@ def main():
             a[0] += v
             a[1] += 1
     summary = {k: {c: round(v[0] / v[1], 1) for c, v in sorted(ctrs.items())} for k, ctrs in sorted(acc.items())}
+    sys.path.insert(0, ROOT)
+    import bench   # the fingerprint of the kernel sources these counters were collected on (bench.py compares it)
+    summary["_meta"] = {"sources_sha16": bench.kernel_sources_sha16()}
     json.dump(summary, open(out_path, "w"), indent=1)
     for k, ctrs in summary.items():
+        if k.startswith("_"):
+            continue
         print(k, {c: ctrs[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU") if c in ctrs})
 
 
