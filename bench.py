@@ -60,7 +60,7 @@ def stage_bytes(P, R, N, Tn, Kbar):
 # whether the kernel's loads are wide (16 B / lane): the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (x2)
 # applies to those only.
 STAGE_KERNELS = {
-    "preprocess_fwd": [("r3::preprocess_geom_kernel", 1, False)],
+    "preprocess_fwd": [("r3::preprocess_geom_kernel<0>", 1, False)],   # <0>: the colour stream is not in this kernel
     # the SH -> RGB stream rides in spare workgroups of three of the four depth-sort kernels (preprocess.hip)
     # (the header reduction is fused into the histogram workgroups on the asynchronous path)
     "depth_sort_scan": [("r3::depth_sort_color_kernel<0, false>", 1, True),

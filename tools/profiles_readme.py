@@ -125,7 +125,7 @@ calibration are round 3's (`r03_bwd_timeline*.txt`, `r03_fwd_timeline.txt`, `r03
 | same, reference rects (`R3DGS_TIGHT_RECT=0`) | {ab[1]['value']} it/s, stages {stages_of(ab[1])} ms against {stages_of(d20)} ms |
 | render-only (forward, `render.py`'s FPS path) | **{d50['render_fps']} FPS = {d50['render_mpix_per_s'] / 1000:.2f} Gpix/s** |
 | whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes, SURVEY 8d) → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %); bytes the counters saw move per step (`{R}_pmc_summary.json`, ×2 on the wide-load kernels' FETCH_SIZE): {CTR_BYTES / 1e9:.2f} GB = {100 * CTR_BYTES * d50['value'] / 8e12:.1f} % — that one is HBM utilisation, the first is not |
-| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), calibrated VALU issue floor / kernel time {vb['frac']} (the bench lines of this visit were taken before its counter passes existed, so their own `roofline.traffic` / `roofline.valu` are null; the driver's line cites the committed counters) |
+| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), calibrated VALU issue floor / kernel time {vb['frac']}; `roofline.traffic` {d50['roofline'].get('traffic')} B from the committed counters (the line's own citation is of the summary committed before this visit; `roofline.traffic_collected_on_this_build` says whether the cited counters were collected on the tree's kernel sources) |
 | CPU baseline (SURVEY 8d) | configs[0] PyTorch restatement, {d50['cpu_baseline']['threads_effective']} threads: {d50['cpu_baseline']['value']} it/s; the bench workload by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
 | host under `tools/cpu_burn.py 64` | {burn[0]['value']} / {burn[1]['value']} it/s (throttled periods inside the timed region: {burn[0]['host']['cgroup']['throttled_periods_in_timed_region']} / {burn[1]['host']['cgroup']['throttled_periods_in_timed_region']}) |
 | BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are VALU-bound: see below) |
@@ -134,7 +134,7 @@ calibration are round 3's (`r03_bwd_timeline*.txt`, `r03_fwd_timeline.txt`, `r03
 
 | stage | avg ms | kernels (rocprofv3 avg µs) | algorithmic bytes (SURVEY 8d) | GB/s vs 8 TB/s |
 |---|---|---|---|---|
-| preprocess_fwd | {st['preprocess_fwd']['avg_ms']} | `preprocess_geom_kernel` {ks['r3::preprocess_geom_kernel']:.1f} [{ks2['r3::preprocess_geom_kernel']:.1f}] (+ the opacity-aware rect) | {st['preprocess_fwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_fwd']['GBps']:.0f} ({st['preprocess_fwd']['GBps'] / 80:.0f} %) |
+| preprocess_fwd | {st['preprocess_fwd']['avg_ms']} | `preprocess_geom_kernel` {ks['r3::preprocess_geom_kernel<0>']:.1f} [{ks2['r3::preprocess_geom_kernel']:.1f}] (+ the opacity-aware rect) | {st['preprocess_fwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_fwd']['GBps']:.0f} ({st['preprocess_fwd']['GBps'] / 80:.0f} %) |
 | depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f}, `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
 | tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f} [{ks2['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}], `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f} [{ks2['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}], `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} — real traffic ≈ 9× lower |
 | blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks[FWD]:.1f} [{ks2[FWD]:.1f}] | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
