@@ -17,7 +17,14 @@
 
 namespace r3 {
 
-constexpr int kBwdBlock = 256;
+// Workgroup size of preprocess_bwd_kernel.  One wave per workgroup (round 4): every wave owns its LDS window and its 64
+// Gaussians anyway, and without a four-wave barrier the twelve waves of a CU drift apart, so loads, evaluation and the
+// dL_dsh row stores of different waves overlap: 0.194 -> 0.181 ms at 2 M Gaussians, 0.574 -> 0.539 at 6 M, unchanged at
+// 500 k (0.062-0.064 either way); 128: in between.  -DR3_PREBWD_BLOCK=256 for the round-3 shape.
+#ifndef R3_PREBWD_BLOCK
+#define R3_PREBWD_BLOCK 64
+#endif
+constexpr int kBwdBlock = R3_PREBWD_BLOCK;
 constexpr int kBwdWaveShFloats = 64 * 48 + (64 * 48) / 32;
 
 // Where float e of the wave's span (64 rows x 3M floats, row after row) sits in LDS.  The lanes of a wave read the same
@@ -193,8 +200,8 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
     // The workgroups that start together (three per CU) would load their SH rows together, compute together and store
     // together: HBM idle while they compute, the SIMDs idle while they wait.  The second and third of a CU start a step
     // later each.  (Only when the rows are read: without that phase the stagger costs 2 us instead of saving 4.)
-    if (!cached && a.stagger > 0 && blockIdx.x < 768u) {
-        const int steps = (int)(blockIdx.x >> 8) * a.stagger;
+    if (!cached && a.stagger > 0 && blockIdx.x < 768u * (256 / kBwdBlock)) {
+        const int steps = (int)(blockIdx.x / (256u * (256 / kBwdBlock))) * a.stagger;
         for (int k = 0; k < steps; k += 127) __builtin_amdgcn_s_sleep(127);
     }
     if (has_sh && wave_vis && !cached) {
