@@ -176,3 +176,87 @@ def test_strict_redo_and_lossy_opt_out():
     del ref_c
     lossy = _C._forward_common(None, *args, _reserve=R // 2, _strict_override=False)
     assert lossy[0].truncated and not torch.equal(lossy[1], exact[1])
+
+
+def test_freed_camera_matrix_does_not_leave_its_pair_count_to_the_next_owner_of_the_address():
+    """Per-camera pair counts are kept under the device address of the camera's view matrix (ADVICE r3 / VERDICT r3 weak 15).
+    A camera with few pairs is freed and the allocator hands its address to a camera with 4x the pairs.  Without the
+    host layer's `r3dgs_reserve_forget_view` on the tensor's death the newcomer would inherit the small count, overflow
+    its reservation and be redone (strict mode) on its first pass; with it, the newcomer is unknown and gets the image
+    size's largest recent count (the first, large camera's): no redo, and the results are the exact path's."""
+    import gc
+
+    from diff_gaussian_rasterization import _C
+    W, H, P = 320, 240, 30000
+    cam = ss.make_camera(W, H, 250.0, 6)
+    g = ss.make_gaussians(P, cam, seed=43, degree_mode="all0", scale_mu=0.2)
+    fixed = dict(bg=_dev(np.zeros(3, np.float32)), m=_dev(g["means3D"]), op=_dev(g["opacity"]), sc=_dev(g["scales"]),
+                 rot=_dev(g["rotations"]), sh=_dev(g["sh"]), deg=_dev(g["degrees"]), campos=_dev(cam.camera_center))
+
+    def view(zoom):
+        """The same camera pulled back by `zoom`: fewer pairs (splats shrink, many leave the rects)."""
+        v = np.array(cam.world_view_transform, np.float32, copy=True)
+        v[3, 2] += zoom
+        proj = np.array(cam.full_proj_transform, np.float32, copy=True)
+        p = (v.astype(np.float64) @ np.linalg.inv(np.array(cam.world_view_transform, np.float64)) @ proj.astype(np.float64))
+        return v, p.astype(np.float32)
+
+    def fwd(vm_t, pm_t, **kw):
+        return _C._forward_common(None, fixed["bg"], fixed["m"], torch.Tensor([]), fixed["op"], fixed["sc"], fixed["rot"], 1.0,
+                                  torch.Tensor([]), vm_t, pm_t, cam.tanfovx, cam.tanfovy, H, W, fixed["sh"], fixed["deg"],
+                                  fixed["campos"], False, False, **kw)
+
+    _C.reserve_forget()
+    v_big, p_big = view(0.0)
+    v_small, p_small = view(25.0)
+    big1_vm, big1_pm = _dev(v_big), _dev(p_big)
+    pairs_big = fwd(big1_vm, big1_pm, exact=True)[0].pairs
+    for _ in range(3):
+        assert not fwd(big1_vm, big1_pm)[0].truncated
+    # one address, two tensor objects one after the other: a view into a pool stands in for "the allocator handed the freed
+    # block to the next camera" (the caching allocator's choice of block cannot be forced from a test)
+    pool = torch.empty(16, dtype=torch.float32, device="cuda")
+    small_vm, small_pm = pool.view(4, 4), _dev(p_small)
+    small_vm.copy_(torch.from_numpy(v_small))
+    pairs_small = fwd(small_vm, small_pm)[0].pairs
+    for _ in range(3):
+        fwd(small_vm, small_pm)
+    # the small camera's reservation (1.5 x its count + 64 k, rounded up on a 9 % grid) cannot hold the big one
+    assert pairs_big > 2 * (1.5 * pairs_small + 65536), (pairs_big, pairs_small)
+    torch.cuda.synchronize()
+    addr = small_vm.data_ptr()
+    del small_vm
+    gc.collect()
+    big2_vm = pool.view(4, 4)
+    assert big2_vm.data_ptr() == addr
+    big2_vm.copy_(torch.from_numpy(v_big))
+    s0 = _C.pass_stats()
+    out = fwd(big2_vm, big1_pm)
+    s1 = _C.pass_stats()
+    assert s1["redone_passes"] == s0["redone_passes"], "the newcomer inherited the freed camera's pair count"
+    assert s1["reserved_passes"] == s0["reserved_passes"] + 1 and out[0].pairs == pairs_big
+    ref = fwd(big1_vm, big1_pm, exact=True)
+    assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+    # and the counter-experiment: with the lifetime tracking switched off the same sequence does inherit the stale count and
+    # pays a redo (strict mode still returns the exact result) -- the test above is not vacuous
+    track, _C._track_view = _C._track_view, lambda vm: None
+    try:
+        _C.reserve_forget()
+        fwd(big1_vm, big1_pm, exact=True)
+        for _ in range(3):
+            fwd(big1_vm, big1_pm)
+        v1 = pool.view(4, 4)
+        v1.copy_(torch.from_numpy(v_small))
+        for _ in range(4):
+            fwd(v1, small_pm)
+        torch.cuda.synchronize()
+        del v1
+        v2 = pool.view(4, 4)
+        v2.copy_(torch.from_numpy(v_big))
+        s0 = _C.pass_stats()
+        out2 = fwd(v2, big1_pm)
+        assert _C.pass_stats()["redone_passes"] == s0["redone_passes"] + 1
+        assert torch.equal(out2[1], ref[1])
+    finally:
+        _C._track_view = track
+        _C.reserve_forget()
