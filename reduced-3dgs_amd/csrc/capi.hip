@@ -437,6 +437,30 @@ void evict_graphs_locked()
     }
 }
 
+// Second stream of a forward whose colour stream runs BESIDE the depth sort and the binning instead of inside the sort's
+// launches (FwdPlan::color_side, large scenes): forked after the geometry kernel, joined before the blend.  One per device;
+// the fork / join events carry no timing and may be re-recorded while an earlier wait is pending (a wait refers to the
+// record that preceded it).  Inside a stream capture the two event waits make the side stream part of the captured graph.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mu;
+std::unordered_map<int, SideStream> g_side;
+SideStream& side_stream()
+{
+    int dev = 0;
+    R3_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream& ss = g_side[dev];
+    if (!ss.stream) {
+        R3_HIP(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+        R3_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+        R3_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+    }
+    return ss;
+}
+
 bool graphs_enabled()
 {
     static const bool on = !env_is("R3DGS_GRAPH", "0");
@@ -463,13 +487,21 @@ void issue_forward(const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& args, hi
         if (!args.depth.fuse_header) issue_header_reduce(&d->header, s);
     }
     if (phases & 2) {
+        SideStream* side = nullptr;
+        if (p.color_side) {   // the colour stream on a stream of its own, beside the sort and the binning
+            side = &side_stream();
+            R3_HIP(hipEventRecord(side->fork, s));
+            R3_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+            issue_preprocess_color(p, &d->pre, side->stream);
+            R3_HIP(hipEventRecord(side->join, side->stream));
+        }
         h.begin(kDepthSort, s);
         if (p.generic_depth_sort)
             run_generic_depth_sort(p.P, *g_host, s);
         else
             issue_depth_sort_and_color(p, d, s);   // the SH -> RGB stream rides in spare workgroups of these kernels
         h.end(kDepthSort, "depth sort + scan", s);
-        if (p.generic_depth_sort && !p.color_in_geom) {
+        if (p.generic_depth_sort && !p.color_in_geom && !p.color_side) {
             h.begin(kColor, s);
             issue_preprocess_color(p, &d->pre, s);
             h.end(kColor, "SH colours", s);
@@ -477,6 +509,7 @@ void issue_forward(const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& args, hi
         h.begin(kBinning, s);
         issue_tile_binning(p, d, s);
         h.end(kBinning, "tile binning", s);
+        if (side) R3_HIP(hipStreamWaitEvent(s, side->join, 0));
         h.begin(kBlendFwd, s);
         issue_blend_forward(p, &d->blend, s);
         h.end(kBlendFwd, "blend forward", s);
@@ -630,6 +663,9 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     static const int in_geom_env = env_int("R3DGS_COLOR_IN_GEOM", -1, -1, 1);
     p.color_in_geom = in_geom_env > 0 ? 1 : 0;
     if (p.color_in_geom) p.color_fuse = 0;
+    static const int side_env = env_int("R3DGS_COLOR_STREAM", -1, -1, 1);
+    p.color_side = (side_env > 0 && !p.color_in_geom) ? 1 : 0;
+    if (p.color_side) p.color_fuse = 0;
     p.tight = tight_rects();
     return p;
 }
@@ -785,7 +821,7 @@ uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
 {
     return (uint32_t)p.ragged | ((uint32_t)p.counters << 1) | ((uint32_t)p.fwd_ppl << 2) |
            ((uint32_t)p.layout.wide << 8) | ((uint32_t)(c.colors_precomp != nullptr) << 6) | ((uint32_t)p.color_fuse << 7) |
-           ((uint32_t)p.tight << 10) | ((uint32_t)p.color_in_geom << 11);
+           ((uint32_t)p.tight << 10) | ((uint32_t)p.color_in_geom << 11) | ((uint32_t)p.color_side << 12);
 }
 
 int current_device()

@@ -611,6 +611,7 @@ struct FwdPlan {
     int nb;                // depth buckets
     int ragged, counters;  // ragged SH addressing; counter mode (calculate_mean_transmittance)
     int color_in_geom;     // the geometry kernel's workgroups colour their own Gaussians (large scenes; preprocess.hip)
+    int color_side;        // the colour kernel runs on a second stream beside the depth sort and the binning (capi.hip)
     int fwd_ppl;           // pixels per lane of the forward blend
     int color_grid;        // workgroups of the SH -> RGB stream (per launch that carries it)
     int color_fuse;        // 1: the colour chunks ride in spare workgroups of the depth-sort kernels

@@ -463,7 +463,7 @@ void issue_depth_sort_and_color(const FwdPlan& p, const FwdPassArgs* pa, hipStre
         launch_sort_color<1, false>(pa, rows, n_color(1), c[1], c[2], lds1, s);
         launch_sort_color<2, false>(pa, (nb + kBucketsPerGroup - 1) / kBucketsPerGroup, n_color(2), c[2], c[3], lds2, s);
     }
-    if (!p.color_fuse && !p.color_in_geom) issue_preprocess_color(p, &pa->pre, s);
+    if (!p.color_fuse && !p.color_in_geom && !p.color_side) issue_preprocess_color(p, &pa->pre, s);
 }
 
 // rasterizer_impl.cu:62-74 checkFrustum: present[i] = (view * p).z > 0.2
