@@ -1034,7 +1034,7 @@ int r3::guarded_call(const std::function<int()>& f) { return guarded(f); }
 
 extern "C" {
 
-const char* r3dgs_version(void) { return "r3dgs-hip gfx950 0.3"; }
+const char* r3dgs_version(void) { return "r3dgs-hip gfx950 0.4"; }
 const char* r3dgs_last_error(void) { return g_last_error.c_str(); }
 
 // The temp-storage part of the geometry blob comes from a rocPRIM query, which needs a visible GPU;
