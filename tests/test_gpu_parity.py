@@ -519,6 +519,51 @@ def test_ragged_sh_inference_and_counters(C_):
     np.testing.assert_allclose(transm, refc["transmittance"], rtol=1e-4, atol=1e-3 + namb)
 
 
+def test_hip_against_the_independent_fp64_autograd_statement_at_configs0(C_):
+    """The HIP path against oracle/torch_ref.py directly -- the one statement of the EWA projection / blend maths that shares
+    no expression with the product (the C oracle restates forward.cu / backward.cu in the same order as gauss_math.h does,
+    which bit-exact integers require but which cannot expose a shared misreading).  BASELINE.json
+    configs[0]: 10k Gaussians, 400x400, degree 0; fp64 autograd, tile by tile.  Radii equal; colour within 2e-5 on the
+    pixels the C oracle does not flag as threshold-ambiguous (fp32 rounding of ~30 blended entries against fp64: the C
+    oracle itself is 1.3e-5 from it); every gradient within 1e-4 of its tensor's maximum."""
+    from oracle import torch_ref as tr
+    w = ss.WORKLOADS["cfg0_10k_400"]
+    W, H, P = w["W"], w["H"], w["P"]
+    cam = ss.make_camera(W, H, w["f"], None)
+    g = ss.make_gaussians(P, cam, seed=0, degree_mode=w["degree_mode"])
+    bg = np.array([0.1, 0.4, 0.9], np.float32)
+    # fp64 and fp32 take the three hard per-pixel decisions differently inside a wider band than two fp32 evaluations do
+    # (the fp32 conic and pixel mean are rounded): pixels within 1e-4 (relative) of a threshold are left out here
+    ref = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None, cam.world_view_transform,
+                      cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"], g["degrees"], cam.camera_center,
+                      want_ambig=True, ambig_rel=1e-4)
+    ok = ref["ambig"].reshape(-1) == 0
+    assert ok.mean() > 0.99
+    dl = mask_ambiguous(ss.upstream_grad(W, H, seed=2) * (W * H), ref)
+    D = torch.float64
+
+    def T(a):
+        return torch.tensor(np.asarray(a), dtype=D)
+    lv = dict(m3=T(g["means3D"]), op=T(g["opacity"]), sc=T(g["scales"]), rot=T(g["rotations"]), sh=T(g["sh"]))
+    for v in lv.values():
+        v.requires_grad_()
+    f32 = lambda v: float(np.float32(v))
+    col, radii, _ = tr.render(lv["m3"], lv["op"], lv["sc"], lv["rot"], lv["sh"], torch.tensor(g["degrees"]),
+                              T(cam.world_view_transform), T(cam.full_proj_transform), T(cam.camera_center), T(bg), W, H,
+                              f32(cam.tanfovx), f32(cam.tanfovy), tiled=True)
+    (col * T(dl)).sum().backward()
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    np.testing.assert_array_equal(fout[2].cpu().numpy(), radii.numpy())
+    cerr = np.abs(fout[1].cpu().numpy().reshape(3, -1).astype(np.float64) - col.detach().numpy().reshape(3, -1))[:, ok].max()
+    assert cerr <= 2e-5, cerr
+    bout = hip_backward(C_, fargs, fout, dl, 0.0)
+    for name, want, got in (("means3D", lv["m3"].grad, bout[3]), ("opacity", lv["op"].grad, bout[2]),
+                            ("scales", lv["sc"].grad, bout[6]), ("rotations", lv["rot"].grad, bout[7]),
+                            ("sh", lv["sh"].grad, bout[5])):
+        grads_close("[hip vs fp64 autograd] " + name, want.numpy(), got.double(), GRAD_REL, per_element=False)
+    achieved["[hip vs fp64 autograd] colour (abs)"] = [float(cerr), 0.0, "test_hip_against_the_independent_fp64_autograd_statement_at_configs0"]
+
+
 def ragged_inputs(g):
     """Degree-sorted copy of a scene and its ragged SH store, as scene/gaussian_model.py keeps it after cull_sh_bands
     (gaussian_model.py:728-760): rows sorted by degree, each holding only its (degree + 1)^2 coefficients."""
