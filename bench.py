@@ -34,9 +34,19 @@ import torch.distributed as dist  # noqa: E402
 import synth_scene as ss  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
-VALU_RATE = os.path.join("profiles", "r03_valu_rate.txt")
-KERNEL_STATS = os.path.join("profiles", "r04_kernel_stats_bench_500k_1600x1062.csv")
+PROFILE_ROUND = "r05" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")) else "r04"
+# committed rocprofv3 --pmc summaries (tools/pmc_summary.py), per workload they were collected on
+PMC_SUMMARIES = {
+    "metric_500k_1600x1062": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary.json"),
+    "garden_like_2M_1600x1062": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary_2M.json"),
+    "train_like_6M_1920x1080": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary_6M.json"),
+    "clustered_500k_1600x1062": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary_clustered_500k.json"),
+}
+PMC_SUMMARY = PMC_SUMMARIES["metric_500k_1600x1062"]
+VALU_RATE = next((p_ for p_ in (os.path.join("profiles", n) for n in ("r05_valu_rate.txt", "r04_valu_rate_warm.txt",
+                                                                      "r03_valu_rate.txt"))
+                  if os.path.exists(os.path.join(ROOT, p_))), None)
+KERNEL_STATS = os.path.join("profiles", f"{PROFILE_ROUND}_kernel_stats_bench_500k_1600x1062.csv")
 
 
 CLOCK_WARMUP_STEPS = 50   # untimed, ahead of the --warmup steps (see main())
@@ -56,9 +66,9 @@ def stage_bytes(P, R, N, Tn, Kbar):
     }
 
 
-# kernels that make up each stage (names as rocprofv3 reports them, without arguments), launches per stage, and
-# whether the kernel's loads are wide (16 B / lane): the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (x2)
-# applies to those only.
+# kernels that make up each stage (name PREFIXES as rocprofv3 reports them, without arguments: the pair-word policy
+# IoNarrow / IoSplit / IoWide and the digit width depend on the workload), launches per stage, and whether the kernel's
+# loads are wide (16 B / lane): the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (x2) applies to those only.
 STAGE_KERNELS = {
     "preprocess_fwd": [("r3::preprocess_geom_kernel<0>", 1, False)],   # <0>: the colour stream is not in this kernel
     # the SH -> RGB stream rides in spare workgroups of three of the four depth-sort kernels (preprocess.hip)
@@ -66,16 +76,26 @@ STAGE_KERNELS = {
     "depth_sort_scan": [("r3::depth_sort_color_kernel<0, false>", 1, True),
                         ("r3::depth_colscan_kernel", 1, False), ("r3::depth_sort_color_kernel<1, false>", 1, True),
                         ("r3::depth_sort_color_kernel<2, false>", 1, True)],
-    "tile_binning": [("r3::emit_pairs_kernel<r3::IoNarrow>", 1, False), ("r3::radix_digit_scan_kernel", 2, False),
-                     ("r3::radix_scatter_kernel<r3::IoNarrow, 7>", 2, False),
-                     ("r3::radix_hist_kernel<r3::IoNarrow>", 1, False),
-                     ("r3::tile_ranges_kernel<r3::IoNarrow>", 1, True)],
+    "tile_binning": [("r3::emit_pairs_kernel<", 1, False), ("r3::radix_digit_scan_kernel", 2, False),
+                     ("r3::radix_scatter_kernel<", 2, False),
+                     ("r3::radix_hist_kernel<", 1, False),
+                     ("r3::tile_ranges_kernel<", 1, True)],
     "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
     # (the one-workgroup kernel that orders the tiles heaviest first runs inside this stage's events too)
     "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
                   ("r3::tile_order_kernel", 1, False)],
-    "preprocess_bwd": [("r3::preprocess_bwd_kernel<true, true>", 1, False)],   # <dense degree-3 rows, covariance chain in double>
+    "preprocess_bwd": [("r3::preprocess_bwd_kernel<", 1, False)],   # <dense degree-3 rows?, covariance chain in double?>
 }
+
+
+def find_kernel(table, prefix):
+    """The entry of a {kernel name: ...} table whose name starts with `prefix` (exact name first), or None."""
+    if prefix in table:
+        return table[prefix]
+    for k in table:
+        if k.startswith(prefix):
+            return table[k]
+    return None
 
 
 def kernel_sources_sha16():
@@ -91,6 +111,11 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def pmc_path(workload):
+    p = PMC_SUMMARIES.get(workload)
+    return os.path.join(ROOT, p) if p else None
+
+
 def pmc_matches_build(path=None):
     """True / False: the committed PMC summary was collected on the kernel sources of this tree; None: it does not say."""
     path = path or os.path.join(ROOT, PMC_SUMMARY)
@@ -102,19 +127,20 @@ def pmc_matches_build(path=None):
 
 def pmc_traffic(stage, workload, path=None):
     """HBM bytes per launch of the stage's own kernels from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, unit KiB).  gfx950 correction of
-    MI355X_MICROARCH.md: FETCH_SIZE counts a 128-B read request as 64 B for wide (16 B/lane) loads, so it is doubled
+    command on this workload (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, unit KiB).  gfx950 correction
+    of MI355X_MICROARCH.md: FETCH_SIZE counts a 128-B read request as 64 B for wide (16 B/lane) loads, so it is doubled
     for the kernels marked wide in STAGE_KERNELS; WRITE_SIZE is taken as reported.  None if no committed counters
     match.  This is a citation of profiles/, not a measurement of the present run: see roofline.traffic_source."""
-    path = path or os.path.join(ROOT, PMC_SUMMARY)
-    if workload != "metric_500k_1600x1062" or stage not in STAGE_KERNELS or not os.path.exists(path):
+    path = path or pmc_path(workload)
+    if path is None or stage not in STAGE_KERNELS or not os.path.exists(path):
         return None
     pmc = json.load(open(path))
     total = 0.0
     for k, launches, wide in STAGE_KERNELS[stage]:
-        if k not in pmc or "FETCH_SIZE" not in pmc[k] or "WRITE_SIZE" not in pmc[k]:
+        c = find_kernel(pmc, k)
+        if c is None or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             return None
-        total += launches * ((2.0 if wide else 1.0) * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0
+        total += launches * ((2.0 if wide else 1.0) * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return int(total)
 
 
@@ -134,7 +160,7 @@ def committed_kernel_ms(kernel, path=None):
     if not os.path.exists(path):
         return None
     for r in csv.DictReader(open(path)):
-        if r["Name"].replace("void ", "").split("(")[0] == kernel:
+        if r["Name"].replace("void ", "").split("(")[0].startswith(kernel):
             return float(r["AverageNs"]) / 1e6
     return None
 
@@ -150,7 +176,7 @@ def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):
     if workload != "metric_500k_1600x1062" or stage not in STAGE_KERNELS or not os.path.exists(path):
         return None
     k = STAGE_KERNELS[stage][0][0]
-    c = json.load(open(path)).get(k, {})
+    c = find_kernel(json.load(open(path)), k) or {}
     if "SQ_INSTS_VALU" not in c:
         return None
     classes = {n: c.get(n, 0.0) for n in VALU_CYCLES if n != "other"}
@@ -256,8 +282,7 @@ def main():
     w = ss.WORKLOADS[args.workload]
     W, H, P = w["W"], w["H"], w["P"]
     N, Tn = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    cam0 = ss.make_camera(W, H, w["f"], None)
-    g = ss.make_gaussians(P, cam0, seed=0, degree_mode=w["degree_mode"], scale_mu=w.get("scale_mu", 0.012))
+    _, cam0, g = ss.make_workload(args.workload, seed=0)
     Kbar = float(((g["degrees"].reshape(-1) + 1) ** 2).mean())
 
     def dv(a):
@@ -501,18 +526,24 @@ def main():
         if cnt:
             avg_ms = ms / cnt
             b = sb.get(name, 0)   # "sh_color" only exists as a stage of its own on the generic-sort path
+            # alg_GBps: SURVEY 8d's reference-algorithm bytes of the stage / its time.  NOT a bandwidth: bytes the library
+            # never moves (the reference's 64-bit key sort, its per-Gaussian fills) count, so it can exceed the HBM peak;
+            # counter_GBps: the bytes the committed rocprofv3 counters of this workload saw move / this run's time
+            tr = pmc_traffic(name, args.workload)
             stages[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "alg_bytes": int(b),
-                            "GBps": round(b / (avg_ms * 1e-3) / 1e9, 1)}
+                            "alg_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
+                            "counter_bytes": tr,
+                            "counter_GBps": round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr is not None else None}
     dom = max(stages, key=lambda k: stages[k]["avg_ms"]) if stages else None
     roofline = None
     if dom:
-        A = stages[dom]["GBps"]
+        A = stages[dom]["alg_GBps"]
         traffic = pmc_traffic(dom, args.workload)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(A / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": (PMC_SUMMARY + " (committed rocprofv3 --pmc passes of this command; not "
-                                       "collected in this run)") if traffic is not None else None,
-                    "traffic_collected_on_this_build": pmc_matches_build() if traffic is not None else None,
+                    "traffic_source": (PMC_SUMMARIES[args.workload] + " (committed rocprofv3 --pmc passes of this command; "
+                                       "not collected in this run)") if traffic is not None else None,
+                    "traffic_collected_on_this_build": pmc_matches_build(pmc_path(args.workload)) if traffic is not None else None,
                     "duration_source": "HIP events around the stage on its stream, inside the timed region",
                     "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
     iters_per_s = args.steps * world / elapsed
@@ -579,7 +610,7 @@ def main():
                           "counter_traffic_bytes": counter_bytes,
                           "frac_counter_traffic": (round(counter_bytes * iters_per_s / world / 8e12, 4)
                                                    if counter_bytes else None),
-                          "counter_traffic_source": PMC_SUMMARY if counter_bytes else None},
+                          "counter_traffic_source": PMC_SUMMARIES.get(args.workload) if counter_bytes else None},
         "value_sh_sparsity": sparsity["value"] if sparsity else None,
         "sh_sparsity": sparsity,
         "stages": stages,

@@ -196,6 +196,110 @@ void hc_pair_stats(int W, int H, const unsigned* ranges, const unsigned* point_l
         }
 }
 
+// Lane utilisation of the two blend kernels (design aid, tools/lane_utilisation.py): for every (list entry, 8x8 quadrant)
+// pair the kernels EVALUATE -- forward: the region pre-test keeps it and a pixel of the quadrant is still live; backward:
+// kept and not behind the quadrant's deepest contributor -- how many of the wave's 64 lanes do useful work there
+// (forward: alpha >= 1/255, power <= 0 and the pixel still live; backward: bwd_test valid).
+//   fwd_hist[0..64], bwd_hist[0..64]: evaluated pairs by number of useful lanes;
+// and what a 4x4-granular pre-test with per-DPP-row entry lists would evaluate instead (lanes remapped so that a 16-lane
+// row owns a 4x4 pixel block; each row walks only the entries whose pre-test keeps ITS block; the wave's trip count is
+// the longest of its four rows' lists):
+//   blk[0] = sum over evaluated (entry, quadrant) of 1 (= today's trips), blk[1] / blk[2] = forward / backward trips with
+//   per-row lists (sum over quadrants and 64-entry chunks of max over the 4 rows of its kept entries of the chunk that
+//   are evaluated), blk[3] / blk[4] = sum over rows of kept (entry, 4x4 block) pairs evaluated by the forward / backward
+//   (the lane-work that remains), blk[5] = backward evaluations today.
+void hc_lane_utilisation(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
+                         const float* conic_op, const unsigned* n_contrib, long* fwd_hist, long* bwd_hist, long* blk)
+{
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    for (int k = 0; k <= 64; k++) fwd_hist[k] = bwd_hist[k] = 0;
+    for (int k = 0; k < 6; k++) blk[k] = 0;
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
+            const unsigned r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            FwdPix pix[256];
+            unsigned qlast[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 256; i++) {
+                const int x = tx * 16 + (i & 15), y = ty * 16 + (i >> 4);
+                const bool in = x < W && y < H;
+                fwd_pix_init(pix[i], in);
+                if (in) {
+                    const int q = ((i >> 4) / 8) * 2 + (i & 15) / 8;
+                    const unsigned nc = n_contrib[(size_t)W * y + x];
+                    if (nc > qlast[q]) qlast[q] = nc;
+                }
+            }
+            // per quadrant and 64-entry chunk: kept entries of each 4x4 block that the forward / backward evaluate
+            long f_rows[4][4], b_rows[4][4];
+            for (unsigned k = r0; k < r1; k++) {
+                const unsigned pos = k - r0;
+                if ((pos & 63u) == 0u)
+                    for (int q = 0; q < 4; q++)
+                        for (int b = 0; b < 4; b++) f_rows[q][b] = b_rows[q][b] = 0;
+                const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
+                const QSplat qs = scale_splat(s);
+                for (int q = 0; q < 4; q++) {
+                    const float qx0 = (float)(tx * 16 + (q & 1) * 8), qy0 = (float)(ty * 16 + (q >> 1) * 8);
+                    const bool keep = region_may_contribute(s, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+                    bool live = false;
+                    for (int j = 0; j < 64; j++) live |= fwd_pix_live(pix[((q >> 1) * 8 + (j >> 3)) * 16 + (q & 1) * 8 + (j & 7)]);
+                    const bool f_eval = keep && live, b_eval = keep && pos < qlast[q];
+                    bool keep_b[4];
+                    for (int b = 0; b < 4; b++) {
+                        const float bx0 = qx0 + (float)((b & 1) * 4), by0 = qy0 + (float)((b >> 1) * 4);
+                        keep_b[b] = region_may_contribute(s, bx0, bx0 + 3.f, by0, by0 + 3.f);
+                    }
+                    int f_lanes = 0, b_lanes = 0;
+                    bool live_b[4] = {false, false, false, false};
+                    for (int j = 0; j < 64; j++) {
+                        const int lx = (q & 1) * 8 + (j & 7), ly = (q >> 1) * 8 + (j >> 3);
+                        const int b = ((j >> 3) / 4) * 2 + (j & 7) / 4;
+                        FwdPix& px = pix[ly * 16 + lx];
+                        live_b[b] |= fwd_pix_live(px);
+                        const float fx = (float)(tx * 16 + lx), fy = (float)(ty * 16 + ly);
+                        bool inb;
+                        const float alpha = fwd_alpha(qs, fx, fy, &inb);
+                        const bool vis = inb && alpha >= 1.0f / 255.0f;
+                        if (vis && fwd_pix_live(px)) f_lanes++;
+                        const bool inside = tx * 16 + lx < W && ty * 16 + ly < H;
+                        if (vis && inside && pos < n_contrib[(size_t)W * (ty * 16 + ly) + tx * 16 + lx]) b_lanes++;
+                        float Tb;
+                        if (keep) fwd_step(qs, fx, fy, pos + 1, px, &Tb);
+                    }
+                    if (f_eval) {
+                        fwd_hist[f_lanes]++;
+                        blk[0]++;
+                        for (int b = 0; b < 4; b++)
+                            if (keep_b[b] && live_b[b]) {
+                                f_rows[q][b]++;
+                                blk[3]++;
+                            }
+                    }
+                    if (b_eval) {
+                        bwd_hist[b_lanes]++;
+                        blk[5]++;
+                        for (int b = 0; b < 4; b++)
+                            if (keep_b[b]) {   // (a per-block deepest contributor would cut a little more)
+                                b_rows[q][b]++;
+                                blk[4]++;
+                            }
+                    }
+                }
+                if ((pos & 63u) == 63u || k + 1 == r1)
+                    for (int q = 0; q < 4; q++) {
+                        long fm = 0, bm = 0;
+                        for (int b = 0; b < 4; b++) {
+                            if (f_rows[q][b] > fm) fm = f_rows[q][b];
+                            if (b_rows[q][b] > bm) bm = b_rows[q][b];
+                        }
+                        blk[1] += fm;
+                        blk[2] += bm;
+                    }
+            }
+        }
+}
+
 // acc: double[P][9] = mx, my, cA, cB, cC, op, r, g, b  (mx,my already scaled by 0.5W / 0.5H)
 void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
                   const float* xy, const float* conic_op, const float* rgb, const float* final_T,

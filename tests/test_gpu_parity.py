@@ -16,11 +16,17 @@ Bars (BASELINE.json north_star), exactly as asserted below:
     |err| <= 1e-4 * |ref| + 1e-6 * max |ref| on >= 99.9 % of the elements, against TWO references: the fp32 oracle
     (raster_oracle.c: the reference's arithmetic) and the double evaluation (backward_f64.c: the exact gradient of the
     function the forward evaluated, derived independently and pinned to fp64 autograd at 1e-10).  The three tensors that
-    come out of the covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- are held to the double evaluation only:
-    the reference's fp32 arithmetic for that chain is itself 2e-4 (dL_drotations) / 5e-5 (dL_dscales) of the maximum away
-    from the exact value at the benchmark shape, so the library evaluates the chain in double (full-rate on CDNA4, the
-    stage is HBM-bound) and two fp32 evaluations are not compared with each other there.  test_zz_report prints every
-    distance measured: HIP vs fp32 oracle, HIP vs f64, fp32 oracle vs f64.
+    come out of the covariance chain -- dL_dcov3D, dL_dscales, dL_drotations -- in ONE place:
+      - default mode (the chain evaluated in double, full-rate fp64 FMAs aside, the stage is HBM-bound): 1e-4 against the
+        double evaluation, and 2.5e-4 (max-normalised) against the fp32 oracle -- the reference's fp32 arithmetic for that
+        chain is itself 1.7e-4 (dL_drotations) / 5e-5 (dL_dscales) of the maximum away from the exact value at the
+        benchmark shape, so two evaluations that differ in precision cannot be held to each other at 1e-4 there;
+      - reference-arithmetic mode (`_C.set_f64_chain(False)`, R3DGS_F64_CHAIN=0: the fp32 restatement of
+        backward.cu:228-306, 311-374): all nine tensors at 1e-4 against the fp32 oracle on the golden cases, configs[0]
+        and the 20k / 300k cases; at the benchmark shape the chain tensors at 1.5e-4 (two fp32 evaluations that contract
+        FMAs differently; measured 9.4e-5), their distance to the exact value recorded
+        (test_reference_arithmetic_chain_mode).
+    test_zz_report prints every distance measured: HIP vs fp32 oracle, HIP vs f64, fp32 oracle vs f64, per mode.
 """
 import os
 
@@ -145,13 +151,18 @@ def _note(name, err, bad):
     achieved[name] = [max(a[0], err), max(a[1], bad), test if err > a[0] else a[2]]
 
 
-def grads_close(name, ref, got, rel=GRAD_REL, per_element=True, check=True):
+def grads_close(name, ref, got, rel=GRAD_REL, per_element=True, check=True, elem_mask=None):
+    """elem_mask (bool, ref's shape): the elements the per-element criterion is applied to (the max-normalised bar always
+    covers every element)."""
     got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
     got = got.reshape(ref.shape)
     scale = np.abs(ref).max() + 1e-30
     e = np.abs(ref - got)
     err = e.max() if e.size else 0.0
-    bad = float((e > 1e-4 * np.abs(ref) + 1e-6 * scale).mean()) if e.size else 0.0
+    outside = e > 1e-4 * np.abs(ref) + 1e-6 * scale
+    if elem_mask is not None:
+        outside = outside[elem_mask.reshape(ref.shape)]
+    bad = float(outside.mean()) if outside.size else 0.0
     _note(name, float(err / scale), bad)
     if not check:
         return float(err / scale)
@@ -169,20 +180,30 @@ def oracle_backward(ref, dl, lam):
 
 
 CHAIN = ("dL_dcov3D", "dL_dscales", "dL_drotations")   # what comes out of the covariance chain (backward.cu:228-306, 311-374)
+# The library's default evaluates that chain in double; two evaluations of it -- the reference's fp32 one and the exact
+# one -- are up to 1.7e-4 of the maximum apart at the benchmark shape.  The default mode's chain tensors are therefore
+# held to 1e-4 against the exact value AND to this looser bar against the fp32 restatement of the reference (so that a
+# regression of either side cannot hide behind the other); the fp32 mode (set_f64_chain(False)) restates the reference's
+# arithmetic and is held to the fp32 oracle at 1e-4 where the case allows it (test_reference_arithmetic_chain_mode).
+CHAIN_F64_VS_FP32_ORACLE_REL = 2.5e-4
 
 
-def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None):
+def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, chain="f64", chain_fp32_rel=GRAD_REL,
+                   tag=""):
     """Every gradient tensor of the HIP path at north_star's bar -- max |err| <= 1e-4 max |ref|, and per element
     |err| <= 1e-4 |ref| + 1e-6 max |ref| on >= 99.9 % of the elements -- against
       * the fp32 oracle `gr` (raster_oracle.c, the reference's arithmetic term by term) AND the double evaluation `gr64`
         (backward_f64.c, the exact gradient) for everything the reference's fp32 arithmetic determines to that accuracy;
-      * `gr64` alone for the three tensors of the covariance chain: the library evaluates that chain in double
-        (gauss_math.h), because the reference's fp32 evaluation of it is itself up to 2e-4 of the maximum away from the
-        exact value (recorded next to it as "[fp32 oracle vs f64]": two fp32 evaluations of an ill-conditioned quadratic
-        form need not agree with each other to 1e-4, each can only be held to the exact value).  The HIP-vs-fp32-oracle
-        distance of those three is recorded, not asserted."""
+      * chain == "f64" (the library's default: the covariance chain evaluated in double, gauss_math.h): the three chain
+        tensors at 1e-4 against `gr64`, and at CHAIN_F64_VS_FP32_ORACLE_REL (max-normalised) against the fp32 oracle --
+        the reference's fp32 evaluation of the chain is itself up to 2e-4 of the maximum away from the exact value
+        (recorded as "[fp32 oracle vs f64]"), so that second bar cannot be 1e-4;
+      * chain == "f32" (set_f64_chain(False): the reference's arithmetic, backward.cu:228-306, 311-374): the three chain
+        tensors at `chain_fp32_rel` against the fp32 oracle (1e-4 on the small cases), and their distance to the exact
+        value is recorded, not asserted."""
     (dm2, dcol, dop, dm3, dcov, dsh, dsc, drot, dconic) = bout
     assert gr64 is not None, "check_backward needs the double evaluation (oracle_backward)"
+    assert chain in ("f64", "f32")
     pairs = [("dL_dmeans2D", dm2, None), ("dL_dconic", dconic.reshape(-1, 4)[:, [0, 1, 3]], [0, 1, 3]), ("dL_dcolors", dcol, None),
              ("dL_dopacity", dop, None), ("dL_dmeans3D", dm3, None), ("dL_dcov3D", dcov, None)]
     if M:
@@ -191,8 +212,18 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None):
     for name, got, cols in pairs:
         r32 = gr[name] if cols is None else gr[name][:, cols]
         r64 = (gr64[name] if cols is None else gr64[name][:, cols]).reshape(r32.shape)
-        grads_close(name, r32, got, rel, per_element, check=name not in CHAIN)
-        grads_close(name + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
+        in_chain = name in CHAIN
+        if chain == "f64":
+            if in_chain:
+                grads_close(name + tag, r32, got, max(rel, CHAIN_F64_VS_FP32_ORACLE_REL), per_element=False)
+            else:
+                grads_close(name + tag, r32, got, rel, per_element)
+            grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
+        else:
+            grads_close(name + tag, r32, got, max(rel, chain_fp32_rel) if in_chain else rel,
+                        per_element and not in_chain)
+            grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element,
+                        check=not in_chain)
         grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
@@ -557,10 +588,27 @@ def test_hip_against_the_independent_fp64_autograd_statement_at_configs0(C_):
     cerr = np.abs(fout[1].cpu().numpy().reshape(3, -1).astype(np.float64) - col.detach().numpy().reshape(3, -1))[:, ok].max()
     assert cerr <= 2e-5, cerr
     bout = hip_backward(C_, fargs, fout, dl, 0.0)
-    for name, want, got in (("means3D", lv["m3"].grad, bout[3]), ("opacity", lv["op"].grad, bout[2]),
-                            ("scales", lv["sc"].grad, bout[6]), ("rotations", lv["rot"].grad, bout[7]),
-                            ("sh", lv["sh"].grad, bout[5])):
-        grads_close("[hip vs fp64 autograd] " + name, want.numpy(), got.double(), GRAD_REL, per_element=False)
+    # Per element.  Autograd differentiates an fp64 FORWARD; the product (like the reference) differentiates the forward it
+    # ran, whose per-Gaussian state -- pixel means, conics, colours -- is rounded to fp32.  What that rounding alone is
+    # worth is measured by the exact backward (backward_f64.c, pinned to autograd at 1e-10 on an fp64 state) fed the fp32
+    # state: 1.05e-5 of the maximum at most, but on 0.37 % (means3D) / 0.39 % (opacity) of the elements -- small components
+    # (median 0.5 % of the tensor's maximum) of Gaussians whose other components are large -- the absolute error of
+    # 1e-6..1e-5 of the maximum exceeds the criterion's floor of 1e-6 of the maximum.  Those elements are a property of the
+    # fp32 forward buffers, the same for every backward (the fp32 oracle has 112 of them, the exact backward 111, the HIP
+    # path the same set): they are excluded, at most 1 % may be, and on all the others the HIP path is held to the
+    # criterion against autograd.
+    g64s = orc.backward_f64(ref["state"], dl, 0.0)
+    for name, want, got, key in (("means3D", lv["m3"].grad, bout[3], "dL_dmeans3D"), ("opacity", lv["op"].grad, bout[2], "dL_dopacity"),
+                                 ("scales", lv["sc"].grad, bout[6], "dL_dscales"), ("rotations", lv["rot"].grad, bout[7], "dL_drotations"),
+                                 ("sh", lv["sh"].grad, bout[5], "dL_dsh")):
+        want = want.numpy()
+        state_only = np.abs(want - g64s[key].reshape(want.shape))
+        keep = state_only <= 1e-4 * np.abs(want) + 1e-6 * (np.abs(want).max() + 1e-30)
+        assert keep.mean() >= 0.99, f"{name}: {1 - keep.mean():.4f} of the elements are decided by the fp32 forward state"
+        achieved[f"[fp32 forward state vs fp64 autograd, exact backward] {name}"] = [
+            float(state_only.max() / (np.abs(want).max() + 1e-30)), float(1 - keep.mean()),
+            "test_hip_against_the_independent_fp64_autograd_statement_at_configs0"]
+        grads_close("[hip vs fp64 autograd] " + name, want, got.double(), GRAD_REL, per_element=True, elem_mask=keep)
     achieved["[hip vs fp64 autograd] colour (abs)"] = [float(cerr), 0.0, "test_hip_against_the_independent_fp64_autograd_statement_at_configs0"]
 
 
@@ -655,11 +703,13 @@ def test_empty_and_all_culled(C_):
 # BASELINE.json metric shape: size-independent properties (the oracle needs minutes here)
 # -------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=["metric_500k_1600x1062", "garden_like_2M_1600x1062",
-                                        "bicycle_like_5M_1600x1062", "train_like_6M_1920x1080"])
+                                        "bicycle_like_5M_1600x1062", "train_like_6M_1920x1080", "garden_clustered_2M"])
 def metric_scene(request):
     """The bench workload, and the 2 M-Gaussian one: 21 depth-rank bits + 13 tile bits > 32, i.e. 64-bit pair words,
     four times the depth-histogram rows and more depth buckets, 14.5 M pairs.  The 5 M / 6 M ones stand in for
-    BASELINE.json configs[3] / configs[4] (bicycle, Tanks&Temples train at 1920x1080 = 8160 tiles)."""
+    BASELINE.json configs[3] / configs[4] (bicycle, Tanks&Temples train at 1920x1080 = 8160 tiles).  garden_clustered_2M:
+    the real-scene-shaped load (synth_scene.make_gaussians_clustered): tile lists up to ~18 k entries (9x the mean) next
+    to a near-empty sky, depth keys concentrated in the foreground's depth range (uneven depth buckets)."""
     return ss.make_workload(request.param)
 
 
@@ -728,7 +778,7 @@ def test_full_size_properties(C_, metric_scene):
     assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())
 
 
-@pytest.mark.parametrize("name", ["metric_500k_1600x1062", "garden_like_2M_1600x1062"])
+@pytest.mark.parametrize("name", ["metric_500k_1600x1062", "garden_like_2M_1600x1062", "clustered_500k_1600x1062"])
 def test_full_size_elementwise_vs_oracle(C_, name):
     """The BASELINE.json metric shape (and the 2 M-Gaussian one) element-wise against the CPU oracle: the oracle needs
     about a second per pass here on the GPU box's cores.  Same bars as the small cases."""
@@ -742,6 +792,68 @@ def test_full_size_elementwise_vs_oracle(C_, name):
     gr, gr64 = oracle_backward(ref, dl, 0.1)
     bout = hip_backward(C_, fargs, fout, dl, 0.1)
     check_backward(bout, gr, ref["state"], 16, gr64=gr64)
+
+
+@pytest.fixture
+def fp32_chain(C_):
+    """The reference-arithmetic instantiation of the per-Gaussian backward (preprocess_bwd_kernel<*, false>)."""
+    before = C_.set_f64_chain(False)
+    assert C_.f64_chain() is False
+    yield
+    C_.set_f64_chain(before)
+
+
+@pytest.mark.parametrize("case", ["golden_a", "golden_b", "golden_c", "cfg0_10k", "20k_mixed_sparsity", "lego_like_300k",
+                                  "metric_500k"])
+def test_reference_arithmetic_chain_mode(C_, fp32_chain, case):
+    """`set_f64_chain(False)`: the only product mode that restates the reference's fp32 arithmetic for conic -> cov2D ->
+    cov3D -> (scale, quaternion) (backward.cu:228-306, 311-374).  All nine gradient tensors against the fp32 oracle at
+    1e-4 (the benchmark shape: the three chain tensors at 1.5e-4, everything else at 1e-4); the same pass through the
+    reserved (graph) path and the exact path bit for bit, so both issue routes of this kernel instantiation run."""
+    chain_rel = GRAD_REL
+    if case.startswith("golden_"):
+        kw = CASES[{"golden_a": "a_deg3_black", "golden_b": "b_mixed_white_sparsity", "golden_c": "c_deg0_rand"}[case]]
+        cam, g, bg, dl = case_inputs(kw)
+        H, W, P, lam = kw["H"], kw["W"], kw["P"], kw["lam"]
+    else:
+        kw = {"cfg0_10k": dict(P=10_000, W=400, H=400, f=300.0, cam_seed=None, gseed=0, degree_mode="all0", lam=0.0),
+              "20k_mixed_sparsity": dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed",
+                                         scale_mu=0.02, lam=0.1),
+              "lego_like_300k": dict(P=300_000, W=800, H=800, f=600.0, cam_seed=1, gseed=0, degree_mode="all3", lam=0.0),
+              "metric_500k": dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3",
+                                  lam=0.1)}[case]
+        W, H, P, lam = kw["W"], kw["H"], kw["P"], kw["lam"]
+        cam = ss.make_camera(W, H, kw["f"], kw["cam_seed"])
+        g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw.get("scale_mu", 0.012))
+        bg = np.array([0.1, 0.4, 0.9], np.float32) if case != "metric_500k" else np.zeros(3, np.float32)
+        dl = ss.upstream_grad(W, H, seed=2 if case != "metric_500k" else 1) * (W * H)
+        if case == "metric_500k":
+            chain_rel = 1.5e-4
+    ref = oracle_forward(bg, g, cam, H, W)
+    dl = mask_ambiguous(dl, ref)
+    gr, gr64 = oracle_backward(ref, dl, lam)
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
+    assert fout[0].ticket == 0
+    bout = hip_backward(C_, fargs, fout, dl, lam)
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", chain_fp32_rel=chain_rel, tag=" {fp32 chain}")
+    # the same view through whichever path the library picks now (reserved / graph once the size has been seen)
+    taken = 0
+    for _ in range(2):
+        fargs2, fout2 = hip_forward(C_, bg, g, cam, H, W)
+        taken += int(fout2[0].ticket != 0)
+        bout2 = hip_backward(C_, fargs2, fout2, dl, lam)
+        for a, b in zip(bout, bout2):
+            assert torch.equal(a, b)
+    assert taken >= 1
+    # and the default mode gives different bits for the chain tensors only (the two instantiations are really two)
+    C_.set_f64_chain(True)
+    try:
+        bout64 = hip_backward(C_, fargs, fout, dl, lam)
+    finally:
+        C_.set_f64_chain(False)
+    for k in (0, 1, 2, 5, 8):   # means2D, colours, opacity, sh, conic: not touched by the chain
+        assert torch.equal(bout[k], bout64[k]), k
+    assert not torch.equal(bout[7], bout64[7])
 
 
 def test_repeated_backward_and_pair_sort_path(C_):

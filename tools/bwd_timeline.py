@@ -17,7 +17,7 @@ os.environ["R3DGS_GRAPH"] = "0"
 import synth_scene as ss  # noqa: E402
 from diff_gaussian_rasterization import _C  # noqa: E402
 
-w, cam, g = ss.make_workload("metric_500k_1600x1062")
+w, cam, g = ss.make_workload(os.environ.get("R3_TL_WORKLOAD", "metric_500k_1600x1062"))
 W, H, P = w["W"], w["H"], w["P"]
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 args = (dv(np.zeros(3, np.float32)), dv(g["means3D"]), torch.Tensor([]), dv(g["opacity"]), dv(g["scales"]), dv(g["rotations"]),

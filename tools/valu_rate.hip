@@ -28,14 +28,15 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, DPP_ADD, CNDMASK, FMA_EXP_MIX, MAD_U32, CNDMASK_VCC_SET, CNDMASK_SGPR, CMP_CNDMASK, MINF, FMAC, FMA_SGPR, MOV, LDS_B128_BCAST, LDS_B32_BCAST, BPERMUTE, READLANE, NUM_KINDS };
+enum Kind { FMA, MUL, ADD, PK_FMA, PK_MUL, EXP, RCP, DPP_ADD, CNDMASK, FMA_EXP_MIX, MAD_U32, CNDMASK_VCC_SET, CNDMASK_SGPR, CMP_CNDMASK, MINF, FMAC, FMA_SGPR, MOV, LDS_B128_BCAST, LDS_B32_BCAST, BPERMUTE, READLANE, FMA_F64, MUL_F64, ADD_F64, NUM_KINDS };
 static const char* kNames[NUM_KINDS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_fma_f32 (2 lanes-ops/lane)",
                                         "v_pk_mul_f32 (2 lanes-ops/lane)", "v_exp_f32", "v_rcp_f32",
                                         "v_add_f32_dpp row_ror:4", "v_cndmask_b32", "7 x v_fma_f32 + 1 x v_exp_f32",
                                         "v_mad_u32_u24", "v_cndmask_b32 vcc (vcc set to 0x5555..)", "v_cndmask_b32_e64 sgpr pair",
                                         "v_cmp_gt_f32 + v_cndmask_b32 (per pair)", "v_min_f32", "v_fmac_f32 (2 vgpr srcs + acc)",
                                         "v_fma_f32 with one SGPR source", "v_mov_b32", "ds_read_b128 same address (per read)",
-                                        "ds_read_b32 same address (per read)", "ds_bpermute_b32", "v_readlane_b32"};
+                                        "ds_read_b32 same address (per read)", "ds_bpermute_b32", "v_readlane_b32",
+                                        "v_fma_f64", "v_mul_f64", "v_add_f64"};
 
 #define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 
@@ -47,6 +48,9 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
     v2f ps = {s, s};
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f q0, q1, q2, q3;
+    // the covariance chain of preprocess_bwd runs in double (gauss_math.h cov2d_backward_f64): what does that cost a SIMD?
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
+    const double sd = (double)s;
     __shared__ float lds[64];
     lds[threadIdx.x] = a0;
     __syncthreads();
@@ -152,7 +156,19 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
                 asm volatile("v_readlane_b32 %0, %4, 3\n v_readlane_b32 %1, %5, 7\n v_readlane_b32 %2, %6, 11\n v_readlane_b32 %3, %7, 19"
                              : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
                 sacc += r0 + r1 + r2 + r3;
-            } else if (KIND == MAD_U32)
+            } else if (KIND == FMA_F64)
+                asm volatile("v_fma_f64 %0, %0, %8, %0\n v_fma_f64 %1, %1, %8, %1\n v_fma_f64 %2, %2, %8, %2\n v_fma_f64 %3, %3, %8, %3\n"
+                             "v_fma_f64 %4, %4, %8, %4\n v_fma_f64 %5, %5, %8, %5\n v_fma_f64 %6, %6, %8, %6\n v_fma_f64 %7, %7, %8, %7"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(sd));
+            else if (KIND == MUL_F64)
+                asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n"
+                             "v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(sd));
+            else if (KIND == ADD_F64)
+                asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                             "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(sd));
+            else if (KIND == MAD_U32)
                 asm volatile("v_mad_u32_u24 %0, %0, %8, %0\n v_mad_u32_u24 %1, %1, %8, %1\n v_mad_u32_u24 %2, %2, %8, %2\n v_mad_u32_u24 %3, %3, %8, %3\n"
                              "v_mad_u32_u24 %4, %4, %8, %4\n v_mad_u32_u24 %5, %5, %8, %5\n v_mad_u32_u24 %6, %6, %8, %6\n v_mad_u32_u24 %7, %7, %8, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
@@ -160,7 +176,8 @@ __global__ __launch_bounds__(64) void rate_kernel(unsigned long long* cycles, fl
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
-    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
+                    (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
     if (r == 123.456f || sacc == 12345) sink[0] = r;   // never true: keeps the chains alive
 }
 
@@ -244,5 +261,8 @@ int main(int argc, char** argv)
     sweep<LDS_B32_BCAST>(iters, d_cyc, d_sink, e0, e1);
     sweep<BPERMUTE>(iters, d_cyc, d_sink, e0, e1);
     sweep<READLANE>(iters, d_cyc, d_sink, e0, e1);
+    sweep<FMA_F64>(iters, d_cyc, d_sink, e0, e1);
+    sweep<MUL_F64>(iters, d_cyc, d_sink, e0, e1);
+    sweep<ADD_F64>(iters, d_cyc, d_sink, e0, e1);
     return 0;
 }
