@@ -83,7 +83,7 @@ STAGE_KERNELS = {
     "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
     # (the one-workgroup kernel that orders the tiles heaviest first runs inside this stage's events too)
     "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
-                  ("r3::tile_order_kernel", 1, False)],
+                  ("r3::unit_order_kernel", 1, False)],
     "preprocess_bwd": [("r3::preprocess_bwd_kernel<", 1, False)],   # <dense degree-3 rows?, covariance chain in double?>
 }
 
@@ -95,6 +95,9 @@ def find_kernel(table, prefix):
     for k in table:
         if k.startswith(prefix):
             return table[k]
+    renamed = {"r3::unit_order_kernel": "r3::tile_order_kernel"}   # name of the same kernel in the round-4 profiles
+    if prefix in renamed:
+        return find_kernel(table, renamed[prefix])
     return None
 
 
@@ -159,10 +162,8 @@ def committed_kernel_ms(kernel, path=None):
     path = path or os.path.join(ROOT, KERNEL_STATS)
     if not os.path.exists(path):
         return None
-    for r in csv.DictReader(open(path)):
-        if r["Name"].replace("void ", "").split("(")[0].startswith(kernel):
-            return float(r["AverageNs"]) / 1e6
-    return None
+    rows = {r["Name"].replace("void ", "").split("(")[0]: float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(path))}
+    return find_kernel(rows, kernel)
 
 
 def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):

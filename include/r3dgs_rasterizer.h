@@ -179,11 +179,21 @@ int r3dgs_set_f64_chain(int on);
  * r3dgs_forward_hint(1), the initial state: they do. */
 void r3dgs_forward_hint(int will_backward);
 
+/* r3dgs_set_bwd_segments(0): the backward blend walks every tile's list with ONE workgroup; 1 (default): a list of at
+ * least max(256, the mean list length of the pass) entries is walked in segments of 128 by several workgroups, each starting from the per-pixel state the forward
+ * blend checkpointed there (real scenes have tiles many times heavier than the mean).  The forward
+ * and the backward of a state must run under the same setting only in the sense that a forward issued with segments off
+ * leaves no checkpoints and its backward then never splits (the pass header says which).  Returns the previous setting (a
+ * negative argument only queries).  Also R3DGS_BWD_SEG=0. */
+int r3dgs_set_bwd_segments(int on);
+
 /* Debug accessor: the forward's per-quadrant depths ([tiles][4] uint32: quadrant q = (x half) + 2 * (y half) of the
- * 16x16 tile) and, after a backward with the order on, the launch order it used ([tiles] uint32); device arrays, either
- * may be NULL. */
-int r3dgs_export_tile_order(int width, int height, char* image_buffer, unsigned int* quad_depth, unsigned int* tile_order,
-                            void* stream);
+ * 16x16 tile) and, after a backward with the order on, the launch order it used: [r3dgs_bwd_units_cap(R, W, H) + 1]
+ * uint32, entry = tile | segment << 20 | segments of the tile << 26, heaviest first; the LAST entry is the number of units
+ * of the pass.  P, R: as given to the backward.  Device arrays, either may be NULL. */
+int r3dgs_export_tile_order(int P, int R, int width, int height, char* binning_buffer, char* image_buffer,
+                            unsigned int* quad_depth, unsigned int* unit_order, void* stream);
+int r3dgs_bwd_units_cap(int R, int width, int height);
 
 /* Forget every pair count learnt so far (a new scene is about to be loaded; tests): the next pass of each image size
  * takes the exact-size path again. */

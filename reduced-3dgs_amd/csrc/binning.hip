@@ -219,7 +219,7 @@ __device__ __forceinline__ void emit_pairs_block(const EmitArgs& a, uint32_t R, 
             const uint32_t g = j_lo + r0 + k, id = a.order[g];
             s_start[k] = r0 + k == 0 ? start0 : offsets[g - 1];
             s_id[k] = id;
-            s_rect[k] = a.rect[id];
+            s_rect[k] = a.rect_sorted ? a.rect_sorted[g] : a.rect[id];   // depth-ordered copy: a coalesced read, no gather
         }
     };
     const uint32_t nr0 = min(n, (uint32_t)kEmitStage);

@@ -284,6 +284,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
     }
 
     // software pipeline: the records of chunk k+1 are gathered into registers while chunk k is blended
+    // A list this long may be walked in segments by the backward (common.h): the state in front of every S-th entry is
+    // parked for it while the walk is here anyway (4 KB per tile and checkpoint; nothing for the other tiles)
+    const uint32_t seg_log2 = a.ckpt ? global_ptr(a.hdr)->ckpt : 0u;
+    const bool segmented = seg_log2 != 0u && range.y - range.x >= global_ptr(a.hdr)->ckpt_thr;
     float4 nxa, nxb, nxc;
     uint32_t nxid = 0;
     nxa = nxb = nxc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,6 +307,15 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
 #pragma unroll
             for (int q = 0; q < PPL; q++) live |= fwd_pix_live(pix[q]);
             if (__ballot(live) == 0ull) break;  // every pixel of the region saturated
+        }
+        if (segmented) {
+            const uint32_t rel = base - range.x;
+            if (rel != 0u && (rel & ((1u << seg_log2) - 1u)) == 0u && (rel >> seg_log2) < (uint32_t)kBwdSegMax) {
+                auto* dst = global_ptr(a.ckpt) + ckpt_slot(range.x, rel >> seg_log2, tile, seg_log2) * 256;
+#pragma unroll
+                for (int q = 0; q < PPL; q++)   // a pixel that is done by now is never looked up here
+                    dst[(part * PPL + q) * 64 + lane] = make_float4(pix[q].T, pix[q].C0, pix[q].C1, pix[q].C2);
+            }
         }
         __syncthreads();
         stage_entry(s_rec[lane], nxa, nxb, nxc);
@@ -384,6 +397,12 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
         if (lane == 0) global_ptr(a.quad_depth)[tile * 4u + (uint32_t)(part * PPL + q)] = m;
     }
+    if (segmented) {   // slot 0: the colour every contributor left (without the background): what lies behind a checkpoint
+        auto* dst = global_ptr(a.ckpt) + ckpt_slot(range.x, 0u, tile, seg_log2) * 256;
+#pragma unroll
+        for (int q = 0; q < PPL; q++)
+            dst[(part * PPL + q) * 64 + lane] = make_float4(fwd_pix_T(pix[q]), pix[q].C0, pix[q].C1, pix[q].C2);
+    }
     const size_t plane = (size_t)a.W * a.H;
     const float bg0 = global_ptr(a.bg)[0], bg1 = global_ptr(a.bg)[1], bg2 = global_ptr(a.bg)[2];
 #pragma unroll
@@ -433,8 +452,14 @@ constexpr int kGradStride = 9;   // the 9 sums of a list entry (odd stride: the 
 #ifndef R3_BWD_OCC
 #define R3_BWD_OCC 6
 #endif
-// FIRST: this is the first kernel of the backward (no tile order): it installs the pass block for the kernels behind it and
-// reads its own arguments from the kernarg segment; otherwise tile_order_kernel did and the arguments come from the block
+// One workgroup = one UNIT: a tile, or -- for a tile whose list the pass splits (common.h) -- entries [lo, hi) of
+// its list.  A segment that ends in front of a pixel's last contributor starts that pixel from the forward's checkpoint at
+// `hi`: T there, and the colour that lies behind it = (final colour - colour in front of hi) / T, projected on the pixel's
+// upstream gradient (the accumulated-colour state A of blend_math.h BwdPix); a pixel whose last contributor is inside
+// [lo, hi) starts as ever, one that ends in front of lo has nothing to do here.  Every list entry belongs to exactly one
+// segment, so every row of the per-pair slab still has ONE writer: no atomics, bit-reproducible.
+// FIRST: this is the first kernel of the backward (no unit order): it installs the pass block for the kernels behind it and
+// reads its own arguments from the kernarg segment; otherwise unit_order_kernel did and the arguments come from the block
 // (a graph replay refreshes the by-value arguments of its first node only).
 template <int PPL, bool REUSE, bool FIRST>
 __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* dst, BwdPassArgs v)
@@ -446,28 +471,17 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     __shared__ float s_grad[kChunk * kGradStride];
     constexpr int PARTS = 4 / PPL;
     const int lane = threadIdx.x;
-#ifdef R3_SPLIT_EMU
-    // TIMING EMULATION ONLY (gradients are WRONG in this build): what would it buy to walk the deep and the shallow half of a
-    // heavy tile's list in two workgroups?  Twice the grid.  Units [0, n): the SHALLOW halves of the split tiles, in the
-    // heaviest-first order (the split tiles are the first of that order, so these come first; the unit of an unsplit tile
-    // leaves after one 16-byte load); units [n, 2n): every tile in heaviest-first order -- its deep half if it is split, the
-    // whole walk if not.  The shallow half starts from garbage pixel state: same instructions, same traffic minus the
-    // checkpoint a real split would load.
-    const uint32_t emu_n = a.nblocks;
-    const uint32_t emu_half = blockIdx.x < emu_n ? 1u : 0u;
-    const uint32_t emu_rank = emu_half ? blockIdx.x : blockIdx.x - emu_n;
-    const uint32_t wg = a.tile_order ? a.tile_order[emu_rank] : xcd_remap(emu_rank, a.nblocks);
-    uint32_t emu_mid = 0u;
-    {
-        const uint32_t* qd = a.quad_depth + 4u * wg;
-        const uint32_t deepest =
-            (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(qd[0], qd[1]), max(qd[2], qd[3])));
-        if (deepest > (uint32_t)R3_SPLIT_EMU) emu_mid = ((deepest / 2u + 63u) / 64u) * 64u;
-        if (emu_half && emu_mid == 0u) return;
+    uint32_t wg, seg = 0u, nseg = 1u, walk_log2 = 0u;
+    if (a.tile_order) {
+        if (blockIdx.x >= a.tile_order[a.units_cap]) return;   // the grid covers the most units a pass of this shape can have
+        walk_log2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[a.units_cap + 1u]);   // segment length of this pass
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[blockIdx.x]);
+        wg = u & ((1u << kUnitTileBits) - 1u);
+        seg = (u >> kUnitTileBits) & 63u;
+        nseg = u >> (kUnitTileBits + 6u);
+    } else {
+        wg = xcd_remap(blockIdx.x, a.nblocks);
     }
-#else
-    const uint32_t wg = a.tile_order ? a.tile_order[blockIdx.x] : xcd_remap(blockIdx.x, a.nblocks);
-#endif
     const uint32_t tile = wg / PARTS;
     const int part = (int)(wg % PARTS);
     const int tile_x = (int)(tile % (uint32_t)a.gx), tile_y = (int)(tile / (uint32_t)a.gx);
@@ -513,22 +527,38 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
         R3_TL_END(0)
         return;
     }
-#ifdef R3_SPLIT_EMU
-    int emu_lo = 0;
-    if (emu_mid != 0u && emu_mid < lmax) {
-        if (emu_half)
-            lmax = emu_mid;           // shallow half: entries [0, mid)
-        else
-            emu_lo = (int)emu_mid;    // deep half: entries [mid, lmax)
+    // this unit's part of the list: [lo, hi)
+    uint32_t lo = 0u, hi = lmax;
+    if (nseg > 1u) {
+        lo = seg << walk_log2;
+        if (seg + 1u < nseg) hi = lo + (1u << walk_log2);   // (the unit order only makes segments with lo < lmax)
+        if (hi < lmax) {
+            // pixels whose last contributor lies behind this segment pass through it: their state in front of entry `hi`
+            // (the forward's checkpoints are S = 2^hdr->ckpt apart; a pass may walk segments of 2 S, 4 S ...)
+            const uint32_t seg_log2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.hdr->ckpt);
+            const float4* ck = a.ckpt + ckpt_slot(range.x, hi >> seg_log2, tile, seg_log2) * 256;
+            const float4* fin = a.ckpt + ckpt_slot(range.x, 0u, tile, seg_log2) * 256;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                BwdPix& p = pix[q];
+                if (p.last > hi) {
+                    const float4 c = ck[(part * PPL + q) * 64 + lane], f = fin[(part * PPL + q) * 64 + lane];
+                    // p.T is the final transmittance here and p.A the background term bg . g
+                    p.A = ((f.y - c.y) * p.g0 + (f.z - c.z) * p.g1 + (f.w - c.w) * p.g2 + p.T * p.A) * R3_RCP(c.x);
+                    p.T = c.x;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PPL; q++) qlast[q] = min(qlast[q], hi);
+        }
     }
-#endif
 
     const float half_w = 0.5f * (float)a.W, half_h = 0.5f * (float)a.H;  // backward.cu:498-499
     float4 nxa, nxb, nxc;
     uint32_t nxid = 0;
     nxa = nxb = nxc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int cfirst = (int)((lmax - 1) / kChunk) * kChunk;
-    if ((uint32_t)cfirst + (uint32_t)lane < lmax) {
+    const int cfirst = (int)((hi - 1) / kChunk) * kChunk;
+    if ((uint32_t)cfirst + (uint32_t)lane < hi) {
         nxid = a.point_list[range.x + (uint32_t)cfirst + (uint32_t)lane];
         const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
         nxa = g[0];
@@ -546,33 +576,29 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     float* const s_grad_slot = s_grad + reduce9_component(lane);
     SplatSums sg;   // zero whenever an entry starts: cleared after every reduction, untouched by entries without a hit
     sg.sx = sg.sy = sg.sxx = sg.sxy = sg.syy = sg.sm = sg.r = sg.g = sg.b = 0.f;
-#ifdef R3_SPLIT_EMU
-    for (int cbase = cfirst; cbase >= emu_lo; cbase -= kChunk) {
-#else
-    for (int cbase = cfirst; cbase >= 0; cbase -= kChunk) {
-#endif
+    for (int cbase = cfirst; cbase >= (int)lo; cbase -= kChunk) {
         __syncthreads();
         stage_entry(s_rec[lane], nxa, nxb, nxc);
         unsigned long long qmask[PPL], anymask = 0ull;
         {
             const Splat mine = splat_from_regs(nxa, nxb, nxc);
-            const bool have = (uint32_t)cbase + (uint32_t)lane < lmax;
+            const bool have = (uint32_t)cbase + (uint32_t)lane < hi;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
                 if (REUSE) {
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nxm, q);
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nxm >> 32), q);
-                    qmask[q] = ((unsigned long long)hi << 32) | lo;
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nxm, q);
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nxm >> 32), q);
+                    qmask[q] = ((unsigned long long)mhi << 32) | mlo;
                 } else {
                     qmask[q] = __ballot(have && region_may_contribute(mine, qx0[q], qx0[q] + 7.f, qy0[q], qy0[q] + 7.f));
                 }
-                // entries behind the quadrant's deepest contributor (scalar arithmetic)
+                // entries behind the quadrant's deepest contributor / behind this unit's segment (scalar arithmetic)
                 const uint32_t left = qlast[q] > (uint32_t)cbase ? qlast[q] - (uint32_t)cbase : 0u;
                 if (left < (uint32_t)kChunk) qmask[q] &= (1ull << left) - 1ull;
                 anymask |= qmask[q];
             }
         }
-        if (cbase >= kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
+        if (cbase >= (int)lo + kChunk) {  // gather the next (shallower) chunk while this one is processed; it is always full
             nxid = nnid;
             if (cbase >= 2 * kChunk) nnid = a.point_list[range.x + (uint32_t)(cbase - 2 * kChunk) + (uint32_t)lane];
             const float4* g = reinterpret_cast<const float4*>(a.rec + nxid);
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             if (REUSE && lane < 4) nxm = masks0[(size_t)((cbase - kChunk) >> 6) * 4 + lane];
         }
         __syncthreads();
-        const int n = (int)min((uint32_t)kChunk, lmax - (uint32_t)cbase);
+        const int n = (int)min((uint32_t)kChunk, hi - (uint32_t)cbase);
         unsigned long long contributed = 0ull;   // wave-uniform: entries of this chunk that got sums
         while (anymask) {  // surviving entries, back to front: highest set bit first
             const int j = 63 - __builtin_clzll(anymask);
@@ -641,7 +667,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             a.pair_flag[slot] = 1;
         }
     }
-    R3_TL_END(lmax)
+    R3_TL_END(hi - lo)
 }
 
 #if defined(R3_TIMELINE) || defined(R3_TIMELINE_FWD)
@@ -651,67 +677,199 @@ extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 }
 #endif
 
-// Launch order of the backward blend's tiles: heaviest first.  All tiles are resident at once for the first half of the
+// Launch order of the backward blend's units: heaviest first.  All units are resident at once for the first half of the
 // kernel and each wave's duration is set by how many share its SIMD, so in row-major order the chip drains for the whole
 // second half (profiles/r03_bwd_timeline_row_major.txt: 20 resident waves per CU for five tenths of a CU's span, then 17, 12, 9, 6,
 // 3); started by decreasing weight, the long walks are under way when the short ones fill the gaps (0.367 -> 0.313 ms on
-// the metric shape).  Weight = sum over the four quadrants of the deepest contributor (ImageState::quad_depth): the
-// entries the wave will visit.  One workgroup, counting sort over 1024 weight classes (64 classes: +2 us for the stage,
-// 16: +10, 4: +22); the order inside a class is
-// whatever the LDS atomics make it -- every tile's arithmetic is its own, so the gradients do not depend on the order
-// (tests/test_gpu_parity.py compares the two orders bit for bit).  The hardware deals consecutive workgroups over the
-// eight XCDs, i.e. every XCD gets every eighth tile of the sorted list: equal work per XCD as well -- and every XCD's L2
-// now sees every Gaussian's record (the kernel's FETCH_SIZE went from 62 to 150 MB; 1.6 TB/s in total, nowhere near a
-// bound).  Keeping each XCD on its band of the image and ordering inside the band only (FETCH_SIZE 74 MB) measured
-// 0.315 ms against 0.305 ms for the stage: balance between the XCDs is worth more here than the locality.
+// the metric shape).  A unit is a tile, or one segment of a tile whose list is long and deep (common.h):
+// on a scene with the load of a real capture the heaviest tile walks three times the mean and the kernel was as long as
+// that walk.  Weight of a unit = sum over the four quadrants of the entries it will visit there (ImageState::quad_depth
+// clamped to the segment).  Tiles nothing contributed to are left out.  One workgroup, counting sort over 1024 weight
+// classes (64 classes: +2 us for the stage, 16: +10, 4: +22); the order inside a class is whatever the LDS atomics make it
+// -- every unit's arithmetic is its own, so the gradients do not depend on the order (tests/test_gpu_parity.py compares
+// the two orders bit for bit).  The hardware deals consecutive workgroups over the eight XCDs, i.e. every XCD gets every
+// eighth unit of the sorted list: equal work per XCD as well -- and every XCD's L2 now sees every Gaussian's record (the
+// kernel's FETCH_SIZE went from 62 to 150 MB; 1.6 TB/s in total, nowhere near a bound).  Keeping each XCD on its band of
+// the image and ordering inside the band only (FETCH_SIZE 74 MB) measured 0.315 ms against 0.305 ms for the stage: balance
+// between the XCDs is worth more here than the locality.
 constexpr int kOrderThreads = 1024, kOrderClasses = 1024;
-__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* dst, BwdPassArgs v)
+
+// segments of 2^walk entries the backward walks a tile in: 1 unless the forward left checkpoints for it (list length)
+// and it is deeper than one segment
+__device__ __forceinline__ uint32_t unit_segments(uint32_t list_len, uint32_t deepest, uint32_t thr, uint32_t walk)
+{
+    if (list_len < thr || deepest <= (1u << walk)) return 1u;
+    return min((deepest + (1u << walk) - 1u) >> walk, (uint32_t)kBwdSegMax);
+}
+// entries segment `s` of `n` visits in the four quadrants whose deepest contributors are d
+__device__ __forceinline__ uint32_t unit_weight(const uint4& d, uint32_t s, uint32_t n, uint32_t walk)
+{
+    if (n == 1u) return d.x + d.y + d.z + d.w;
+    const uint32_t lo = s << walk, hi = s + 1u < n ? lo + (1u << walk) : 0xFFFFFFFFu;
+    auto part = [&](uint32_t q) { return min(max(q, lo), hi) - lo; };
+    return part(d.x) + part(d.y) + part(d.z) + part(d.w);
+}
+
+__global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ uint32_t s_count[kOrderClasses];
     __shared__ uint32_t s_scan[kOrderThreads / 64];
-    __shared__ uint32_t s_max;
-    const uint32_t tid = threadIdx.x;
+    constexpr int kWalks = 4;   // segment lengths a pass may walk: S, 2 S, 4 S, 8 S (the first whose units fit the launch)
+    __shared__ uint32_t s_max[kWalks + 1], s_units[kWalks];
+    const uint32_t tid = threadIdx.x, lane_id = tid & 63u;
     install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
     const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(v.blend.quad_depth);
+    const uint2* __restrict__ ranges = v.blend.ranges;
     uint32_t* __restrict__ order = v.blend.tile_order;
-    const uint32_t n_tiles = v.blend.nblocks;   // one workgroup of the backward blend per tile
+    const uint32_t n_tiles = v.blend.nblocks;   // one workgroup of the backward blend per tile at least
+    const uint32_t cap = v.blend.units_cap;
+    const uint32_t seg_log2 = (v.blend.segments != 0 && v.blend.ckpt != nullptr && n_tiles <= (1u << kUnitTileBits))
+                                  ? v.blend.hdr->ckpt : 0u;   // 0: the forward left no checkpoints / segments are off
+    const uint32_t thr = seg_log2 ? v.blend.hdr->ckpt_thr : 0xFFFFFFFFu;
+    // Units of the shortest segments: every tile once plus at most (list length / S) more, i.e. <= tiles + pairs / S.  Only a
+    // pass whose lists are so long that this exceeds what it may launch has to look at longer segments.  (The bound is taken
+    // from the pass's pair count, not from the capacity its binning blob happens to have: the exact-size path and the
+    // reserved path of one view then walk the same segments and give the same bits.)
+    const uint32_t pairs_s = v.blend.hdr->num_pairs >> kBwdSegMinLog2;
+    const uint32_t fit = min(cap, n_tiles + min(pairs_s, 8u * n_tiles));
+    const bool always_fits = n_tiles + pairs_s <= fit;
     s_count[tid] = 0u;
-    if (tid == 0) s_max = 0u;
+    if (tid <= kWalks) s_max[tid] = 0u;
+    if (tid < kWalks) s_units[tid] = 0u;
     __syncthreads();
-    // up to kOrderKeep tiles per thread stay in registers between the three passes (one memory round trip instead of
-    // three: the kernel is a chain of latencies, 9.5 us when every pass went back to memory); a larger grid re-reads
+    // up to kOrderKeep tiles per thread stay in registers between the passes (one memory round trip instead of four: the
+    // kernel is a chain of latencies, 9.5 us when every pass went back to memory); a larger grid re-reads
     constexpr int kOrderKeep = 8;
     const bool keep = n_tiles <= (uint32_t)(kOrderKeep * kOrderThreads);
-    uint32_t w[kOrderKeep];
-    uint32_t wmax = 0u;
-    auto weight = [&](uint32_t t) {
-        const uint4 d = qd[t];
-        return d.x + d.y + d.z + d.w;
+    uint4 w[kOrderKeep];
+    uint32_t len[kOrderKeep];
+    auto load = [&](uint32_t t, uint4& d, uint32_t& l) {
+        d = make_uint4(0u, 0u, 0u, 0u);
+        l = 0u;
+        if (t < n_tiles) {
+            d = qd[t];
+            const uint2 r = ranges[t];
+            l = r.y - r.x;
+        }
+    };
+    if (keep) {
+        // every load in flight before the first use (written as `load` per tile the compiler reused one register pair for the
+        // ranges and waited for each of the eight loads in turn: 12 us of the kernel's 22)
+        uint2 rr[kOrderKeep];
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++) {
+            const uint32_t t = min(tid + (uint32_t)(k * kOrderThreads), n_tiles - 1u);
+            w[k] = qd[t];
+            rr[k] = ranges[t];
+        }
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++) {
+            const bool in = tid + (uint32_t)(k * kOrderThreads) < n_tiles;
+            if (!in) w[k] = make_uint4(0u, 0u, 0u, 0u);
+            len[k] = in ? rr[k].y - rr[k].x : 0u;
+        }
+    }
+    uint32_t walk = seg_log2;
+    if (seg_log2 && !always_fits) {
+        // pass 0 (rare: tens of millions of pairs): units of every candidate segment length
+        uint32_t units[kWalks];
+#pragma unroll
+        for (int m = 0; m < kWalks; m++) units[m] = 0u;
+        auto look = [&](const uint4& d, uint32_t l) {
+            if (d.x + d.y + d.z + d.w == 0u) return;
+            const uint32_t deepest = max(max(d.x, d.y), max(d.z, d.w));
+#pragma unroll
+            for (int m = 0; m < kWalks; m++) units[m] += unit_segments(l, deepest, thr, seg_log2 + m);
+        };
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kOrderKeep; k++) look(w[k], len[k]);
+        } else {
+            for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+                uint4 d;
+                uint32_t l;
+                load(t, d, l);
+                look(d, l);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int m = 0; m < kWalks; m++) units[m] += (uint32_t)__shfl_xor((int)units[m], off);
+        if (lane_id == 0u)
+#pragma unroll
+            for (int m = 0; m < kWalks; m++) atomicAdd(&s_units[m], units[m]);
+        __syncthreads();
+        int m = 0;
+        while (m < kWalks && s_units[m] > fit) m++;
+        walk = m < kWalks ? seg_log2 + (uint32_t)m : 0u;   // none fits: whole tiles
+    }
+    auto segs = [&](const uint4& d, uint32_t l) -> uint32_t {
+        if (d.x + d.y + d.z + d.w == 0u) return 0u;   // nothing contributed to this tile: no unit
+        return walk ? unit_segments(l, max(max(d.x, d.y), max(d.z, d.w)), thr, walk) : 1u;
+    };
+    // Leading segments of a split tile that all four quadrants walk in full: they all weigh 4 x the segment length -- one
+    // class, thousands of units in a deep scene, and one LDS counter they would all queue on (the kernel took 52 us at
+    // 2 M Gaussians that way).  A tile's FULL segments are therefore counted and placed as a group, and the groups of the
+    // tiles a wave holds at the same step add up among themselves (a shuffle scan): one atomic per wave and step.
+    auto full_segments = [&](const uint4& d, uint32_t n) -> uint32_t {
+        if (n <= 1u) return 0u;
+        const uint32_t f = min(min(d.x, d.y), min(d.z, d.w)) >> walk;
+        return min(f, n == (uint32_t)kBwdSegMax ? n - 1u : n);   // (a capped tile's last segment takes the rest: not "full")
+    };
+    // pass 1: the heaviest unit
+    uint32_t kmax = 0u;
+    auto heaviest = [&](const uint4& d, uint32_t l) {
+        const uint32_t n = segs(d, l);
+        if (n == 0u) return;
+        kmax = max(kmax, unit_weight(d, 0u, n, walk));
+        if (n > 1u) kmax = max(kmax, unit_weight(d, n - 1u, n, walk));   // (only a capped tile's last segment can be heavier)
     };
     if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
-            const uint32_t t = tid + (uint32_t)(k * kOrderThreads);
-            w[k] = t < n_tiles ? weight(t) : 0u;
-            wmax = max(wmax, w[k]);
-        }
+        for (int k = 0; k < kOrderKeep; k++) heaviest(w[k], len[k]);
     } else {
-        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) wmax = max(wmax, weight(t));
+        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+            uint4 d;
+            uint32_t l;
+            load(t, d, l);
+            heaviest(d, l);
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
-    if ((tid & 63u) == 0u) atomicMax(&s_max, wmax);
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+    if (lane_id == 0u) atomicMax(&s_max[0], kmax);
     __syncthreads();
-    const float scale = (float)(kOrderClasses - 1) / (float)max(s_max, 1u);
+    const float scale = (float)(kOrderClasses - 1) / (float)max(s_max[0], 1u);
     // class 0 = the heaviest
     auto klass = [&](uint32_t wt) {
         return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)wt * scale), (uint32_t)(kOrderClasses - 1));
     };
+    const uint32_t full_class = klass(4u << walk);
+    auto wave_prefix = [&](uint32_t x, uint32_t* total) {   // exclusive prefix and total of x over the wave
+        uint32_t incl = x;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if (lane_id >= (uint32_t)off) incl += up;
+        }
+        *total = (uint32_t)__shfl((int)incl, 63);
+        return incl - x;
+    };
+    auto count = [&](const uint4& d, uint32_t l) {   // (called by every lane of a wave at the same step)
+        const uint32_t n = segs(d, l), f = full_segments(d, n);
+        uint32_t total;
+        wave_prefix(f, &total);
+        if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
+        for (uint32_t k = f; k < n; k++) atomicAdd(&s_count[klass(unit_weight(d, k, n, walk))], 1u);
+    };
     if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++)
-            if (tid + (uint32_t)(k * kOrderThreads) < n_tiles) atomicAdd(&s_count[klass(w[k])], 1u);
+        for (int k = 0; k < kOrderKeep; k++) count(w[k], len[k]);
     } else {
-        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) atomicAdd(&s_count[klass(weight(t))], 1u);
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {   // uniform trip count: the wave scan needs every lane
+            uint4 d;
+            uint32_t l;
+            load(t0 + tid, d, l);
+            count(d, l);
+        }
     }
     __syncthreads();
     // exclusive scan of the class counts (one class per thread)
@@ -719,37 +877,52 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(BwdPassArgs* 
     uint32_t incl = mine;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-        if ((tid & 63u) >= (uint32_t)off) incl += up;
+        if (lane_id >= (uint32_t)off) incl += up;
     }
-    if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+    if (lane_id == 63u) s_scan[tid >> 6] = incl;
     __syncthreads();
     uint32_t before = 0u;
     for (uint32_t k = 0; k < (tid >> 6); k++) before += s_scan[k];
     __syncthreads();
     s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
+    if (tid == kOrderThreads - 1) {
+        order[cap] = before + incl;   // the units of this pass (<= cap by the choice of `walk`; whole tiles: <= tiles <= cap)
+        order[cap + 1u] = walk;       // log2 of the segment length they walk (0: whole tiles)
+    }
     __syncthreads();
+    auto place = [&](uint32_t t, const uint4& d, uint32_t l) {
+        const uint32_t n = segs(d, l), f = full_segments(d, n);
+        uint32_t total;
+        const uint32_t ahead = wave_prefix(f, &total);
+        uint32_t base = 0u;
+        if (lane_id == 0u && total) base = atomicAdd(&s_count[full_class], total);
+        base = (uint32_t)__shfl((int)base, 0) + ahead;
+        const uint32_t word = t | (n << (kUnitTileBits + 6u));
+        for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
+        for (uint32_t k = f; k < n; k++)
+            order[atomicAdd(&s_count[klass(unit_weight(d, k, n, walk))], 1u)] = word | (k << kUnitTileBits);
+    };
     if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
-            const uint32_t t = tid + (uint32_t)(k * kOrderThreads);
-            if (t < n_tiles) order[atomicAdd(&s_count[klass(w[k])], 1u)] = t;
-        }
+        for (int k = 0; k < kOrderKeep; k++) place(tid + (uint32_t)(k * kOrderThreads), w[k], len[k]);
     } else {
-        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) order[atomicAdd(&s_count[klass(weight(t))], 1u)] = t;
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
+            uint4 d;
+            uint32_t l;
+            load(t0 + tid, d, l);
+            place(t0 + tid, d, l);
+        }
     }
 }
 
 template <bool REUSE>
-static void launch_bwd(uint32_t nblocks, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
+static void launch_bwd(uint32_t nblocks, uint32_t units_cap, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
 {
     if (v.blend.tile_order) {
         static const int lds_pad = env_int("R3DGS_BWD_LDS_PAD", 0, 0, 65536);
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
-#ifdef R3_SPLIT_EMU
-        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(2 * nblocks), dim3(64), lds_pad, s, dst, v);
-#else
-        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(nblocks), dim3(64), lds_pad, s, dst, v);
-#endif
+        hipLaunchKernelGGL(unit_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
+        // one workgroup per unit the pass MAY have (those beyond its count leave at once)
+        hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(units_cap), dim3(64), lds_pad, s, dst, v);
     } else {
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
     }
@@ -760,9 +933,9 @@ void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs&
     // one wave per tile (PPL = 4): the per-pair gradient slab has exactly one owner per (tile, Gaussian)
     const uint32_t nblocks = (uint32_t)(p.gx * p.gy);   // == v.blend.nblocks
     if (v.blend.quad_masks)
-        launch_bwd<true>(nblocks, dst, v, s);
+        launch_bwd<true>(nblocks, p.units_cap, dst, v, s);
     else
-        launch_bwd<false>(nblocks, dst, v, s);
+        launch_bwd<false>(nblocks, p.units_cap, dst, v, s);
 }
 
 }  // namespace r3

@@ -51,6 +51,16 @@ bool keep_quad_masks()   // R3DGS_KEEP_QUAD_MASKS=0: the backward repeats the fo
     static const bool keep = env_int("R3DGS_KEEP_QUAD_MASKS", 1, 0, 1) != 0;
     return keep;
 }
+int bwd_segment_log2()
+{
+    static const int v = env_int("R3DGS_BWD_SEG_LEN", 128, 128, 256) == 256 ? 8 : 7;
+    return v;
+}
+int bwd_segment_factor_pct()
+{
+    static const int v = env_int("R3DGS_BWD_SEG_FACTOR", 100, 10, 100000);
+    return v;
+}
 int depth_bucket_load()
 {
     static const int load = env_int("R3DGS_DEPTH_BUCKET_LOAD", 128, 32, 2048);   // 64 / 128 / 256 / 512 measured: 0.106 / 0.084 / 0.099 / 0.139 ms
@@ -79,7 +89,7 @@ int tight_rects()
     return v;
 }
 
-// The backward blend starts its tiles heaviest first (blend.hip tile_order_kernel); R3DGS_TILE_ORDER=0 /
+// The backward blend starts its tiles heaviest first (blend.hip unit_order_kernel); R3DGS_TILE_ORDER=0 /
 // r3dgs_set_tile_order(0): row-major bands, one per XCD, as the forward (A/B runs, the bit-identity test).
 std::atomic<int> g_tile_order{-1};
 int heaviest_tiles_first()
@@ -93,6 +103,19 @@ int heaviest_tiles_first()
 }
 
 // Without a sparsity term the backward takes the SH direction derivatives the forward left (GeomState::sh_ddir) instead of
+// Long tile lists are walked by several workgroups of the backward blend, from checkpoints the forward blend leaves
+// (common.h, blend.hip); R3DGS_BWD_SEG=0 / r3dgs_set_bwd_segments(0): one workgroup per tile whatever its list
+// (A/B runs, the bit-identity tests of the launch order).
+std::atomic<int> g_bwd_segments{-1};
+int bwd_segments()
+{
+    int v = g_bwd_segments.load();
+    if (v < 0) {
+        v = env_int("R3DGS_BWD_SEG", 1, 0, 1);
+        g_bwd_segments.store(v);
+    }
+    return v;
+}
 // reading every SH row again; R3DGS_SH_CACHE=0 / r3dgs_set_sh_cache(0): it reads the rows (A/B runs, the bit-identity test).
 std::atomic<int> g_sh_cache{-1};
 int sh_derivative_cache()
@@ -718,6 +741,14 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     a.header.reserve = p.reserve;
     a.header.stamp_sort = p.generic_depth_sort ? 1 : 0;   // no scan kernel behind the header on the generic-sort route
     a.header.sh_cache = a.pre.sh_ddir ? 1u : 0u;
+    // checkpoints for a split backward walk: only a forward that a backward will follow leaves them
+    // (the header is written in the exact-size path's first phase, before the binning blob exists: what it says must not
+    // depend on `b`)
+    const bool leave_ckpt = g_next_forward_trains && bwd_segments() && !p.counters;
+    float4* const ckpt = (b && leave_ckpt) ? b->ckpt : nullptr;
+    a.header.ckpt = leave_ckpt ? (uint32_t)bwd_segment_log2() : 0u;
+    a.header.ckpt_factor_pct = (uint32_t)bwd_segment_factor_pct();
+    a.header.n_tiles = (uint32_t)(p.gx * p.gy);
 
     DepthArgs& d = a.depth;
     d.P = c.P;
@@ -737,6 +768,9 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     d.bucket_id = g.bucket_id;
     d.ovf_key = g.ovf_key;
     d.ovf_id = g.ovf_id;
+    d.rect = g.rect;
+    d.rec16 = g.rec16;
+    d.rect_sorted = g.rect_sorted;
     d.order = g.order;
     d.offsets = g.offsets;
     // only on the asynchronous path does the binning blob exist while the depth sort runs (and only the bucketed sort's
@@ -757,6 +791,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
         e.offsets = g.offsets;
         e.block_first = block_first;
         e.rect = g.rect;
+        e.rect_sorted = p.generic_depth_sort ? nullptr : g.rect_sorted;
         e.rec = g.rec;
         e.rank_bits = l.rank_bits;
         e.digit_bits = l.digit_bits;
@@ -815,6 +850,8 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     f.transmittance = p.counters ? c.out_transmittance : nullptr;
     f.quad_masks = b && keep_quad_masks() ? b->quad_masks : nullptr;
     f.quad_depth = img.quad_depth;
+    f.ckpt = ckpt;
+    f.hdr = g.header;
 }
 
 uint32_t fwd_flags(const FwdPlan& p, const FwdCall& c)
@@ -1265,6 +1302,13 @@ int r3dgs_set_f64_chain(int on)   // on < 0: query only
     return before;
 }
 
+int r3dgs_set_bwd_segments(int on)   // on < 0: query only
+{
+    const int before = bwd_segments();
+    if (on >= 0) g_bwd_segments.store(on ? 1 : 0);
+    return before;
+}
+
 int r3dgs_set_tile_order(int on)   // on < 0: query only
 {
     const int before = heaviest_tiles_first();
@@ -1336,6 +1380,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         plan.reserve = R > 0 ? (uint32_t)R : 1u;
         plan.grid_pairs = grid_pairs_for(plan.reserve);
         plan.has_pairs = binning_buffer != nullptr ? 1 : 0;
+        plan.units_cap = bwd_units_cap(plan.reserve, (size_t)plan.gx * plan.gy);
         plan.f64_chain = f64_chain();
         const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
@@ -1360,8 +1405,13 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         bb.pair_grad = bin.pair_grad;
         bb.pair_flag = bin.pair_flag;
         bb.quad_masks = binning_buffer && keep_quad_masks() ? bin.quad_masks : nullptr;
-        bb.tile_order = heaviest_tiles_first() ? img.tile_order : nullptr;
+        // the unit order lives in the binning blob: a pass without one (no pair was reserved) has nothing to order
+        bb.tile_order = (heaviest_tiles_first() && plan.has_pairs) ? bin.unit_order : nullptr;
+        bb.units_cap = plan.units_cap;
         bb.quad_depth = img.quad_depth;
+        bb.ckpt = plan.has_pairs ? bin.ckpt : nullptr;
+        bb.hdr = geom.header;
+        bb.segments = bwd_segments();
         PairReduceArgs& pr = a.reduce;
         pr.hdr = geom.header;
         pr.pair_grad = bin.pair_grad;
@@ -1530,8 +1580,8 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
     });
 }
 
-int r3dgs_export_tile_order(int width, int height, char* image_buffer, uint32_t* quad_depth, uint32_t* tile_order,
-                            void* stream)
+int r3dgs_export_tile_order(int P, int R, int width, int height, char* binning_buffer, char* image_buffer,
+                            uint32_t* quad_depth, uint32_t* unit_order, void* stream)
 {
     return guarded([&]() {
         using namespace r3;
@@ -1541,10 +1591,21 @@ int r3dgs_export_tile_order(int width, int height, char* image_buffer, uint32_t*
         const size_t Tn = (size_t)gx * gy;
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, Tn);
         if (quad_depth) R3_HIP(hipMemcpyAsync(quad_depth, img.quad_depth, sizeof(uint32_t) * 4 * Tn, hipMemcpyDeviceToDevice, s));
-        if (tile_order) R3_HIP(hipMemcpyAsync(tile_order, img.tile_order, sizeof(uint32_t) * Tn, hipMemcpyDeviceToDevice, s));
+        if (unit_order) {
+            if (!binning_buffer || R <= 0) throw Error("the unit order lives in the binning buffer");
+            BinState bin = BinState::carve(binning_buffer, (size_t)R, pair_layout(P, Tn).wide, Tn);
+            R3_HIP(hipMemcpyAsync(unit_order, bin.unit_order, sizeof(uint32_t) * ((size_t)bwd_units_cap((uint32_t)R, Tn) + 2),
+                                  hipMemcpyDeviceToDevice, s));
+        }
         check_launch("export", s, false);
         return 0;
     });
+}
+
+int r3dgs_bwd_units_cap(int R, int width, int height)
+{
+    const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
+    return (int)r3::bwd_units_cap((uint32_t)(R > 0 ? R : 1), (size_t)gx * gy);
 }
 
 }  // extern "C"

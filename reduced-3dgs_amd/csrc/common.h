@@ -61,7 +61,9 @@ struct GeomHeader {
     uint32_t binned;          // Gaussians that own pairs: the first `binned` entries of the depth order
     uint32_t rendered_ref;    // the reference's num_rendered (reported; nothing on the device uses it)
     uint32_t sh_cache;        // 1: GeomState::sh_ddir holds this pass's SH direction derivatives (dense SH input)
-    uint32_t pad[54];
+    uint32_t ckpt;            // log2 of the segment length the forward blend left checkpoints for (BinState::ckpt); 0: none
+    uint32_t ckpt_thr;        // ... in the tiles whose list has at least this many entries
+    uint32_t pad[52];
 };
 static_assert(sizeof(GeomHeader) == 256, "header = 256 B");
 inline size_t pre_partials(size_t P) { return (P + kPreBlockSize - 1) / kPreBlockSize; }
@@ -144,8 +146,10 @@ struct GeomState {
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
     uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
     uint32_t* tiles;      // [P]  tiles_touched
-    uint32_t* key_sorted; // [P]  keys grouped by depth bucket (bucketed sort) / sorted keys (generic sort)
-    uint32_t* bucket_id;  // [P]  Gaussian ids grouped by depth bucket
+    uint32_t* key_sorted; // [P]  sorted keys (generic sort); bucketed sort: the keys of a bucket too big for the LDS sort
+    uint32_t* bucket_id;  // [P]  ... and its ids (ping-pong partners of ovf_key / ovf_id on that slow path)
+    uint4* rec16;         // [P]  (depth key, id, rect x0 | y0 << 16, x1 | y1 << 16) grouped by depth bucket (depth_sort.h)
+    ushort4* rect_sorted; // [P]  tile rects in depth order, for the pair emission (bucketed sort only)
     uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
     uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
     int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
@@ -178,6 +182,8 @@ struct GeomState {
         g.radii_internal = c.take<int>(P);
         g.ovf_key = c.take<uint32_t>(P);
         g.ovf_id = c.take<uint32_t>(P);
+        g.rec16 = c.take<uint4>(P);
+        g.rect_sorted = c.take<ushort4>(P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         // LAST, so that a blob without it is a valid blob: a forward that will not leave the derivatives (inference /
@@ -235,6 +241,33 @@ inline uint32_t radix_row_stride(size_t R)
     return (uint32_t)(((R + kRadixBlock - 1) / kRadixBlock + 3) & ~(size_t)3);
 }
 
+// ---- list segments of the backward blend (blend.hip) ------------------------------------------------------------------
+// A tile whose list is long is walked by SEVERAL workgroups of the backward blend, each over one segment of the list:
+// a real scene has tiles many times heavier than the mean (a foreground object in front of an empty sky), and a kernel of
+// one wave per tile is then as long as its heaviest tile is slow -- the chip drains for the last third of it
+// (profiles/r05_bwd_timeline_clustered.txt).  A segment that does not start at the list's end needs the per-pixel state
+// there: the forward blend checkpoints (T, accumulated colour) of every pixel each S = 2^GeomHeader::ckpt entries while it
+// walks such a list, and its final colour.  Which lists: those at least GeomHeader::ckpt_thr entries long -- the pass's
+// mean list length times a factor, at least 2 S (the forward only knows the LENGTH of a list, not how deep its pixels will
+// look; a uniform scene then pays nothing).  Slot of checkpoint k >= 1 (state in front of entry k * S; k = 0: the final
+// colour) of tile t whose list starts at pair `first`:  first / S + t + k  -- lists are contiguous and in tile order, so
+// the slots of different tiles are disjoint without a prefix sum (as quad_mask_slot).
+constexpr int kBwdSegMinLog2 = 7;      // smallest segment: 128 entries (two 64-entry chunks); the checkpoint pool is sized for it
+constexpr int kBwdSegMaxLog2 = 8;
+constexpr int kBwdSegMax = 32;         // segments per tile at most: the last one takes whatever is left
+constexpr uint32_t kUnitTileBits = 20; // a unit word of the backward's launch order: tile | segment << 20 | segments << 26
+R3_HD size_t ckpt_slot(uint32_t first, uint32_t k, uint32_t tile, uint32_t seg_log2) { return (size_t)(first >> seg_log2) + tile + k; }
+inline size_t ckpt_slots(size_t R, size_t Tn) { return (R >> kBwdSegMinLog2) + Tn + 2; }
+// workgroups of the backward blend = capacity of its unit order: every tile once, plus the extra segments a pass may have
+// (bounded by the lists: sum over tiles of len / S <= R / S; capped -- a pass that wants more walks longer segments)
+inline uint32_t bwd_units_cap(uint32_t reserve, size_t Tn)
+{
+    const size_t extra = (size_t)reserve >> kBwdSegMinLog2;
+    return (uint32_t)(Tn + (extra < 8 * Tn ? extra : 8 * Tn));
+}
+int bwd_segment_log2();         // R3DGS_BWD_SEG_LEN = 128 (default) | 256 -> 7 | 8; capi.hip
+int bwd_segment_factor_pct();   // R3DGS_BWD_SEG_FACTOR: lists >= this percentage of the pass's mean length are split (100)
+
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile
     float* pair_grad;      // [R * kPairGrad] per-pair gradients in EMISSION order (Gaussian-major), backward only
@@ -253,6 +286,10 @@ struct BinState {
     unsigned long long* quad_masks;  // [R/64 + Tn + 2][4] region pre-test of the forward blend, kept for the backward:
                                      // bit j of [slot][q] = entry j of a 64-entry chunk of a tile's list may reach 8x8
                                      // quadrant q; slot = quad_mask_slot(first pair of the tile, chunk, tile)
+    uint32_t* unit_order;            // [bwd_units_cap + 2] launch order of the backward blend's (tile, segment) units,
+                                     // heaviest first; [cap] = how many there are, [cap + 1] = log2 of the segment length
+                                     // the pass walks (blend.hip unit_order_kernel)
+    float4* ckpt;                    // [ckpt_slots][256] forward checkpoints of the segmented tiles: (T, C0, C1, C2) per pixel
     char* end;
     static BinState carve(char* base, size_t R, int wide, size_t Tn)
     {
@@ -283,6 +320,9 @@ struct BinState {
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
         b.block_first = c.take<uint32_t>(R / kRadixBlock + 2);
+        b.unit_order = c.take<uint32_t>((size_t)bwd_units_cap((uint32_t)R, Tn) + 2);
+        // LAST: only touched for the tiles a pass segments (32 B per pair + 4 KB per tile of address space)
+        b.ckpt = c.take<float4>(ckpt_slots(R, Tn) * 256);
         b.end = c.p;
         return b;
     }
@@ -301,7 +341,8 @@ struct ImageState {
     uint32_t* n_contrib;  // [N]
     uint2* ranges;        // [Tn]
     uint32_t* quad_depth; // [Tn][4] deepest contributor of each 8x8 quadrant (max of n_contrib), left by the forward blend
-    uint32_t* tile_order; // [Tn] tiles, heaviest backward first (blend.hip tile_order_kernel), written by the backward
+    uint32_t* tile_order; // [Tn] unused since the launch order became a list of (tile, segment) units (BinState::unit_order);
+                          // kept so that the image blob keeps its size
     char* end;
     static ImageState carve(char* base, size_t N, size_t Tn)
     {
@@ -463,6 +504,8 @@ struct HeaderArgs {       // binning.hip header_reduce_kernel
     uint32_t reserve;
     uint32_t stamp_sort;  // 1: no depth-scan kernel follows (generic sort): the header stamps PassInfo::sort_seq itself
     uint32_t sh_cache;    // -> GeomHeader::sh_cache
+    uint32_t ckpt;        // -> GeomHeader::ckpt (log2 of the segment length; 0: the forward leaves no checkpoints)
+    uint32_t ckpt_factor_pct, n_tiles;   // GeomHeader::ckpt_thr = max(2 S, factor * num_pairs / n_tiles)
 };
 struct DepthArgs {        // depth_sort.h bucketed depth sort
     int P, nb, rows, per_block;
@@ -480,6 +523,9 @@ struct DepthArgs {        // depth_sort.h bucketed depth sort
     uint32_t* bucket_id;
     uint32_t* ovf_key;
     uint32_t* ovf_id;
+    const ushort4* rect;     // GeomState::rect (by Gaussian id)
+    uint4* rec16;            // GeomState::rec16
+    ushort4* rect_sorted;    // GeomState::rect_sorted (written by the bucket sort)
     uint32_t* order;
     uint32_t* offsets;
     uint32_t* block_first;   // BinState::block_first or nullptr (exact-size path: the binning blob does not exist yet)
@@ -491,7 +537,8 @@ struct EmitArgs {         // binning.hip emit_pairs_kernel
     const uint32_t* order;
     const uint32_t* offsets;
     const uint32_t* block_first;   // as DepthArgs::block_first (nullptr: search the scan)
-    const ushort4* rect;
+    const ushort4* rect;          // by Gaussian id (generic depth sort)
+    const ushort4* rect_sorted;   // in depth order, left by the bucketed depth sort (nullptr: gather rect[id])
     GRec* rec;
     int rank_bits, digit_bits;
     char* words_out;
@@ -539,6 +586,8 @@ struct BlendFwdArgs {     // blend.hip
     float* transmittance;
     unsigned long long* quad_masks;   // BinState::quad_masks (null: not kept)
     uint32_t* quad_depth;             // ImageState::quad_depth
+    float4* ckpt;                     // BinState::ckpt (null: no backward will follow / segments off: nothing is left)
+    const GeomHeader* hdr;            // hdr->ckpt, hdr->ckpt_thr: segment length and which lists get checkpoints
 };
 struct BlendBwdArgs {     // blend.hip
     const uint2* ranges;
@@ -553,9 +602,13 @@ struct BlendBwdArgs {     // blend.hip
     float* pair_grad;  // [R][kPairGrad]: mx, my, cA, cB, cC, op, r, g, b per (tile, Gaussian) pair, emission order
     unsigned char* pair_flag;  // [R] set for rows written in this pass
     const unsigned long long* quad_masks;   // BinState::quad_masks as the forward left them (null: recompute)
-    uint32_t* tile_order;                   // ImageState::tile_order: launch order of the tiles, heaviest first
-                                            // (null: row-major bands, one per XCD)
+    uint32_t* tile_order;                   // BinState::unit_order: launch order of the (tile, segment) units, heaviest
+                                            // first (null: one workgroup per tile, row-major bands, one per XCD)
+    uint32_t units_cap;                     // entries of tile_order (= workgroups launched); [units_cap] = units of this pass
     const uint32_t* quad_depth;             // ImageState::quad_depth, what the order is built from
+    const float4* ckpt;                     // BinState::ckpt
+    const GeomHeader* hdr;                  // hdr->ckpt / ckpt_thr: what the forward checkpointed (0: every tile is one unit)
+    int segments;                           // 0: never split a list (r3dgs_set_bwd_segments(0))
 };
 struct PairReduceArgs {   // preprocess_bwd.hip
     const GeomHeader* hdr;
@@ -622,6 +675,7 @@ struct FwdPlan {
 struct BwdPlan {
     int P, M, W, H, gx, gy;
     uint32_t reserve, grid_pairs;
+    uint32_t units_cap;    // workgroups of the backward blend when it runs in unit order (bwd_units_cap)
     PairLayout layout;
     int bwd_ppl;
     int has_pairs;         // 0: the forward ran with an empty reservation (P > 0, no binning blob)

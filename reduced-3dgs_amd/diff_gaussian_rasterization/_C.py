@@ -73,7 +73,12 @@ _lib.r3dgs_set_f64_chain.argtypes = [_i]
 _lib.r3dgs_set_tile_order.restype = _i
 _lib.r3dgs_set_tile_order.argtypes = [_i]
 _lib.r3dgs_export_tile_order.restype = _i
-_lib.r3dgs_export_tile_order.argtypes = [_i, _i, _vp, _vp, _vp, _vp]
+_lib.r3dgs_export_tile_order.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
+if hasattr(_lib, "r3dgs_bwd_units_cap"):   # (absent from an older A/B build loaded through R3DGS_LIB)
+    _lib.r3dgs_bwd_units_cap.restype = _i
+    _lib.r3dgs_bwd_units_cap.argtypes = [_i, _i, _i]
+    _lib.r3dgs_set_bwd_segments.restype = _i
+    _lib.r3dgs_set_bwd_segments.argtypes = [_i]
 _lib.r3dgs_export_rects.restype = _i
 _lib.r3dgs_export_rects.argtypes = [_i, _vp, _vp, _vp]
 _lib.r3dgs_reserve_overflow_events.restype = C.c_longlong
@@ -733,15 +738,41 @@ def tile_order():
     return bool(_lib.r3dgs_set_tile_order(-1))
 
 
-def export_tile_order(H, W, imageBuffer):
+def set_bwd_segments(on):
+    """True (default): the backward blend walks a long tile list (>= 768 entries) in segments of 256, several workgroups per
+    tile, from checkpoints the forward leaves; False: one workgroup per tile.  Gradients agree to rounding (the state at a
+    segment's end is the forward's running product instead of the backward's own division chain).  A forward issued while
+    this is off leaves no checkpoints, and its backward never splits.  Returns the previous setting."""
+    return bool(_lib.r3dgs_set_bwd_segments(int(bool(on))))
+
+
+def bwd_segments():
+    return bool(_lib.r3dgs_set_bwd_segments(-1))
+
+
+def export_tile_order(H, W, imageBuffer, P=0, num_rendered=0, binningBuffer=None):
     """Debug accessor (not in the reference): quad_depth int32[tiles, 4] (deepest contributor of each 8x8 quadrant, left by
-    the forward) and tile_order int32[tiles] (the backward blend's launch order; valid after a backward)."""
+    the forward) and -- given the binning buffer, P and num_rendered of the pass -- `units`, the launch order of the last
+    backward over this state (heaviest first): dict(tile, segment, segments) int64 arrays of its (tile, list segment) units."""
     n = ((W + 15) // 16) * ((H + 15) // 16)
     qd = torch.empty((n, 4), dtype=torch.int32, device=imageBuffer.device)
-    order = torch.empty((n,), dtype=torch.int32, device=imageBuffer.device)
+    out = dict(quad_depth=qd)
+    order, R = None, 0
+    if binningBuffer is not None and binningBuffer.numel():
+        R = (num_rendered.capacity if isinstance(num_rendered, NumRendered) else
+             _lib.r3dgs_binning_capacity(int(P), W, H, int(binningBuffer.numel())))
+        cap = int(_lib.r3dgs_bwd_units_cap(R, W, H))
+        order = torch.empty((cap + 1,), dtype=torch.int32, device=imageBuffer.device)
     with _on_device(imageBuffer.device):
-        _check(_lib.r3dgs_export_tile_order(W, H, _ptr(imageBuffer), _ptr(qd), _ptr(order), _stream()), "export_tile_order")
-    return dict(quad_depth=qd, tile_order=order)
+        _check(_lib.r3dgs_export_tile_order(int(P), int(R), W, H, _ptr(binningBuffer) if order is not None else None,
+                                            _ptr(imageBuffer), _ptr(qd), _ptr(order) if order is not None else None,
+                                            _stream()), "export_tile_order")
+    if order is not None:
+        o = order.cpu().numpy().astype("int64") & 0xFFFFFFFF
+        cnt = int(o[-1])
+        u = o[:cnt]
+        out["units"] = dict(tile=u & 0xFFFFF, segment=(u >> 20) & 63, segments=u >> 26)
+    return out
 
 
 def rasterize_gaussians_counters(*args):

@@ -215,7 +215,12 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, c
         in_chain = name in CHAIN
         if chain == "f64":
             if in_chain:
-                grads_close(name + tag, r32, got, max(rel, CHAIN_F64_VS_FP32_ORACLE_REL), per_element=False)
+                # triangle inequality: within 1e-4 of the exact value, the HIP result can be no further from the fp32
+                # restatement than that restatement is from the exact value, plus 1e-4 (a scene of large anisotropic splats
+                # -- the clustered workload -- has the fp32 chain 5e-4 off)
+                off32 = float(np.abs(r64 - r32).max() / (np.abs(r64).max() + 1e-30))
+                grads_close(name + tag, r32, got, max(rel, CHAIN_F64_VS_FP32_ORACLE_REL, 1.1 * off32 + GRAD_REL),
+                            per_element=False)
             else:
                 grads_close(name + tag, r32, got, rel, per_element)
             grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
@@ -347,27 +352,114 @@ def test_backward_tile_order_changes_no_bit(C_, kw):
     dl = ss.upstream_grad(W, H, seed=5) * (W * H)
     assert C_.tile_order()
     fargs, fout = hip_forward(C_, bg, g, cam, H, W)
-    heavy_first = hip_backward(C_, fargs, fout, dl, 0.05)
-    st = C_.export_tile_order(H, W, fout[5])
+    # whole tiles: a pass that walks long lists in segments (test_backward_list_segments) rounds differently by design
+    was_seg = C_.set_bwd_segments(False)
+    try:
+        heavy_first = hip_backward(C_, fargs, fout, dl, 0.05)
+        st = C_.export_tile_order(H, W, fout[5], P, fout[0], fout[4])
+        was = C_.set_tile_order(False)
+        try:
+            row_major = hip_backward(C_, fargs, fout, dl, 0.05)
+        finally:
+            C_.set_tile_order(was)
+    finally:
+        C_.set_bwd_segments(was_seg)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    order = st["tile_order"].cpu().numpy().astype(np.int64)
-    assert np.array_equal(np.sort(order), np.arange(gx * gy))                      # a permutation of the tiles
     ex = C_.export_binning(P, fout[0], H, W, fout[3], fout[4], fout[5])
     nc = np.zeros((gy * 16, gx * 16), np.int64)
     nc[:H, :W] = ex["n_contrib"].cpu().numpy().reshape(H, W)
     want = nc.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5)).transpose(0, 2, 1, 3).reshape(gx * gy, 4)
     assert np.array_equal(st["quad_depth"].cpu().numpy().astype(np.int64), want)
+    units = st["units"]
+    # one unit per tile that anything contributed to (tiles nothing reached are left out): a permutation of those tiles
+    assert np.all(units["segments"] == 1) and np.all(units["segment"] == 0)
+    order = units["tile"]
+    assert np.array_equal(np.sort(order), np.nonzero(want.sum(axis=1) > 0)[0])
     weight = want.sum(axis=1)[order]
     klass = (weight.astype(np.float64) * 1023.0 / max(int(weight.max()), 1)).astype(np.int64)   # the kernel's 1024 classes
     assert np.all(np.diff(klass) <= 1), "heavier classes must come first (one class of slack for the fp32 product)"
     assert weight[0] == weight.max()
-    was = C_.set_tile_order(False)
-    try:
-        row_major = hip_backward(C_, fargs, fout, dl, 0.05)
-    finally:
-        C_.set_tile_order(was)
     for a, b in zip(heavy_first, row_major):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["long_lists_small", "clustered_500k_1600x1062"])
+def test_backward_list_segments(C_, name):
+    """A tile whose list is long and deep is walked by several workgroups of the backward blend, each over one segment of the
+    list, from the per-pixel state the forward checkpointed there (blend.hip, common.h).  (1) The units of the launch order:
+    every tile that anything contributed to appears once per segment, segments 0 .. n - 1; lists of at least
+    max(256, mean list length of the pass) entries are split into n = ceil(deepest contributor / S) segments (32 at most),
+    S = 128, or 256 / 512 / 1024 if the launch has not enough workgroups for the units of the shorter one; weights in
+    decreasing class order.  (2) Gradients: within 2e-5 of each tensor's maximum of the unsplit walk's (the state at a
+    segment's end is the forward's running product and a colour difference instead of the backward's own division chain
+    -- rounding, nothing else; both are held to the oracle at 1e-4 by test_full_size_elementwise_vs_oracle), and
+    bit-identical between two split passes (no atomics: one owner per slab row).  (3) With segments off, heaviest-first ==
+    row-major bit for bit, whatever the lists."""
+    if name == "long_lists_small":
+        W, H, P = 256, 192, 120_000
+        cam = ss.make_camera(W, H, 220.0, 3)
+        g = ss.make_gaussians(P, cam, seed=12, degree_mode="mixed", scale_mu=0.03, zmin=2.0, zmax=6.0)
+        g["opacity"] -= 2.5    # weak entries: the pixels stay live deep into the lists
+    else:
+        w, cam, g = ss.make_workload(name)
+        W, H, P = w["W"], w["H"], w["P"]
+    bg = np.array([0.2, 0.3, 0.1], np.float32)
+    dl = ss.upstream_grad(W, H, seed=7) * (W * H)
+    assert C_.bwd_segments() and C_.tile_order()
+    fargs, fout = hip_forward(C_, bg, g, cam, H, W)
+    split = hip_backward(C_, fargs, fout, dl, 0.0)
+    st = C_.export_tile_order(H, W, fout[5], P, fout[0], fout[4])
+    u, qd = st["units"], st["quad_depth"].cpu().numpy().astype(np.int64)
+    ex = C_.export_binning(P, fout[0], H, W, fout[3], fout[4], fout[5])
+    rng_ = ex["ranges"].cpu().numpy().astype(np.int64)
+    length, deepest = rng_[:, 1] - rng_[:, 0], qd.max(axis=1)
+    thr = max(256, int(fout[0].pairs) * 100 // len(length) // 100)
+    cap = len(length) + min(int(fout[0].pairs) >> 7, 8 * len(length))
+    assert cap <= int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H))
+    for walk in (128, 256, 512, 1024):   # the shortest segments whose units fit the launch
+        n_want = np.where((length >= thr) & (deepest > walk), np.minimum((deepest + walk - 1) // walk, 32), 1)
+        n_want[qd.sum(axis=1) == 0] = 0
+        if n_want.sum() <= cap:
+            break
+    else:
+        raise AssertionError("no segment length fits the launch")
+    assert n_want.max() > 1, "the scene must have lists that are split"
+    assert len(u["tile"]) == n_want.sum()
+    key = np.sort(u["tile"] * 64 + u["segment"])
+    assert np.array_equal(key, np.concatenate([t * 64 + np.arange(n) for t, n in enumerate(n_want) if n]))
+    assert np.array_equal(u["segments"], n_want[u["tile"]])
+    lo = u["segment"] * walk
+    hi = np.where(u["segment"] + 1 < u["segments"], lo + walk, 1 << 40)
+    weight = (np.clip(qd[u["tile"]], lo[:, None], hi[:, None]) - lo[:, None]).sum(axis=1)
+    weight[u["segments"] == 1] = qd[u["tile"]].sum(axis=1)[u["segments"] == 1]
+    klass = (weight.astype(np.float64) * 1023.0 / max(int(weight.max()), 1)).astype(np.int64)
+    assert np.all(np.diff(klass) <= 1) and weight[0] == weight.max()
+    print(f"\n  {name}: {int((n_want > 0).sum())} tiles in {len(key)} units of up to {walk} entries (lists >= {thr}); deepest contributor {int(deepest.max())}, "
+          f"heaviest unit / mean unit {weight.max() / weight.mean():.2f} (per tile: {qd.sum(axis=1).max() / qd.sum(axis=1)[n_want > 0].mean():.2f})")
+    again = hip_backward(C_, fargs, fout, dl, 0.0)
+    for a, b in zip(split, again):
+        assert torch.equal(a, b)
+    was = C_.set_bwd_segments(False)
+    try:
+        whole = hip_backward(C_, fargs, fout, dl, 0.0)
+        st1 = C_.export_tile_order(H, W, fout[5], P, fout[0], fout[4])
+        assert np.all(st1["units"]["segments"] == 1) and len(st1["units"]["tile"]) == int((n_want > 0).sum())
+        was_order = C_.set_tile_order(False)
+        try:
+            row_major = hip_backward(C_, fargs, fout, dl, 0.0)
+        finally:
+            C_.set_tile_order(was_order)
+    finally:
+        C_.set_bwd_segments(was)
+    for a, b in zip(whole, row_major):
+        assert torch.equal(a, b)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    for n, a, b in zip(names, split, whole):
+        scale = float(b.abs().max()) + 1e-30
+        err = float((a - b).abs().max()) / scale
+        _note(f"[segments vs whole lists] {n}", err, 0.0)
+        assert err <= 2e-5, f"{n}: split walk differs from the unsplit one by {err:.2e} of the maximum"
+    assert not torch.equal(split[3], whole[3])   # (and the split really ran)
 
 
 @pytest.mark.parametrize("kw", [
@@ -396,10 +488,17 @@ def test_sh_direction_derivatives_from_the_forward_change_no_bit(C_, kw):
     assert float(from_forward[3].abs().max()) > 0 and float(from_forward[5].abs().max()) > 0   # means3D, sh: not all zero
     # a forward issued as a rendering (under no_grad: r3dgs_forward_hint(0)) leaves no derivatives and says so in its
     # header: a backward on its state must notice and read the rows
+    # (such a forward leaves no list checkpoints either: its backward walks every list whole -- the bits of a backward over
+    # the training forward's state with the segments off)
     with torch.no_grad():
         fargs_r, fout_r = hip_forward(C_, bg, g, cam, H, W)
     assert torch.equal(fout_r[1], fout[1])
-    for a, b in zip(from_forward, hip_backward(C_, fargs_r, fout_r, dl, 0.0)):
+    was_seg = C_.set_bwd_segments(False)
+    try:
+        whole_lists = hip_backward(C_, fargs, fout, dl, 0.0)
+    finally:
+        C_.set_bwd_segments(was_seg)
+    for a, b in zip(whole_lists, hip_backward(C_, fargs_r, fout_r, dl, 0.0)):
         assert torch.equal(a, b)
 
 

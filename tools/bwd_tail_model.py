@@ -2,7 +2,7 @@
 
 A processor-sharing model of blend_bwd_kernel's schedule, fed the real per-tile weights of the benchmark shape:
   * a tile's work = the sum over its four 8x8 quadrants of the deepest contributor (ImageState::quad_depth -- the weight
-    tile_order_kernel sorts by; computed here with the CPU oracle: max of n_contrib per quadrant);
+    unit_order_kernel sorts by; computed here with the CPU oracle: max of n_contrib per quadrant);
   * 1024 SIMDs, `slots` single-wave workgroups resident per SIMD (6 at 80 VGPRs), dispatched in launch order into free slots;
   * the waves of a SIMD share its issue capacity equally, but ONE wave cannot use more than `rmax` of it (a wave issues a
     dependent instruction every ~5 cycles against a pipe that takes one every 2.4-4: profiles/r03_valu_rate.txt).

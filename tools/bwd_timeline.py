@@ -30,10 +30,13 @@ for rep in range(6):   # warm clocks, then keep the last pass's table
     _C.rasterize_gaussians_backward(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9], args[10],
                                     args[11], dl, args[14], args[15], args[16], geom, R, binning, img, 0.0, False)
 torch.cuda.synchronize()
-n = ((W + 15) // 16) * ((H + 15) // 16) * (4 if FWD else 1)
+# forward: one workgroup per 8x8 quadrant; backward: one per (tile, list segment) unit, launched for the most a pass may have
+n = ((W + 15) // 16) * ((H + 15) // 16) * 4 if FWD else min(65536, int(_C._lib.r3dgs_bwd_units_cap(R.capacity, W, H)))
 tab = np.zeros((n, 4), np.uint64)
 rc = _C._lib.r3dgs_debug_timeline(tab.ctypes.data_as(C.c_void_p), C.c_int(n))
 assert rc == 0, rc
+tab = tab[tab[:, 1] > 0]   # workgroups beyond the pass's unit count (and tiles nothing contributed to) leave no record
+n = len(tab)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.save(os.path.join(ROOT, "gpurun_out", "fwd_timeline.npy" if FWD else "bwd_timeline.npy"), tab)
 t0, t1, hw, lmax = (tab[:, k].astype(np.int64) for k in range(4))

@@ -17,7 +17,7 @@ for step in "${LIST[@]}"; do
       ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)" >> $S ;;
     tests)
       if [ -n "${F[1]:-}" ]; then K=(-k "${F[1]}"); else K=(); fi
-      ( timeout ${T_TEST:-600} python -m pytest tests -m gpu -x -q -s "${K[@]}" ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/pytest_gpu.log)" >> $S ;;
+      ( timeout ${T_TEST:-600} python -m pytest tests -m gpu ${T_X--x} -q -s "${K[@]}" ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/pytest_gpu.log)" >> $S ;;
     bench)
       tag=${F[1]:-default}; envs=$(echo "${F[2]:-}" | tr ',' ' '); extra=$(echo "${F[3]:-}" | tr ',' ' ')
       ( env $envs timeout ${T_BENCH:-240} python bench.py --steps ${BSTEPS:-20} --warmup 5 ${extra:---no-cpu-baseline} ) > gpurun_out/bench_$tag.log 2>&1
