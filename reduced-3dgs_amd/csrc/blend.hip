@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs* __res
         }
         if (segmented) {
             const uint32_t rel = base - range.x;
-            if (rel != 0u && (rel & ((1u << seg_log2) - 1u)) == 0u && (rel >> seg_log2) < (uint32_t)kBwdSegMax) {
+            if (rel != 0u && (rel & ((1u << seg_log2) - 1u)) == 0u && (rel >> seg_log2) < (uint32_t)kFwdCkptMax) {
                 auto* dst = global_ptr(a.ckpt) + ckpt_slot(range.x, rel >> seg_log2, tile, seg_log2) * 256;
 #pragma unroll
                 for (int q = 0; q < PPL; q++)   // a pixel that is done by now is never looked up here
@@ -816,27 +816,27 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         const uint32_t f = min(min(d.x, d.y), min(d.z, d.w)) >> walk;
         return min(f, n == (uint32_t)kBwdSegMax ? n - 1u : n);   // (a capped tile's last segment takes the rest: not "full")
     };
-    // pass 1: the heaviest unit
-    uint32_t kmax = 0u;
-    auto heaviest = [&](const uint4& d, uint32_t l) {
-        const uint32_t n = segs(d, l);
-        if (n == 0u) return;
-        kmax = max(kmax, unit_weight(d, 0u, n, walk));
-        if (n > 1u) kmax = max(kmax, unit_weight(d, n - 1u, n, walk));   // (only a capped tile's last segment can be heavier)
-    };
-    if (keep) {
-#pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) heaviest(w[k], len[k]);
+    // The heaviest unit.  A pass that splits knows a bound without looking: a whole tile is shorter than `thr` entries (or it
+    // would be split) and no deeper than its list, a segment weighs at most 4 x its length -- only the last segment of a tile
+    // capped at kBwdSegMax can be heavier, and lands in the heaviest class.  Without segments: one more pass over the tiles.
+    if (walk) {
+        if (tid == 0) s_max[0] = max(4u << walk, 4u * min(thr, 1u << 20));
     } else {
-        for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
-            uint4 d;
-            uint32_t l;
-            load(t, d, l);
-            heaviest(d, l);
+        uint32_t kmax = 0u;
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kOrderKeep; k++) kmax = max(kmax, w[k].x + w[k].y + w[k].z + w[k].w);
+        } else {
+            for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+                uint4 d;
+                uint32_t l;
+                load(t, d, l);
+                kmax = max(kmax, d.x + d.y + d.z + d.w);
+            }
         }
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+        if (lane_id == 0u) atomicMax(&s_max[0], kmax);
     }
-    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
-    if (lane_id == 0u) atomicMax(&s_max[0], kmax);
     __syncthreads();
     const float scale = (float)(kOrderClasses - 1) / (float)max(s_max[0], 1u);
     // class 0 = the heaviest
@@ -853,22 +853,37 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         *total = (uint32_t)__shfl((int)incl, 63);
         return incl - x;
     };
-    auto count = [&](const uint4& d, uint32_t l) {   // (called by every lane of a wave at the same step)
-        const uint32_t n = segs(d, l), f = full_segments(d, n);
+    // (the kernel runs on ONE compute unit and is bound by its vector-instruction issue -- 2700 instructions per wave, 16
+    // waves, integer min / max at half rate: 19 us -- so nothing is worked out twice: segment counts and the classes of a
+    // tile's first three partial segments wait in registers for the placement pass)
+    constexpr uint32_t kCached = 3u;
+    auto count = [&](const uint4& d, uint32_t n, uint32_t f, uint32_t* classes) {   // (every lane of a wave at the same step)
         uint32_t total;
         wave_prefix(f, &total);
         if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
-        for (uint32_t k = f; k < n; k++) atomicAdd(&s_count[klass(unit_weight(d, k, n, walk))], 1u);
+        uint32_t packed = 0u;
+        for (uint32_t k = f; k < n; k++) {
+            const uint32_t c = klass(unit_weight(d, k, n, walk));
+            atomicAdd(&s_count[c], 1u);
+            if (k - f < kCached) packed |= c << (10u * (k - f));
+        }
+        *classes = packed;
     };
+    uint32_t nf[kOrderKeep], pc[kOrderKeep];   // segments | full segments << 8, and the cached classes, of the kept tiles
     if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) count(w[k], len[k]);
+        for (int k = 0; k < kOrderKeep; k++) {
+            const uint32_t n = segs(w[k], len[k]), f = full_segments(w[k], n);
+            nf[k] = n | (f << 8);
+            count(w[k], n, f, &pc[k]);
+        }
     } else {
         for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {   // uniform trip count: the wave scan needs every lane
             uint4 d;
-            uint32_t l;
+            uint32_t l, unused;
             load(t0 + tid, d, l);
-            count(d, l);
+            const uint32_t n = segs(d, l);
+            count(d, n, full_segments(d, n), &unused);
         }
     }
     __syncthreads();
@@ -890,8 +905,7 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         order[cap + 1u] = walk;       // log2 of the segment length they walk (0: whole tiles)
     }
     __syncthreads();
-    auto place = [&](uint32_t t, const uint4& d, uint32_t l) {
-        const uint32_t n = segs(d, l), f = full_segments(d, n);
+    auto place = [&](uint32_t t, const uint4& d, uint32_t n, uint32_t f, uint32_t classes, bool cached) {
         uint32_t total;
         const uint32_t ahead = wave_prefix(f, &total);
         uint32_t base = 0u;
@@ -899,18 +913,22 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         base = (uint32_t)__shfl((int)base, 0) + ahead;
         const uint32_t word = t | (n << (kUnitTileBits + 6u));
         for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
-        for (uint32_t k = f; k < n; k++)
-            order[atomicAdd(&s_count[klass(unit_weight(d, k, n, walk))], 1u)] = word | (k << kUnitTileBits);
+        for (uint32_t k = f; k < n; k++) {
+            const uint32_t c = (cached && k - f < kCached) ? (classes >> (10u * (k - f))) & 1023u
+                                                           : klass(unit_weight(d, k, n, walk));
+            order[atomicAdd(&s_count[c], 1u)] = word | (k << kUnitTileBits);
+        }
     };
     if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) place(tid + (uint32_t)(k * kOrderThreads), w[k], len[k]);
+        for (int k = 0; k < kOrderKeep; k++) place(tid + (uint32_t)(k * kOrderThreads), w[k], nf[k] & 255u, nf[k] >> 8, pc[k], true);
     } else {
         for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
             uint4 d;
             uint32_t l;
             load(t0 + tid, d, l);
-            place(t0 + tid, d, l);
+            const uint32_t n = segs(d, l);
+            place(t0 + tid, d, n, full_segments(d, n), 0u, false);
         }
     }
 }

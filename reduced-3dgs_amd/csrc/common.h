@@ -255,6 +255,7 @@ inline uint32_t radix_row_stride(size_t R)
 constexpr int kBwdSegMinLog2 = 7;      // smallest segment: 128 entries (two 64-entry chunks); the checkpoint pool is sized for it
 constexpr int kBwdSegMaxLog2 = 8;
 constexpr int kBwdSegMax = 32;         // segments per tile at most: the last one takes whatever is left
+constexpr int kFwdCkptMax = 256;       // checkpoints per tile at most (a pass may walk segments of up to 8 S: 31 x 8 < 256)
 constexpr uint32_t kUnitTileBits = 20; // a unit word of the backward's launch order: tile | segment << 20 | segments << 26
 R3_HD size_t ckpt_slot(uint32_t first, uint32_t k, uint32_t tile, uint32_t seg_log2) { return (size_t)(first >> seg_log2) + tile + k; }
 inline size_t ckpt_slots(size_t R, size_t Tn) { return (R >> kBwdSegMinLog2) + Tn + 2; }

@@ -432,8 +432,11 @@ def test_backward_list_segments(C_, name):
     hi = np.where(u["segment"] + 1 < u["segments"], lo + walk, 1 << 40)
     weight = (np.clip(qd[u["tile"]], lo[:, None], hi[:, None]) - lo[:, None]).sum(axis=1)
     weight[u["segments"] == 1] = qd[u["tile"]].sum(axis=1)[u["segments"] == 1]
-    klass = (weight.astype(np.float64) * 1023.0 / max(int(weight.max()), 1)).astype(np.int64)
-    assert np.all(np.diff(klass) <= 1) and weight[0] == weight.max()
+    # the kernel's 1024 classes: of a bound of the heaviest unit a splitting pass knows without looking (a segment weighs at
+    # most 4 x its length, an unsplit tile is shorter than thr entries); the last segment of a capped tile may exceed it
+    bound = max(4 * walk, 4 * thr)
+    klass = np.minimum((weight.astype(np.float64) * 1023.0 / bound).astype(np.int64), 1023)
+    assert np.all(np.diff(klass) <= 1) and klass[0] == klass.max()
     print(f"\n  {name}: {int((n_want > 0).sum())} tiles in {len(key)} units of up to {walk} entries (lists >= {thr}); deepest contributor {int(deepest.max())}, "
           f"heaviest unit / mean unit {weight.max() / weight.mean():.2f} (per tile: {qd.sum(axis=1).max() / qd.sum(axis=1)[n_want > 0].mean():.2f})")
     again = hip_backward(C_, fargs, fout, dl, 0.0)
