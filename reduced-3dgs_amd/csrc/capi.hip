@@ -58,7 +58,7 @@ int bwd_segment_log2()
 }
 int bwd_segment_factor_pct()
 {
-    static const int v = env_int("R3DGS_BWD_SEG_FACTOR", 100, 10, 100000);
+    static const int v = env_int("R3DGS_BWD_SEG_FACTOR", 75, 10, 100000);
     return v;
 }
 int depth_bucket_load()

@@ -112,10 +112,15 @@ inline int depth_bucket_count(size_t P)
     return nb;
 }
 struct DepthSortScratch {
-    uint32_t depth_max, depth_inv_min, pad_[2];      // depth range of the visible Gaussians
+    uint32_t depth_max, depth_inv_min;               // depth range of the visible Gaussians
+    uint32_t big_count, big_cursor;                  // buckets above one wave's capacity (big_list): dealt out over all the
+                                                     // workgroups of the bucket-sort kernel (a real scene piles its foreground
+                                                     // into a few hundred neighbouring buckets; cleared by the histogram
+                                                     // kernel, filled by the column scan; the cursor is unused)
     unsigned long long total[kMaxDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [nb] = culled
     uint32_t start[kMaxDepthBuckets + 2];            // exclusive scan of the bucket sizes
     uint32_t tile_base[kMaxDepthBuckets + 2];        // exclusive scan of the buckets' tiles_touched sums
+    uint32_t big_list[kMaxDepthBuckets];             // the buckets above one wave's capacity, in no particular order
 };
 inline size_t depth_hist_rows(size_t P) { const size_t per = depth_hist_per_block(P); return (P + per - 1) / per; }
 
@@ -267,7 +272,7 @@ inline uint32_t bwd_units_cap(uint32_t reserve, size_t Tn)
     return (uint32_t)(Tn + (extra < 8 * Tn ? extra : 8 * Tn));
 }
 int bwd_segment_log2();         // R3DGS_BWD_SEG_LEN = 128 (default) | 256 -> 7 | 8; capi.hip
-int bwd_segment_factor_pct();   // R3DGS_BWD_SEG_FACTOR: lists >= this percentage of the pass's mean length are split (100)
+int bwd_segment_factor_pct();   // R3DGS_BWD_SEG_FACTOR: lists >= this percentage of the pass's mean length are split (75)
 
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, tile-major, (depth, id) order inside a tile

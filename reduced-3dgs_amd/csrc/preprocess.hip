@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kPreBlock) void depth_sort_color_kernel(const FwdPa
         else if (STEP == 1)
             depth_scatter_role(d, smem, wg);
         else
-            depth_bucket_group_role(d, smem, wg);
+            depth_bucket_group_role(d, smem, wg, n_sort);
     } else {
         const PreArgs a = pa->pre;
         color_role<RAGGED, kPreBlock>(a, smem, c0, c1, wg - n_sort, (int)gridDim.x - n_sort);

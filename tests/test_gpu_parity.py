@@ -413,7 +413,7 @@ def test_backward_list_segments(C_, name):
     ex = C_.export_binning(P, fout[0], H, W, fout[3], fout[4], fout[5])
     rng_ = ex["ranges"].cpu().numpy().astype(np.int64)
     length, deepest = rng_[:, 1] - rng_[:, 0], qd.max(axis=1)
-    thr = max(256, int(fout[0].pairs) * 100 // len(length) // 100)
+    thr = max(256, int(fout[0].pairs) * 75 // len(length) // 100)   # R3DGS_BWD_SEG_FACTOR = 75 % of the mean list length
     cap = len(length) + min(int(fout[0].pairs) >> 7, 8 * len(length))
     assert cap <= int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H))
     for walk in (128, 256, 512, 1024):   # the shortest segments whose units fit the launch
