@@ -857,10 +857,10 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     // waves, integer min / max at half rate: 19 us -- so nothing is worked out twice: segment counts and the classes of a
     // tile's first three partial segments wait in registers for the placement pass)
     constexpr uint32_t kCached = 3u;
-    auto count = [&](const uint4& d, uint32_t n, uint32_t f, uint32_t* classes) {   // (every lane of a wave at the same step)
-        uint32_t total;
-        wave_prefix(f, &total);
-        if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
+    // (a) the partial units of a tile: one LDS atomic each; (b) its full segments: the lanes of a wave add theirs up (one
+    // shuffle scan per pass over the sum of a thread's tiles) and send one atomic.  Measured: loads 5.6 us, counting 5.5, scan
+    // 1.0, placing 6.9 with a scan per tile.
+    auto count_partials = [&](const uint4& d, uint32_t n, uint32_t f, uint32_t* classes) {
         uint32_t packed = 0u;
         for (uint32_t k = f; k < n; k++) {
             const uint32_t c = klass(unit_weight(d, k, n, walk));
@@ -871,19 +871,25 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     };
     uint32_t nf[kOrderKeep], pc[kOrderKeep];   // segments | full segments << 8, and the cached classes, of the kept tiles
     if (keep) {
+        uint32_t fsum = 0u, total;
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
             const uint32_t n = segs(w[k], len[k]), f = full_segments(w[k], n);
             nf[k] = n | (f << 8);
-            count(w[k], n, f, &pc[k]);
+            fsum += f;
+            count_partials(w[k], n, f, &pc[k]);
         }
+        wave_prefix(fsum, &total);
+        if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
     } else {
         for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {   // uniform trip count: the wave scan needs every lane
             uint4 d;
-            uint32_t l, unused;
+            uint32_t l, unused, total;
             load(t0 + tid, d, l);
-            const uint32_t n = segs(d, l);
-            count(d, n, full_segments(d, n), &unused);
+            const uint32_t n = segs(d, l), f = full_segments(d, n);
+            count_partials(d, n, f, &unused);
+            wave_prefix(f, &total);
+            if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
         }
     }
     __syncthreads();
@@ -905,12 +911,7 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         order[cap + 1u] = walk;       // log2 of the segment length they walk (0: whole tiles)
     }
     __syncthreads();
-    auto place = [&](uint32_t t, const uint4& d, uint32_t n, uint32_t f, uint32_t classes, bool cached) {
-        uint32_t total;
-        const uint32_t ahead = wave_prefix(f, &total);
-        uint32_t base = 0u;
-        if (lane_id == 0u && total) base = atomicAdd(&s_count[full_class], total);
-        base = (uint32_t)__shfl((int)base, 0) + ahead;
+    auto place = [&](uint32_t t, const uint4& d, uint32_t n, uint32_t f, uint32_t base, uint32_t classes, bool cached) {
         const uint32_t word = t | (n << (kUnitTileBits + 6u));
         for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
         for (uint32_t k = f; k < n; k++) {
@@ -919,16 +920,30 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
             order[atomicAdd(&s_count[c], 1u)] = word | (k << kUnitTileBits);
         }
     };
+    auto full_base = [&](uint32_t f) {   // where this lane's full segments go: one atomic per wave
+        uint32_t total;
+        const uint32_t ahead = wave_prefix(f, &total);
+        uint32_t base = 0u;
+        if (lane_id == 0u && total) base = atomicAdd(&s_count[full_class], total);
+        return (uint32_t)__shfl((int)base, 0) + ahead;
+    };
     if (keep) {
+        uint32_t fsum = 0u;
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) place(tid + (uint32_t)(k * kOrderThreads), w[k], nf[k] & 255u, nf[k] >> 8, pc[k], true);
+        for (int k = 0; k < kOrderKeep; k++) fsum += nf[k] >> 8;
+        uint32_t base = full_base(fsum);
+#pragma unroll
+        for (int k = 0; k < kOrderKeep; k++) {
+            place(tid + (uint32_t)(k * kOrderThreads), w[k], nf[k] & 255u, nf[k] >> 8, base, pc[k], true);
+            base += nf[k] >> 8;
+        }
     } else {
         for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {
             uint4 d;
             uint32_t l;
             load(t0 + tid, d, l);
-            const uint32_t n = segs(d, l);
-            place(t0 + tid, d, n, full_segments(d, n), 0u, false);
+            const uint32_t n = segs(d, l), f = full_segments(d, n);
+            place(t0 + tid, d, n, f, full_base(f), 0u, false);
         }
     }
 }

@@ -4,7 +4,7 @@
 set -u
 mkdir -p gpurun_out
 : > gpurun_out/other_workloads.jsonl
-for wl in ${WORKLOADS:-cfg0_10k_400 lego_like_300k_800 garden_like_2M_1600x1062 bicycle_like_5M_1600x1062 train_like_6M_1920x1080}; do
+for wl in ${WORKLOADS:-cfg0_10k_400 lego_like_300k_800 garden_like_2M_1600x1062 bicycle_like_5M_1600x1062 train_like_6M_1920x1080 clustered_500k_1600x1062 garden_clustered_2M}; do
   timeout 300 python bench.py --workload $wl --steps ${STEPS:-20} --warmup 5 --cameras 4 --no-cpu-baseline 2> gpurun_out/other_$wl.err | tail -1 >> gpurun_out/other_workloads.jsonl
   echo "$wl rc=$?"
 done

@@ -1,7 +1,8 @@
 """Per-kernel means of the rocprofv3 --pmc passes written by tools/gpu_round.sh (PMC="...;...") into
 gpurun_out/pmc*/..._counter_collection.csv  ->  one JSON {kernel: {counter: mean per launch}}.
 
-    python tools/pmc_summary.py [out.json]        (default: gpurun_out/pmc_summary.json)
+    python tools/pmc_summary.py [out.json [dir-prefix]]   (default: gpurun_out/pmc_summary.json from gpurun_out/pmc*;
+                                                          a prefix such as pmc2M_ takes gpurun_out/pmc2M_*)
 
 Only kernels of this library (r3::*) are kept; template arguments stay in the name, parameter lists are cut.
 Every pass is a separate run of `bench.py --steps 3 --warmup 1`, so the launch counts of the passes agree."""
@@ -32,9 +33,11 @@ def short(name):
 
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_summary.json")
+    prefix = sys.argv[2] if len(sys.argv) > 2 else "pmc"
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc*", "**", "*counter_collection.csv"),
-                                 recursive=True)):
+    dirs = [d for d in glob.glob(os.path.join(ROOT, "gpurun_out", prefix + "*")) if os.path.isdir(d) and
+            (prefix != "pmc" or os.path.basename(d)[3:].isdigit())]   # plain "pmc": pmc0, pmc1 ... only
+    for path in sorted(p_ for d in dirs for p_ in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         per_dispatch = defaultdict(float)   # a counter is reported once per XCD/SE instance: sum them per dispatch
         names = {}
         with open(path) as f:
