@@ -584,6 +584,20 @@ __global__ __launch_bounds__(256) void export_keys_kernel(int R, uint32_t cap, i
     keys[i] = ((uint64_t)IO::tile_at(sorted, cap, (uint32_t)i, rank_bits) << 32) | (uint64_t)depth_key[point_list[i]];
 }
 
+// debug accessor: the first min(count, pairs binned) entries of the point list (the caller has filled `out` with ~0)
+__global__ __launch_bounds__(256) void export_point_list_kernel(int count, const uint32_t* __restrict__ point_list,
+                                                                const GeomHeader* hdr, uint32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count && (uint32_t)i < hdr->num_pairs) out[i] = point_list[i];
+}
+
+void launch_export_point_list(int count, const uint32_t* point_list, const GeomHeader* hdr, uint32_t* out, hipStream_t s)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(export_point_list_kernel, dim3((count + 255) / 256), dim3(256), 0, s, count, point_list, hdr, out);
+}
+
 // which buffer of the blob holds the sorted words (split layout: their keys) after the passes (see the fill of RadixArgs
 // in capi.hip)
 const char* sorted_words(const BinState& b, const PairLayout& l)

@@ -511,7 +511,12 @@ void issue_forward(const FwdPlan& p, FwdPassArgs* d, const FwdPassArgs& args, hi
     }
     if (phases & 2) {
         SideStream* side = nullptr;
+        // (one fork / join event pair per device: two host threads issuing forwards at once would interleave record and
+        // wait of each other's passes, so the issue of a pass that uses the side stream is serialised -- opt-in A/B path)
+        static std::mutex side_issue_mu;
+        std::unique_lock<std::mutex> side_lk(side_issue_mu, std::defer_lock);
         if (p.color_side) {   // the colour stream on a stream of its own, beside the sort and the binning
+            side_lk.lock();
             side = &side_stream();
             R3_HIP(hipEventRecord(side->fork, s));
             R3_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -1567,8 +1572,12 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
             const PairLayout l = pair_layout(P, Tn);
             BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide, Tn);
             if (keys) launch_export_keys(P, count, R, Tn, bin, geom, keys, s);
-            if (point_list)
-                R3_HIP(hipMemcpyAsync(point_list, bin.point_list, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, s));
+            if (point_list) {
+                // entries beyond the pairs the pass binned (a caller holding only the reference's num_rendered may ask for
+                // them: the exact-size blob is carved for that count) are not list entries: ~0, as the keys
+                R3_HIP(hipMemsetAsync(point_list, 0xFF, sizeof(uint32_t) * (size_t)count, s));
+                launch_export_point_list(count, bin.point_list, geom.header, point_list, s);
+            }
         }
         if (ranges) R3_HIP(hipMemcpyAsync(ranges, img.ranges, sizeof(uint2) * Tn, hipMemcpyDeviceToDevice, s));
         if (n_contrib) R3_HIP(hipMemcpyAsync(n_contrib, img.n_contrib, sizeof(uint32_t) * N, hipMemcpyDeviceToDevice, s));

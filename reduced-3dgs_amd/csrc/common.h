@@ -706,6 +706,7 @@ void issue_tile_binning(const FwdPlan& p, const FwdPassArgs* a, hipStream_t s);
 const char* sorted_words(const BinState& b, const PairLayout& l);   // which blob buffer holds the sorted words
 void launch_export_keys(int P, int R, int cap, size_t n_tiles, const BinState& b, const GeomState& g, uint64_t* keys_out,
                         hipStream_t s);
+void launch_export_point_list(int count, const uint32_t* point_list, const GeomHeader* hdr, uint32_t* out, hipStream_t s);
 
 void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s);
 void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s);   // installs the block too

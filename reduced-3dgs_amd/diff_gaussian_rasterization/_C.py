@@ -438,7 +438,11 @@ def _track_view(vm):
 
 def _forget_view(ptr, ident):
     ref = _tracked_views.get(ptr)
-    if ref is not None and ref() is None:
+    if ref is not None and ref() is not None:
+        # a live tensor has registered this address since (a fresh wrapper over the same storage every iteration --
+        # stacked[i], .view() -- dies while its successor is in use): the camera's learnt pair count stays
+        return
+    if ref is not None:
         del _tracked_views[ptr]
     try:
         _lib.r3dgs_reserve_forget_view(ptr)

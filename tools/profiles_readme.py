@@ -1,4 +1,4 @@
-"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r04_*).
+"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r05_*).
 
     python tools/profiles_readme.py
 
@@ -6,14 +6,12 @@ Numbers in that README are therefore exactly the ones in the JSON / CSV / txt fi
 import csv
 import json
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-R = "r04"
-PREV = "r03"   # bracketed numbers; also where the (unchanged) blend-kernel timelines and the VALU calibration live
+R, PREV = "r05", "r04"   # bracketed numbers: the previous round's files
 
 
 def jl(name):
@@ -28,187 +26,200 @@ def kstats(name):
     return ks
 
 
+import bench  # noqa: E402  (traffic and the calibrated VALU floor are computed by bench.py's own functions)
+
 d20 = jl(f"{R}_bench_n1_steps20.json")[0]
 d50 = jl(f"{R}_bench_n1_default.json")[0]
-ab = jl(f"{R}_bench_n1_ab.jsonl")
+ab = {k: v for k, v in zip(("nonstrict", "refrects", "whole_lists", "f32chain"), jl(f"{R}_bench_n1_ab.jsonl"))}
 burn = jl(f"{R}_bench_n1_cpu_burner64.jsonl")
-others = jl(f"{R}_other_workloads.jsonl")
+others = {o["config"]["workload"]: o for o in jl(f"{R}_other_workloads.jsonl")}
 old_others = {o["config"]["workload"]: o for o in jl(f"{PREV}_other_workloads.jsonl")}
+old50 = jl(f"{PREV}_bench_n1_default.json")[0]
 ks = kstats(f"{R}_kernel_stats_bench_500k_1600x1062.csv")
-ks2 = kstats(f"{PREV}_kernel_stats_bench_500k_1600x1062.csv")
-pmc = json.load(open(os.path.join(P, f"{R}_pmc_summary.json")))
+ks_old = kstats(f"{PREV}_kernel_stats_bench_500k_1600x1062.csv")
 st = d50["stages"]
-BWD, FWD = "r3::blend_bwd_kernel<4, true, false>", "r3::blend_fwd_kernel<1, false>"
-
-import bench  # noqa: E402  (the calibrated VALU floor is computed by bench.py's own function)
-vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", st["blend_bwd"]["avg_ms"])
-vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", st["blend_fwd"]["avg_ms"])
-for v_ in (vb, vf):   # this file prices the kernels of the committed kernel trace
-    v_["kernel_ms"] = v_["kernel_ms_committed_profile"]
-    v_["frac"] = round(v_["floor_ms"] / v_["kernel_ms"], 3)
-
-
-CTR_BYTES = sum(bench.pmc_traffic(k_, "metric_500k_1600x1062") for k_ in bench.STAGE_KERNELS)
-
-
-def row(k):
-    v = pmc[k]
-    wc = v["SQ_WAVE_CYCLES"]
-    return (f"| `{k.replace('r3::', '')}` | {v['SQ_INSTS_VALU'] / 1e6:.1f} M | {v['SQ_INSTS_SALU'] / 1e6:.1f} M | "
-            f"{v['SQ_INSTS_LDS'] / 1e6:.1f} M | {100 * v['SQ_ACTIVE_INST_ANY'] / wc:.0f} % | "
-            f"{100 * v['SQ_WAIT_INST_ANY'] / wc:.0f} % | {100 * v['SQ_WAIT_ANY'] / wc:.0f} % | "
-            f"{v['FETCH_SIZE'] / 1024:.0f} MiB | {v['WRITE_SIZE'] / 1024:.0f} MiB |")
+STAGES = ("preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd", "blend_bwd", "preprocess_bwd")
 
 
 def stages_of(d):
-    s = d["stages"]
-    return " / ".join(str(s[k]["avg_ms"]) for k in ("preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd", "blend_bwd",
-                                                     "preprocess_bwd"))
+    return " / ".join(f"{d['stages'][k]['avg_ms']:.3f}" for k in STAGES)
 
 
-valu_lines = [l.rstrip() for l in open(os.path.join(P, f"{PREV}_valu_rate.txt")) if " 8 waves/SIMD" in l]
+def kern(table, prefix):
+    v = bench.find_kernel(table, prefix)
+    return float("nan") if v is None else v
 
 
-def rate(prefix):
-    for l in valu_lines:
-        if l.startswith(prefix):
-            return float(re.search(r"([\d.]+) cyc/inst/SIMD@2.4GHz", l).group(1))
-    return float("nan")
+KERNELS = [("preprocess_geom_kernel<0>", "r3::preprocess_geom_kernel<0>"), ("depth_sort_color<0> (histogram + header + colour)", "r3::depth_sort_color_kernel<0, false>"),
+           ("depth_colscan", "r3::depth_colscan_kernel"), ("depth_sort_color<1> (scatter + colour)", "r3::depth_sort_color_kernel<1, false>"),
+           ("depth_sort_color<2> (bucket sort + scan + colour)", "r3::depth_sort_color_kernel<2, false>"),
+           ("emit_pairs", "r3::emit_pairs_kernel<"), ("radix_digit_scan (x2)", "r3::radix_digit_scan_kernel"),
+           ("radix_scatter (x2)", "r3::radix_scatter_kernel<"), ("radix_hist", "r3::radix_hist_kernel<"),
+           ("tile_ranges", "r3::tile_ranges_kernel<"), ("blend_fwd_kernel<1>", "r3::blend_fwd_kernel<1, false>"),
+           ("unit_order_kernel [tile_order_kernel]", "r3::unit_order_kernel"), ("blend_bwd_kernel<4, true, false>", "r3::blend_bwd_kernel<4, true, false>"),
+           ("pair_reduce", "r3::pair_reduce_kernel"), ("preprocess_bwd_kernel<true, true>", "r3::preprocess_bwd_kernel<")]
+WL = [("metric_500k_1600x1062", "bench_500k_1600x1062", ""), ("clustered_500k_1600x1062", "clustered_500k", "_clustered_500k"),
+      ("garden_like_2M_1600x1062", "garden_like_2M", "_2M"), ("train_like_6M_1920x1080", "train_like_6M", "_6M")]
 
 
-timeline = ""
-tl_path = os.path.join(P, f"{PREV}_bwd_timeline.txt")
-if os.path.exists(tl_path):
-    timeline = "".join(l for l in open(tl_path) if not l.startswith("/opt"))
-fwd_timeline = ""
-if os.path.exists(os.path.join(P, f"{PREV}_fwd_timeline.txt")):
-    fwd_timeline = "".join(l for l in open(os.path.join(P, f"{PREV}_fwd_timeline.txt")) if not l.startswith("/opt"))
+def kernel_table():
+    cols = {w: kstats(f"{R}_kernel_stats_{short}.csv") for w, short, _ in WL}
+    old = {"metric_500k_1600x1062": ks_old, "garden_like_2M_1600x1062": kstats(f"{PREV}_kernel_stats_garden_like_2M.csv"),
+           "train_like_6M_1920x1080": kstats(f"{PREV}_kernel_stats_train_like_6M.csv")}
+    out = ["| kernel (µs, rocprofv3 --kernel-trace --stats; [round 4]) | " + " | ".join(w for w, _, _ in WL) + " |", "|---|" + "---|" * len(WL)]
+    for label, prefix in KERNELS:
+        cells = []
+        for w, _, _ in WL:
+            c = f"{kern(cols[w], prefix):.1f}"
+            if w in old:
+                c += f" [{kern(old[w], prefix):.1f}]"
+            cells.append(c)
+        out.append(f"| `{label}` | " + " | ".join(cells) + " |")
+    return "\n".join(out)
 
-new = f'''# profiles/ — measurements on MI355X (round 4)
 
-All `r04_bench_*`, `r04_kernel_stats_*`, `r04_pmc_summary.json` and `r04_valu_rate_warm.txt` files come from ONE visit of `tools/refresh_profiles.sh` (`tools/collect_profiles.py` copies the results here
-and runs `tools/profiles_readme.py`, which generates this file from them) to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch
-2.10+rocm7.0; 256 visible CPUs, **cgroup CPU quota 16**).  The command profiled is always `python bench.py` (workload
-`metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe, 8 cameras; V̄ =
-{d50['config']['visible_mean'] / 1e3:.0f}k visible, `num_rendered` R̄ = {d50['config']['num_rendered_mean'] / 1e6:.2f} M — the reference's count, which the byte
-formulas are written in — of which {d50['config']['pairs_binned_mean'] / 1e6:.2f} M (tile, Gaussian) pairs are binned (opacity-aware rects), N = 1.70 Mpix).
-These are this build's own visits; **the number of record is the driver's `BENCH_r04.json`**.  `r01_*` … `r03_*` files are
-kept for comparison; the blend kernels did not change this round, so their workgroup timelines and the VALU-rate
-calibration are round 3's (`r03_bwd_timeline*.txt`, `r03_fwd_timeline.txt`, `r03_valu_rate.txt`).
+def traffic_table():
+    out = ["| stage: counter bytes per launch (MB; FETCH_SIZE x2 on the wide-load kernels + WRITE_SIZE), its time in this bench line, GB/s of bytes that moved | " +
+           " | ".join(w for w, _, _ in WL) + " |", "|---|" + "---|" * len(WL)]
+    lines = {"metric_500k_1600x1062": d50, **{w: others[w] for w, _, _ in WL[1:] if w in others}}
+    for s_ in STAGES:
+        cells = []
+        for w, _, _ in WL:
+            d = lines.get(w)
+            if d is None or d["stages"][s_].get("counter_bytes") is None:
+                cells.append("–")
+            else:
+                x = d["stages"][s_]
+                cells.append(f"{x['counter_bytes'] / 1e6:.0f} MB, {x['avg_ms']:.3f} ms, **{x['counter_GBps']:.0f}**")
+        out.append(f"| {s_} | " + " | ".join(cells) + " |")
+    cells = []
+    for w, _, _ in WL:
+        d = lines.get(w)
+        ir = d["iter_roofline"] if d else None
+        cells.append("–" if not ir or ir["frac_counter_traffic"] is None else
+                     f"{ir['counter_traffic_bytes'] / 1e9:.2f} GB/step = **{100 * ir['frac_counter_traffic']:.1f} %** of 8 TB/s moved; "
+                     f"{100 * ir['frac_of_8TBps']:.1f} % in SURVEY §8d's reference-algorithm bytes")
+    out.append("| whole iteration | " + " | ".join(cells) + " |")
+    return "\n".join(out)
+
+
+def others_table():
+    out = ["| workload | it/s [round 4] | ms/step | stages ms: " + " / ".join(STAGES) + " | render FPS |", "|---|---|---|---|---|"]
+    for w, o in others.items():
+        prev = f" [{old_others[w]['value']}]" if w in old_others else ""
+        out.append(f"| {w} (P = {o['config']['gaussians']}, R̄ = {o['config']['num_rendered_mean'] / 1e6:.2f} M, binned "
+                   f"{o['config']['pairs_binned_mean'] / 1e6:.2f} M) | **{o['value']}**{prev} | {o['ms_per_step']} | {stages_of(o)}"
+                   + (f" (+ sh_color {o['stages']['sh_color']['avg_ms']:.3f}: generic depth sort)" if "sh_color" in o["stages"] else "")
+                   + f" | {o['render_fps']} |")
+    return "\n".join(out)
+
+
+def txt(name, skip="/opt"):
+    p_ = os.path.join(P, name)
+    return "".join(l for l in open(p_) if not l.startswith(skip)) if os.path.exists(p_) else "(not collected)\n"
+
+
+vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", st["blend_bwd"]["avg_ms"])
+vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", st["blend_fwd"]["avg_ms"])
+f64 = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if "f64" in l and " 8 waves/SIMD" in l]
+f32 = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if l.startswith("v_fma_f32 ") and " 8 waves/SIMD" in l]
+
+new = f'''# profiles/ — measurements on MI355X (round 5)
+
+Every `{R}_*` file comes from visits of `tools/refresh_profiles.sh` to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch 2.10+rocm7.0;
+256 visible CPUs, **cgroup CPU quota 16**); `tools/collect_profiles.py` copies the results here and runs this generator
+(`tools/profiles_readme.py`), so the numbers below are the ones in the files.  The command profiled is `python bench.py`
+(workload `metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe, 8 cameras; V̄ =
+{d50['config']['visible_mean'] / 1e3:.0f}k visible, `num_rendered` R̄ = {d50['config']['num_rendered_mean'] / 1e6:.2f} M — the reference's count, which the byte formulas are
+written in — of which {d50['config']['pairs_binned_mean'] / 1e6:.2f} M (tile, Gaussian) pairs are binned, N = 1.70 Mpix) unless a workload is named.  These are
+this build's own visits; **the number of record is the driver's `BENCH_r05.json`**.  Boxes differ: one visit of this round measured
+every stage 1.2–1.4× slower than the others (1057 it/s for the same build), so every A/B below is from ONE visit, with the
+previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds are compared.
 
 | file | what |
 |---|---|
-| `{R}_bench_n1_default.json` | the JSON line of `python bench.py` (50 steps, 10 warm-up) |
-| `{R}_bench_n1_steps20.json` | `python bench.py --steps 20 --warmup 5` (the driver's form) |
-| `{R}_bench_n1_ab.jsonl` | the driver's form with `R3DGS_STRICT=0` (no check of the pass's pair count: the round-2 behaviour) and with `R3DGS_TIGHT_RECT=0` (the reference's 3σ squares) |
+| `{R}_bench_n1_default.json`, `{R}_bench_n1_steps20.json` | the JSON line of `python bench.py` (50 steps, 10 warm-up) and of the driver's form (`--steps 20 --warmup 5`) |
+| `{R}_bench_n1_ab.jsonl` | the driver's form with `R3DGS_STRICT=0`, `R3DGS_TIGHT_RECT=0` (the reference's 3σ squares), `R3DGS_BWD_SEG=0` (whole tile lists: no list segments) and `R3DGS_F64_CHAIN=0` (the reference's fp32 covariance chain), in this order |
 | `{R}_bench_n1_cpu_burner64.jsonl` | the driver's form twice while `tools/cpu_burn.py 64` exhausts the container's CPU quota |
-| `{R}_kernel_stats_bench_500k_1600x1062.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` |
-| `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic` and `roofline.valu` |
-| `{PREV}_valu_rate.txt`, `{R}_valu_rate_warm.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 22 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD — the calibration behind `roofline.valu` (the first from a visit that ran nothing else, the second at the end of the refresh visit, on a warm chip: the wall-clock rates are ~10 % lower there, the clock having come down) |
-| `{PREV}_bwd_timeline.txt`, `{PREV}_fwd_timeline.txt` | `tools/bwd_timeline.py [fwd]` (debug builds `-DR3_TIMELINE` / `-DR3_TIMELINE_FWD`): when and where every workgroup of the backward / forward blend ran |
-| `{PREV}_bwd_timeline_row_major.txt` | the same for the backward blend before its tiles were started heaviest first (mid-round build, 5 waves per SIMD) |
-| `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins (10k, 300k, 2 M, 5 M, 6 M @1920×1080) |
-| `{R}_kernel_stats_garden_like_2M.csv`, `{R}_kernel_stats_train_like_6M.csv` | `rocprofv3 --kernel-trace --stats` of the 2 M / 6 M workloads |
-| `{R}_gpu_tests.txt` | `pytest tests -m gpu -s`: every gradient distance measured (HIP vs the fp32 oracle, HIP vs the double evaluation, fp32 oracle vs the double evaluation, with the test each worst case came from), the own-loop report |
-| `{R}_host_bound_bindings.txt` | `tools/host_bound_bench.py`: steps/s of the 10k and 300k workloads through the ctypes marshalling and through the compiled torch binding (strict mode) |
-| `{R}_sweep_6M_depth_sort_colour.txt` | 6 M Gaussians @1920×1080: bucketed depth sort with the colour stream inside (default) against the generic rocPRIM sort + a standalone colour kernel, colour grid sizes, bucket loads, colour splits |
-| `{R}_bwd_tail_model.txt` | `tools/bwd_tail_model.py`: processor-sharing model of the backward blend's schedule on the real tile weights — what splitting tiles along their lists could buy |
+| `{R}_kernel_stats_*.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` on the metric workload, the clustered 500 k scene, 2 M, 6 M @1920×1080 and the clustered 2 M scene |
+| `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic`, `roofline.valu`, `stages.*.counter_bytes` |
+| `{R}_pmc_summary_2M.json`, `_6M.json`, `_clustered_500k.json` | the `FETCH_SIZE` / `WRITE_SIZE` passes of the same command on those workloads (`bench.py --workload …` cites them) |
+| `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins and of the two clustered scenes |
+| `{R}_bwd_timeline.txt`, `{R}_bwd_timeline_clustered.txt`, `{R}_bwd_timeline_clustered_whole_lists.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran — metric scene, clustered scene with list segments (default) and without |
+| `{R}_bwd_tail_model_clustered_500k.txt` | `tools/bwd_tail_model.py clustered_500k_1600x1062`: tile-weight histogram of the clustered scene and the processor-sharing model of its schedule |
+| `{R}_lane_utilisation.txt` | `tools/lane_utilisation.py` (CPU, the kernels' own per-lane functions): useful lanes per evaluated (entry, quadrant) pair of both blend kernels, and what a 4×4-granular pre-test with per-row lists would evaluate |
+| `{R}_valu_rate.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 25 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD, now with `v_fma_f64 / v_mul_f64 / v_add_f64` |
+| `{R}_gpu_tests.txt` | `pytest tests -m gpu -s`: every gradient distance measured (HIP vs the fp32 oracle, HIP vs the double evaluation, fp32 oracle vs the double evaluation, the fp32-chain mode, segments vs whole lists), the own-loop report |
+| `{R}_host_bound_bindings.txt` | `tools/host_bound_bench.py`: steps/s of the 10k and 300k workloads through the ctypes marshalling and the compiled torch binding |
+| `r01_*` … `r04_*` | earlier rounds, kept for comparison |
 
 ## Headline (N = 1)
 
 | | value |
 |---|---|
-| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, **strict**: every forward checks its pair count before returning), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) |
+| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, strict), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) [round 4: {old50['value']}] |
 | the driver's form, 20 steps / 5 warm-up | **{d20['value']} it/s** ({d20['ms_per_step']} ms/step = {d20['host']['step_over_gpu_stage_sum']} × Σ stage ms); passes in the timed region: {d20['config']['passes_in_timed_region']} |
-| same, strict mode off (round-2 behaviour) | {ab[0]['value']} it/s — the check costs nothing measurable: the pass publishes its numbers ~40 µs after it starts and the GPU has the rest of the forward to work on while the host goes on |
-| the method's own configuration, `lambda_sh_sparsity = 0.1` (full_eval.py:33,44; the backward then reads the SH rows) | {d50['value_sh_sparsity']} it/s ({d50['sh_sparsity']['ms_per_step']} ms/step; `preprocess_bwd` {d50['sh_sparsity']['stages_ms']['preprocess_bwd']} ms against {st['preprocess_bwd']['avg_ms']}) |
-| same, reference rects (`R3DGS_TIGHT_RECT=0`) | {ab[1]['value']} it/s, stages {stages_of(ab[1])} ms against {stages_of(d20)} ms |
-| render-only (forward, `render.py`'s FPS path) | **{d50['render_fps']} FPS = {d50['render_mpix_per_s'] / 1000:.2f} Gpix/s** |
-| whole-iteration roofline | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes, SURVEY 8d) → {d50['iter_roofline']['achieved_GBps']} GB/s = **{100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s** (target 40 %); bytes the counters saw move per step (`{R}_pmc_summary.json`, ×2 on the wide-load kernels' FETCH_SIZE): {CTR_BYTES / 1e9:.2f} GB = {100 * CTR_BYTES * d50['value'] / 8e12:.1f} % — that one is HBM utilisation, the first is not |
-| dominant stage | `blend_bwd` {st['blend_bwd']['avg_ms']} ms → `roofline.frac` {d50['roofline']['frac']} (HBM), calibrated VALU issue floor / kernel time {vb['frac']}; `roofline.traffic` {d50['roofline'].get('traffic')} B from the committed counters (the line's own citation is of the summary committed before this visit; `roofline.traffic_collected_on_this_build` says whether the cited counters were collected on the tree's kernel sources) |
-| CPU baseline (SURVEY 8d) | configs[0] PyTorch restatement, {d50['cpu_baseline']['threads_effective']} threads: {d50['cpu_baseline']['value']} it/s; the bench workload by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
-| host under `tools/cpu_burn.py 64` | {burn[0]['value']} / {burn[1]['value']} it/s (throttled periods inside the timed region: {burn[0]['host']['cgroup']['throttled_periods_in_timed_region']} / {burn[1]['host']['cgroup']['throttled_periods_in_timed_region']}) |
-| BASELINE.json target | ≥ 1000 it/s at ≥ 40 % of the HBM roof: the first is met, the second is not (the blend kernels are VALU-bound: see below) |
+| stages ms ({' / '.join(STAGES)}) | {stages_of(d50)} [round 4: {stages_of(old50)}] |
+| same, strict mode off | {ab['nonstrict']['value']} it/s |
+| `lambda_sh_sparsity = 0.1` (full_eval.py:33,44) | {d50['value_sh_sparsity']} it/s ({d50['sh_sparsity']['ms_per_step']} ms/step) |
+| reference rects (`R3DGS_TIGHT_RECT=0`) | {ab['refrects']['value']} it/s, stages {stages_of(ab['refrects'])} |
+| whole tile lists (`R3DGS_BWD_SEG=0`) | {ab['whole_lists']['value']} it/s, `blend_bwd` stage {ab['whole_lists']['stages']['blend_bwd']['avg_ms']} ms against {d20['stages']['blend_bwd']['avg_ms']} |
+| fp32 covariance chain (`R3DGS_F64_CHAIN=0`) | {ab['f32chain']['value']} it/s, `preprocess_bwd` {ab['f32chain']['stages']['preprocess_bwd']['avg_ms']} ms against {d20['stages']['preprocess_bwd']['avg_ms']} |
+| under `cpu_burn 64` | {burn[0]['value']} / {burn[1]['value']} it/s |
+| render only (`render.py`'s FPS path) | {d50['render_fps']} FPS = {d50['render_mpix_per_s']} Mpix/s |
+| dominant kernel against the HBM roof (contract form) | `blend_bwd` stage: {d50['roofline']['achieved']} GB/s of SURVEY §8d bytes = **{d50['roofline']['frac']}** of 8 TB/s; bytes that moved per launch (counters): {d50['roofline']['traffic'] / 1e6:.0f} MB |
+| dominant kernel against the roof that binds it (VALU issue) | `blend_bwd_kernel`: {vb['insts'] / 1e6:.1f} M VALU instructions, floor {vb['floor_ms']} ms / kernel {vb['kernel_ms_committed_profile']} ms = **{vb['floor_ms'] / vb['kernel_ms_committed_profile']:.2f}** [round 4: 0.72]; `blend_fwd_kernel`: floor {vf['floor_ms']} / {vf['kernel_ms_committed_profile']} ms = {vf['floor_ms'] / vf['kernel_ms_committed_profile']:.2f} |
+| whole iteration | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes) → {100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s (target 40 %); bytes the counters saw move: {d50['iter_roofline']['counter_traffic_bytes'] / 1e9:.2f} GB/step = {100 * d50['iter_roofline']['frac_counter_traffic']:.1f} % |
+| CPU baseline (`cpu_baseline`, kind "port") | {d50['cpu_baseline']['value']} it/s on {d50['cpu_baseline']['cores']} threads of a {d50['cpu_baseline'].get('cpu_model')}: {d50['cpu_baseline']['sample'][:110]}…; the bench workload itself by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
 
-## Where the {d50['ms_per_step']} ms go (HIP-event stage timers; kernel times from rocprofv3, round 3 in brackets)
+## Kernels
 
-| stage | avg ms | kernels (rocprofv3 avg µs) | algorithmic bytes (SURVEY 8d) | GB/s vs 8 TB/s |
-|---|---|---|---|---|
-| preprocess_fwd | {st['preprocess_fwd']['avg_ms']} | `preprocess_geom_kernel` {ks['r3::preprocess_geom_kernel<0>']:.1f} [{ks2['r3::preprocess_geom_kernel']:.1f}] (+ the opacity-aware rect) | {st['preprocess_fwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_fwd']['GBps']:.0f} ({st['preprocess_fwd']['GBps'] / 80:.0f} %) |
-| depth_sort_scan (+ SH→RGB) | {st['depth_sort_scan']['avg_ms']} | `depth_sort_color<0>` {ks['r3::depth_sort_color_kernel<0, false>']:.1f}, `depth_colscan` {ks['r3::depth_colscan_kernel']:.1f}, `<1>` {ks['r3::depth_sort_color_kernel<1, false>']:.1f}, `<2>` {ks['r3::depth_sort_color_kernel<2, false>']:.1f} | {st['depth_sort_scan']['alg_bytes'] / 1e6:.0f} MB | {st['depth_sort_scan']['GBps']:.0f} ({st['depth_sort_scan']['GBps'] / 80:.0f} %) |
-| tile_binning | {st['tile_binning']['avg_ms']} | `emit_pairs` {ks['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f} [{ks2['r3::emit_pairs_kernel<r3::IoNarrow>']:.1f}], `radix_digit_scan` 2 × {ks['r3::radix_digit_scan_kernel']:.1f}, `radix_scatter` 2 × {ks['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f} [{ks2['r3::radix_scatter_kernel<r3::IoNarrow, 7>']:.1f}], `radix_hist` {ks['r3::radix_hist_kernel<r3::IoNarrow>']:.1f}, `tile_ranges` {ks['r3::tile_ranges_kernel<r3::IoNarrow>']:.1f} | {st['tile_binning']['alg_bytes'] / 1e6:.0f} MB (reference-algorithm figure) | {st['tile_binning']['GBps']:.0f} — real traffic ≈ 9× lower |
-| blend_fwd | {st['blend_fwd']['avg_ms']} | `blend_fwd_kernel<1>` {ks[FWD]:.1f} [{ks2[FWD]:.1f}] | {st['blend_fwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_fwd']['GBps']:.0f} ({st['blend_fwd']['GBps'] / 80:.0f} %) |
-| blend_bwd | {st['blend_bwd']['avg_ms']} | `blend_bwd_kernel<4, true, false>` {ks[BWD]:.1f} [{ks2[BWD]:.1f}], `pair_reduce` {ks['r3::pair_reduce_kernel']:.1f} [{ks2['r3::pair_reduce_kernel']:.1f}], `tile_order` {ks['r3::tile_order_kernel']:.1f} | {st['blend_bwd']['alg_bytes'] / 1e6:.0f} MB | {st['blend_bwd']['GBps']:.0f} ({st['blend_bwd']['GBps'] / 80:.1f} %) |
-| preprocess_bwd | {st['preprocess_bwd']['avg_ms']} | `preprocess_bwd_kernel<true, true>` (covariance chain in double) {ks['r3::preprocess_bwd_kernel<true, true>']:.1f} [{ks2['r3::preprocess_bwd_kernel<true>']:.1f}] | {st['preprocess_bwd']['alg_bytes'] / 1e6:.1f} MB | {st['preprocess_bwd']['GBps']:.0f} ({st['preprocess_bwd']['GBps'] / 80:.0f} %) |
+{kernel_table()}
 
-## What the VALU costs on this chip (`{PREV}_valu_rate.txt`) and what that says about the blend kernels
+## HBM traffic from the counters, per stage and workload
 
-Cycles per wave64 instruction and SIMD at 8 waves per SIMD, from the wall-clock rate at 2.4 GHz: `v_add_f32` {rate('v_add_f32 ')},
-`v_mul_f32` {rate('v_mul_f32')}, `v_mov_b32` {rate('v_mov_b32')}, `v_fmac_f32` {rate('v_fmac_f32')}, `v_fma_f32` {rate('v_fma_f32  ')} — with one SGPR source
-{rate('v_fma_f32 with one SGPR')}; `v_min_f32` {rate('v_min_f32')}, `v_cmp + v_cndmask` {rate('v_cmp_gt_f32')} per pair, `v_cndmask_b32_e64` {rate('v_cndmask_b32_e64')},
-`v_add_f32_dpp` {rate('v_add_f32_dpp')}, `v_mad_u32_u24` {rate('v_mad_u32_u24')}; `v_exp_f32` {rate('v_exp_f32')}, `v_rcp_f32` {rate('v_rcp_f32')};
-`v_pk_fma_f32` {rate('v_pk_fma_f32')} and `v_pk_mul_f32` {rate('v_pk_mul_f32')} (for TWO lane-operations each: a gain only for FMAs);
-`ds_read_b128` of one address {rate('ds_read_b128')}, `ds_read_b32` {rate('ds_read_b32')}, `ds_bpermute_b32` {rate('ds_bpermute_b32')}, `v_readlane_b32` {rate('v_readlane_b32')}.
-A lone wave issues one dependent-free VALU instruction per ~5 cycles; two waves reach the rates above.
+{traffic_table()}
 
-With rocprofv3's per-class instruction counts (`{R}_pmc_summary.json`) these rates give an issue-time floor per kernel
-(`bench.py` `pmc_valu`, 1024 SIMDs at 2.4 GHz): `blend_fwd` {vf['insts'] / 1e6:.0f} M VALU instructions ({", ".join(f"{k} {v / 1e6:.1f} M" for k, v in vf['insts_by_class'].items())}) →
-**{vf['floor_ms']} ms of {vf['kernel_ms']} ms = {100 * vf['frac']:.0f} %**: the forward sits on its VALU floor.  `blend_bwd` {vb['insts'] / 1e6:.0f} M ({", ".join(f"{k} {v / 1e6:.1f} M" for k, v in vb['insts_by_class'].items())}; the ~28 M DPP adds of its
-reductions are counted as `add_f32` here although they cost 4.2 cycles, so the floor is a lower bound) → **{vb['floor_ms']} ms of {vb['kernel_ms']} ms =
-{100 * vb['frac']:.0f} %**; the SQ's own activity counter says {vb.get('sq_active_cycles_per_inst', float('nan'))} cycles per VALU instruction, i.e. the pipe busy
-{100 * pmc[BWD]['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / 2.4e9 * 1e6 / ks[BWD]:.0f} % of the kernel's time.  Where the rest goes, from the timeline of its 6700 single-wave workgroups:
+`alg_GBps` in the bench lines is SURVEY §8d's reference-algorithm bytes over the stage time — it counts bytes this library never
+moves (the reference's 64-bit key sort) and can exceed the HBM peak; `counter_GBps` above is what moved.
+
+## Other workloads
+
+{others_table()}
+
+## The backward blend on a scene with a real capture's load (clustered_500k_1600x1062)
+
+Tile weights (`{R}_bwd_tail_model_clustered_500k.txt`, first lines):
 
 ```
-{timeline.strip()}
-```
+{"".join(open(os.path.join(P, f"{R}_bwd_tail_model_clustered_500k.txt")).readlines()[:3])}```
 
-i.e. with the tiles started heaviest first (`blend.hip tile_order_kernel`) a CU is full — 24 single-wave workgroups at 80
-registers — for seven tenths of its span and the CUs end within ~9 % of each other; the longest workgroup lives for the
-whole span of its CU, so the kernel is as long as its heaviest tile is slow.  In row-major order
-(`{PREV}_bwd_timeline_row_major.txt`, round 3, 5 per SIMD) the residency decayed from the middle of the
-span on (20, 20, 20, 22, 22, 17, 12, 9, 6, 3) and the kernel took 0.340 ms instead of {ks[BWD] / 1e3:.3f}.  The forward
-blend's 26 800 one-wave workgroups (`{PREV}_fwd_timeline.txt`) show the same kind of tail, without a predictor to order by:
+Whole tile lists (`R3DGS_BWD_SEG=0`; one workgroup per tile, heaviest first) — the chip drains for the last third of the kernel:
 
 ```
-{fwd_timeline.strip()}
+{txt(f"{R}_bwd_timeline_clustered_whole_lists.txt")}```
+
+List segments (default): lists of at least max(256, 0.75 × the pass's mean list length) entries are walked in segments of 128 by
+several workgroups, from checkpoints the forward leaves:
+
 ```
+{txt(f"{R}_bwd_timeline_clustered.txt")}```
 
-Tried against the backward's remaining tail, all measured on this workload (DESIGN.md §6): two waves for the heaviest tiles
-(0.348–0.352 ms for the stage against 0.305), `s_setprio` for the heaviest workgroups (no change), 16 / 20 resident
-workgroups per CU instead of 24 (0.343 / 0.329 ms), 28 / 32 by launch bounds (35 / 59 spilled registers: 0.327 / 0.343 ms),
-a banded order that keeps each XCD on its part of the image (0.315 ms, FETCH_SIZE 74 instead of 150 MB).  Earlier in the
-round, before the tile order: two waves per tile for every tile 0.373–0.383 against 0.378–0.381 ms; `v_permlane16/32_swap`
-instead of the two `ds_bpermute` of the reduction +2 %; hand-packed `v_pk_*_f32` x/y and r/g arithmetic +4 % (forward) /
-+6 % (backward) — consistent with the rates above.
+The metric scene with list segments:
 
-## PMC view (per launch; FETCH_SIZE raw, before the ×2 correction for 16-B/lane loads)
+```
+{txt(f"{R}_bwd_timeline.txt")}```
 
-| kernel | VALU inst | SALU inst | LDS inst | active / wave-cycles | issue-stall (`WAIT_INST_ANY`) | parked (`WAIT_ANY`) | FETCH_SIZE | WRITE_SIZE |
-|---|---|---|---|---|---|---|---|---|
-{row(FWD)}
-{row(BWD)}
-{row('r3::pair_reduce_kernel')}
-{row('r3::preprocess_bwd_kernel<true, true>')}
-{row('r3::depth_sort_color_kernel<2, false>')}
-{row('r3::emit_pairs_kernel<r3::IoNarrow>')}
-{row('r3::radix_scatter_kernel<r3::IoNarrow, 7>')}
+## Lane utilisation of the blend kernels (CPU, the kernels' own per-lane functions)
 
-## Other workloads (`{R}_other_workloads.jsonl`, 20 steps, 4 cameras; round 3 in brackets)
+```
+{txt(f"{R}_lane_utilisation.txt")}```
 
-| workload | it/s | ms/step | `B_iter`·it/s ÷ 8 TB/s (reference-algorithm bytes, SURVEY 8d) | R̄ (reference) / pairs binned | stage ms (pre / depth+colour / binning / blend fwd / blend bwd / pre bwd) | render FPS |
-|---|---|---|---|---|---|---|
-'''
-for o in others:
-    wl = o["config"]["workload"]
-    prev = old_others.get(wl)
-    new += (f"| `{wl}` | {o['value']} [{prev['value'] if prev else '-'}] | {o['ms_per_step']} | {100 * o['iter_roofline']['frac_of_8TBps']:.1f} % | {o['config']['num_rendered_mean'] / 1e6:.2f} M / "
-            f"{o['config'].get('pairs_binned_mean', 0) / 1e6:.2f} M | {stages_of(o)} | {o['render_fps']} [{prev['render_fps'] if prev else '-'}] |\n")
-new += '''
-**The 40 % clause of the north star holds at the scene sizes of BASELINE.json configs[2..4]** (2 M / 5 M / 6 M Gaussians: 54–60 %
-of the 8 TB/s roof in the reference algorithm's bytes) and not at the 500 k headline shape (31 %), where the two VALU-bound
-blend kernels are 57 % of the step.  The per-Gaussian stages dominate above 2 M Gaussians (6 M: geometry + depth sort + binning + per-Gaussian backward are two
-thirds of the step).  VERDICT r3's bars for these shapes (6 M >= 360 it/s, 5 M >= 430) are not met; the sweep of
-`r04_sweep_6M_depth_sort_colour.txt` and DESIGN.md section 11 say what was tried and what it would need.
+## fp64 on the vector unit (`{R}_valu_rate.txt`, 8 waves per SIMD)
+
+```
+{chr(10).join(f32 + f64)}
+```
 '''
 open(os.path.join(P, "README.md"), "w").write(new)
-print("wrote profiles/README.md,", len(new.splitlines()), "lines")
+print(f"profiles/README.md written ({len(new.splitlines())} lines)")
