@@ -570,8 +570,9 @@ R3_HD void cov3d_backward(const float* scale, float mod, const float* q, const f
 // the reference does and as cov2d_backward / cov3d_backward above restate -- the rounding of the intermediates alone
 // puts dL/drotations 2e-4 and dL/dscales 5e-5 of the tensor's maximum away from the exact value at the benchmark shape,
 // measured with the oracle's double evaluation (oracle/backward_f64.c; the same fp32 inputs through a double chain:
-// 2e-6 / 4e-6).  Two fp32 evaluations then differ from EACH OTHER by more than north_star's 1e-4.  fp64 FMAs issue at
-// the fp32 rate on CDNA4 and this stage is HBM-bound, so the per-Gaussian backward evaluates the chain in double from
+// 2e-6 / 4e-6).  Two fp32 evaluations then differ from EACH OTHER by more than north_star's 1e-4.  This stage is
+// HBM-bound (a v_fma_f64 costs a SIMD 4.2 cycles per wave against 2.7 for v_fma_f32, tools/valu_rate.hip; the kernel waits
+// for memory either way: 0.0625 vs 0.0614 ms), so the per-Gaussian backward evaluates the chain in double from
 // the same fp32 inputs and rounds once at the end: the closest fp32 number to the exact gradient of what the forward
 // computed.  Decisions (the 1.3 tan(fov) clamp masks) are taken in fp32 exactly as the forward took them, and the
 // reference's conventions are kept (fp32 focal lengths and clamp limits, 1 / (det^2 + 1e-7), no quaternion-normalisation
