@@ -775,6 +775,7 @@ void fill_fwd_args(FwdPassArgs& a, const FwdPlan& p, const FwdCall& c, const Geo
     d.ovf_id = g.ovf_id;
     d.rect = g.rect;
     d.rec16 = g.rec16;
+    d.rec16_b = g.rec16_b;
     d.rect_sorted = g.rect_sorted;
     d.order = g.order;
     d.offsets = g.offsets;

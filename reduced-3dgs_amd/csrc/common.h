@@ -155,6 +155,7 @@ struct GeomState {
     uint32_t* bucket_id;  // [P]  ... and its ids (ping-pong partners of ovf_key / ovf_id on that slow path)
     uint4* rec16;         // [P]  (depth key, id, rect x0 | y0 << 16, x1 | y1 << 16) grouped by depth bucket (depth_sort.h)
     ushort4* rect_sorted; // [P]  tile rects in depth order, for the pair emission (bucketed sort only)
+    uint4* rec16_b;       // [P]  second record array: where a bucket too big for the LDS sort is split into sub-buckets
     uint32_t* order;      // [P]  Gaussian ids in (depth, id) order
     uint32_t* offsets;    // [P]  inclusive scan of tiles[order[j]]
     int* radii_internal;  // [P]  used when the caller passes radii == nullptr (rasterizer_impl.cu:393-396)
@@ -189,6 +190,7 @@ struct GeomState {
         g.ovf_id = c.take<uint32_t>(P);
         g.rec16 = c.take<uint4>(P);
         g.rect_sorted = c.take<ushort4>(P);
+        g.rec16_b = c.take<uint4>(P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         // LAST, so that a blob without it is a valid blob: a forward that will not leave the derivatives (inference /
@@ -531,6 +533,7 @@ struct DepthArgs {        // depth_sort.h bucketed depth sort
     uint32_t* ovf_id;
     const ushort4* rect;     // GeomState::rect (by Gaussian id)
     uint4* rec16;            // GeomState::rec16
+    uint4* rec16_b;          // GeomState::rec16_b
     ushort4* rect_sorted;    // GeomState::rect_sorted (written by the bucket sort)
     uint32_t* order;
     uint32_t* offsets;

@@ -69,6 +69,8 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
 }
 
 constexpr int kWaveSortMax = 512;    // largest bucket one wave sorts in registers (8 words per lane)
+constexpr int kGlobalSplitMax = 64;                                  // sub-buckets of a bucket that does not fit the LDS sort
+constexpr uint32_t kGlobalSplitCap = kGlobalSplitMax * 2048u;       // ... which it can hold at an average of half the LDS capacity
 constexpr int kBucketsPerGroup = 4;  // buckets per 256-thread workgroup of the bucket-sort kernel: one per wave
 constexpr int kHistPerThread = kHistBatch / 256;
 constexpr int kCountBits = 24;
@@ -272,7 +274,7 @@ __device__ inline void depth_colscan_role(const DepthArgs& a, int wg)
         }
         if (w == 0) {
             a.ds->total[c] = total;
-            if (c < nb && (uint32_t)(total & kCountMask) > (uint32_t)kBucketCap) s_over = 1u;
+            if (c < nb && (uint32_t)(total & kCountMask) > kGlobalSplitCap) s_over = 1u;
         }
     }
     if (w == 0) {   // the buckets one wave cannot sort in registers go on the list the bucket-sort kernel's workgroups share
@@ -489,13 +491,12 @@ __device__ inline int block_radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_
 }
 
 // One wave sorts m <= 64 * E sort words it finds in LDS (src[0 .. m)) in registers and writes the entries' outputs at
-// positions out0 .. out0 + m of the bucket that starts at `start`: ids, rects (fetched from the bucket's records by the
-// position the word carries), and the inclusive scan of the tile counts on top of `tile_base`.
+// depth ranks out0 .. out0 + m: ids, rects (fetched from the records `rec` by the position the word carries), and the
+// inclusive scan of the tile counts on top of `tile_base`.
 template <int E>
-__device__ __forceinline__ void wave_sort_words(const DepthArgs& a, const unsigned long long* src, uint32_t m, uint32_t start,
-                                                uint32_t out0, uint32_t tile_base, int lane)
+__device__ __forceinline__ void wave_sort_words(const DepthArgs& a, const unsigned long long* src, uint32_t m,
+                                                const uint4* __restrict__ rec, uint32_t out0, uint32_t tile_base, int lane)
 {
-    const uint4* __restrict__ rec = a.rec16 + start;
     unsigned long long v[E];
 #pragma unroll
     for (int r = 0; r < E; r++) {
@@ -511,16 +512,16 @@ __device__ __forceinline__ void wave_sort_words(const DepthArgs& a, const unsign
         rc[r] = have ? *reinterpret_cast<const uint2*>(&rec[word_pos(v[r])].z) : make_uint2(0u, 0u);
         t[r] = have ? rect_tiles(rc[r]) : 0u;
     }
-    uint2* __restrict__ rect_out = reinterpret_cast<uint2*>(a.rect_sorted) + start + out0;
+    uint2* __restrict__ rect_out = reinterpret_cast<uint2*>(a.rect_sorted) + out0;
     uint32_t run = tile_base;
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const uint32_t i = (uint32_t)(r * 64 + lane);
         const uint32_t incl = wave_inclusive_scan(t[r], lane);
         if (i < m) {
-            a.order[start + out0 + i] = word_id(v[r]);
+            a.order[out0 + i] = word_id(v[r]);
             rect_out[i] = rc[r];
-            publish_offset(a, start + out0 + i, run + incl, t[r]);
+            publish_offset(a, out0 + i, run + incl, t[r]);
         }
         run += (uint32_t)__shfl((int)incl, 63);
     }
@@ -529,52 +530,16 @@ __device__ __forceinline__ void wave_sort_words(const DepthArgs& a, const unsign
 constexpr int kSplitMax = 32;       // sub-buckets a big bucket is split into at most
 constexpr int kSplitTarget = 192;   // ... aiming at this many entries each (a sub-bucket above kWaveSortMax: merge path)
 
-// Workgroup-level sort of ONE bucket b (the big ones, see depth_bucket_group_role): the sort words in LDS, then the
-// inclusive scan of tiles_touched in that order on top of the bucket's base.
-__device__ __forceinline__ void depth_bucket_sort_role(const DepthArgs& a, char* smem, int b)
+// Sorts the n <= kBucketCap records rec[0 .. n) by (key, id) with the whole workgroup -- the sort words in LDS -- and writes
+// ids, rects and the inclusive scan of the tile counts (on top of `tb`) at depth ranks out0 .. out0 + n.
+__device__ __forceinline__ void sort_records_lds(const DepthArgs& a, char* smem, const uint4* __restrict__ rec, uint32_t n,
+                                                 uint32_t out0, uint32_t tb)
 {
     unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);                     // [kBucketCap]
     uint32_t* s_sum = reinterpret_cast<uint32_t*>(smem + (size_t)kBucketCap * 8);            // [256]
-    uint32_t* s_radix = s_sum + 256;                                                          // slow path scratch
-    const DepthSortScratch* __restrict__ ds = a.ds;
+    uint32_t* s_radix = s_sum + 256;                                                          // scratch of the split
     uint32_t* __restrict__ order = a.order;
-    const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
-    if (n == 0) return;
-    const uint4* __restrict__ rec = a.rec16 + start;
-    uint2* __restrict__ rect_out = reinterpret_cast<uint2*>(a.rect_sorted) + start;
-    if (n > (uint32_t)kBucketCap) {
-        // the bucket does not fit the LDS sort: its (key, id) pairs are copied out of the records, sorted by a radix sort in
-        // global memory, then the scan in strides of 256 (tile counts and rects gathered by id: the slow path)
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint4 r = rec[i];
-            a.key_sorted[start + i] = r.x;
-            a.bucket_id[start + i] = r.y;
-        }
-        __threadfence();
-        __syncthreads();
-        const int cur = block_radix_sort_pairs(a.key_sorted + start, a.bucket_id + start, a.ovf_key + start,
-                                               a.ovf_id + start, n, s_radix);
-        const uint32_t* ids = (cur ? a.ovf_id : a.bucket_id) + start;
-        const uint2* __restrict__ rects = reinterpret_cast<const uint2*>(a.rect);
-        uint32_t run = ds->tile_base[b];
-        for (uint32_t c0 = 0; c0 < n; c0 += 256) {
-            const uint32_t r = c0 + threadIdx.x;
-            const uint32_t id = r < n ? ids[r] : 0u;
-            const uint2 rc = r < n ? rects[id] : make_uint2(0u, 0u);
-            const uint32_t t = r < n ? rect_tiles(rc) : 0u;
-            const uint32_t incl = block256_inclusive_scan(t, s_sum);
-            if (r < n) {
-                order[start + r] = id;
-                rect_out[r] = rc;
-                publish_offset(a, start + r, run + incl, t);
-            }
-            __syncthreads();
-            if (threadIdx.x == 255) s_sum[4] = incl;
-            __syncthreads();
-            run += s_sum[4];
-        }
-        return;
-    }
+    uint2* __restrict__ rect_out = reinterpret_cast<uint2*>(a.rect_sorted) + out0;
     // smallest key of the bucket: the words hold keys relative to it
     uint32_t kmin = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < n; i += 256) kmin = min(kmin, rec[i].x);
@@ -640,18 +605,17 @@ __device__ __forceinline__ void depth_bucket_sort_role(const DepthArgs& a, char*
                 s[s_first[sb] + atomicAdd(&s_cnt[sb], 1u)] = sort_word(ki.x, kmin, ki.y, i);
             }
             __syncthreads();
-            const uint32_t tb = ds->tile_base[b];
             for (uint32_t sb = (uint32_t)w; sb < nsub; sb += 4u) {   // wave-uniform
                 const uint32_t f0 = s_first[sb], m = s_first[sb + 1u] - f0;
                 if (m == 0u) {
                 } else if (m <= 64u) {
-                    wave_sort_words<1>(a, s + f0, m, start, f0, tb + s_tbase[sb], lane);
+                    wave_sort_words<1>(a, s + f0, m, rec, out0 + f0, tb + s_tbase[sb], lane);
                 } else if (m <= 128u) {
-                    wave_sort_words<2>(a, s + f0, m, start, f0, tb + s_tbase[sb], lane);
+                    wave_sort_words<2>(a, s + f0, m, rec, out0 + f0, tb + s_tbase[sb], lane);
                 } else if (m <= 256u) {
-                    wave_sort_words<4>(a, s + f0, m, start, f0, tb + s_tbase[sb], lane);
+                    wave_sort_words<4>(a, s + f0, m, rec, out0 + f0, tb + s_tbase[sb], lane);
                 } else {
-                    wave_sort_words<8>(a, s + f0, m, start, f0, tb + s_tbase[sb], lane);
+                    wave_sort_words<8>(a, s + f0, m, rec, out0 + f0, tb + s_tbase[sb], lane);
                 }
             }
             __syncthreads();   // (the window is reused by the workgroup's next big bucket)
@@ -707,16 +671,136 @@ __device__ __forceinline__ void depth_bucket_sort_role(const DepthArgs& a, char*
         const uint32_t r = r0 + k;
         if (r < n) mine += rect_tiles(*reinterpret_cast<const uint2*>(&rec[word_pos(s[r])].z));
     }
-    uint32_t run = ds->tile_base[b] + block256_inclusive_scan(mine, s_sum) - mine;
+    uint32_t run = tb + block256_inclusive_scan(mine, s_sum) - mine;
     for (uint32_t k = 0; k < per; k++) {
         const uint32_t r = r0 + k;
         if (r < n) {
             const uint2 rc = *reinterpret_cast<const uint2*>(&rec[word_pos(s[r])].z);
             const uint32_t t = rect_tiles(rc);
             run += t;
-            order[start + r] = word_id(s[r]);
+            order[out0 + r] = word_id(s[r]);
             rect_out[r] = rc;
-            publish_offset(a, start + r, run, t);
+            publish_offset(a, out0 + r, run, t);
+        }
+    }
+}
+
+// Workgroup-level sort of ONE bucket b (the big ones, see depth_bucket_group_role), and the inclusive scan of tiles_touched
+// in that order on top of the bucket's base.  Up to kBucketCap entries: sort_records_lds.  Above -- a real scene's
+// foreground at 2 M Gaussians puts 4000-5000 into each of a few hundred buckets -- the bucket is first split in GLOBAL
+// memory (the same monotone split of its key range, records copied into the sub-buckets' places of a second record array)
+// and every piece sorted that way; only a bucket whose pieces do not fit either (keys piled on a few values: a
+// fronto-parallel plane of splats) takes the radix sort in global memory.
+__device__ __forceinline__ void depth_bucket_sort_role(const DepthArgs& a, char* smem, int b)
+{
+    uint32_t* s_sum = reinterpret_cast<uint32_t*>(smem + (size_t)kBucketCap * 8);            // [256]
+    uint32_t* s_radix = s_sum + 256;                                                          // slow path scratch
+    const DepthSortScratch* __restrict__ ds = a.ds;
+    uint32_t* __restrict__ order = a.order;
+    const uint32_t start = ds->start[b], n = ds->start[b + 1] - start;
+    if (n == 0) return;
+    const uint4* __restrict__ rec = a.rec16 + start;
+    uint2* __restrict__ rect_out = reinterpret_cast<uint2*>(a.rect_sorted) + start;
+    if (n <= (uint32_t)kBucketCap) {
+        sort_records_lds(a, smem, rec, n, start, ds->tile_base[b]);
+        return;
+    }
+    if (n <= kGlobalSplitCap) {
+        __shared__ uint32_t g_cnt[kGlobalSplitMax], g_tiles[kGlobalSplitMax], g_first[kGlobalSplitMax + 1], g_tbase[kGlobalSplitMax];
+        __shared__ uint32_t g_ok;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t k = rec[i].x;
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            s_sum[w] = kmin;
+            s_sum[4 + w] = kmax;
+        }
+        if (threadIdx.x < (uint32_t)kGlobalSplitMax) g_cnt[threadIdx.x] = g_tiles[threadIdx.x] = 0u;
+        __syncthreads();
+        kmin = min(min(s_sum[0], s_sum[1]), min(s_sum[2], s_sum[3]));
+        kmax = max(max(s_sum[4], s_sum[5]), max(s_sum[6], s_sum[7]));
+        const uint32_t nsub = min((uint32_t)kGlobalSplitMax, (n + 2047u) / 2048u);
+        const float scale = (float)nsub / ((float)(kmax - kmin) + 1.0f);   // monotone in the key, as depth_bucket
+        auto sub_of = [&](uint32_t key) { return min((uint32_t)((float)(key - kmin) * scale), nsub - 1u); };
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint4 r = rec[i];
+            const uint32_t sb = sub_of(r.x);
+            atomicAdd(&g_cnt[sb], 1u);
+            atomicAdd(&g_tiles[sb], rect_tiles(make_uint2(r.z, r.w)));
+        }
+        __syncthreads();
+        if (w == 0) {
+            const uint32_t c = lane < (int)nsub ? g_cnt[lane] : 0u, tl = lane < (int)nsub ? g_tiles[lane] : 0u;
+            const uint32_t ci = wave_inclusive_scan(c, lane), ti = wave_inclusive_scan(tl, lane);
+            const unsigned long long big = __ballot(c > (uint32_t)kBucketCap);
+            if (lane < (int)nsub) {
+                g_first[lane] = ci - c;
+                g_tbase[lane] = ti - tl;
+                g_cnt[lane] = 0u;   // from here on: the placement cursor
+            }
+            if (lane == 0) {
+                g_first[nsub] = n;
+                g_ok = big == 0ull;
+            }
+        }
+        __syncthreads();
+        if (g_ok) {
+            uint4* __restrict__ dst = a.rec16_b + start;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                const uint4 r = rec[i];
+                const uint32_t sb = sub_of(r.x);
+                dst[g_first[sb] + atomicAdd(&g_cnt[sb], 1u)] = r;
+            }
+            __threadfence();
+            __syncthreads();
+            const uint32_t tb = ds->tile_base[b];
+            for (uint32_t sb = 0; sb < nsub; sb++) {   // workgroup-uniform
+                const uint32_t f0 = g_first[sb], m = g_first[sb + 1u] - f0;
+                if (m) sort_records_lds(a, smem, dst + f0, m, start + f0, tb + g_tbase[sb]);
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    {
+        // the bucket fits neither: its (key, id) pairs are copied out of the records, sorted by a radix sort in global memory,
+        // then the scan in strides of 256 (tile counts and rects gathered by id: the slow path)
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint4 r = rec[i];
+            a.key_sorted[start + i] = r.x;
+            a.bucket_id[start + i] = r.y;
+        }
+        __threadfence();
+        __syncthreads();
+        const int cur = block_radix_sort_pairs(a.key_sorted + start, a.bucket_id + start, a.ovf_key + start,
+                                               a.ovf_id + start, n, s_radix);
+        const uint32_t* ids = (cur ? a.ovf_id : a.bucket_id) + start;
+        const uint2* __restrict__ rects = reinterpret_cast<const uint2*>(a.rect);
+        uint32_t run = ds->tile_base[b];
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+            const uint32_t r = c0 + threadIdx.x;
+            const uint32_t id = r < n ? ids[r] : 0u;
+            const uint2 rc = r < n ? rects[id] : make_uint2(0u, 0u);
+            const uint32_t t = r < n ? rect_tiles(rc) : 0u;
+            const uint32_t incl = block256_inclusive_scan(t, s_sum);
+            if (r < n) {
+                order[start + r] = id;
+                rect_out[r] = rc;
+                publish_offset(a, start + r, run + incl, t);
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) s_sum[4] = incl;
+            __syncthreads();
+            run += s_sum[4];
         }
     }
 }
