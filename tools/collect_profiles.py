@@ -35,6 +35,8 @@ for tl in ("bwd_timeline", "bwd_timeline_clustered", "bwd_timeline_clustered_who
         shutil.copy(os.path.join(G, tl + ".txt"), os.path.join(P, f"{R}_{tl}.txt"))
 open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write(open(os.path.join(G, "pytest_gpu.log")).read() +
                                                        "\n" + open(os.path.join(G, "smoke.log")).read()[-1600:])
+if os.path.exists(os.path.join(G, "ab_rounds.txt")):
+    shutil.copy(os.path.join(G, "ab_rounds.txt"), os.path.join(P, f"{R}_ab_round4_vs_round5.txt"))
 if os.path.exists(os.path.join(G, "host_bound.log")):
     shutil.copy(os.path.join(G, "host_bound.log"), os.path.join(P, f"{R}_host_bound_bindings.txt"))
 for wl, short in (("garden_like_2M_1600x1062", "garden_like_2M"), ("train_like_6M_1920x1080", "train_like_6M"),

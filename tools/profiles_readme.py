@@ -144,6 +144,7 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | `{R}_kernel_stats_*.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` on the metric workload, the clustered 500 k scene, 2 M, 6 M @1920×1080 and the clustered 2 M scene |
 | `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic`, `roofline.valu`, `stages.*.counter_bytes` |
 | `{R}_pmc_summary_2M.json`, `_6M.json`, `_clustered_500k.json` | the `FETCH_SIZE` / `WRITE_SIZE` passes of the same command on those workloads (`bench.py --workload …` cites them) |
+| `{R}_ab_round4_vs_round5.txt` | five workloads through round 4's library and this round's, alternating, in one visit |
 | `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins and of the two clustered scenes |
 | `{R}_bwd_timeline.txt`, `{R}_bwd_timeline_clustered.txt`, `{R}_bwd_timeline_clustered_whole_lists.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran — metric scene, clustered scene with list segments (default) and without |
 | `{R}_bwd_tail_model_clustered_500k.txt` | `tools/bwd_tail_model.py clustered_500k_1600x1062`: tile-weight histogram of the clustered scene and the processor-sharing model of its schedule |
@@ -171,6 +172,11 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | dominant kernel against the roof that binds it (VALU issue) | `blend_bwd_kernel`: {vb['insts'] / 1e6:.1f} M VALU instructions, floor {vb['floor_ms']} ms / kernel {vb['kernel_ms_committed_profile']} ms = **{vb['floor_ms'] / vb['kernel_ms_committed_profile']:.2f}** [round 4: 0.72]; `blend_fwd_kernel`: floor {vf['floor_ms']} / {vf['kernel_ms_committed_profile']} ms = {vf['floor_ms'] / vf['kernel_ms_committed_profile']:.2f} |
 | whole iteration | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes) → {100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s (target 40 %); bytes the counters saw move: {d50['iter_roofline']['counter_traffic_bytes'] / 1e9:.2f} GB/step = {100 * d50['iter_roofline']['frac_counter_traffic']:.1f} % |
 | CPU baseline (`cpu_baseline`, kind "port") | {d50['cpu_baseline']['value']} it/s on {d50['cpu_baseline']['cores']} threads of a {d50['cpu_baseline'].get('cpu_model')}: {d50['cpu_baseline']['sample'][:110]}…; the bench workload itself by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
+
+## This round's library against round 4's, same visit (`{R}_ab_round4_vs_round5.txt`: `bench.py --steps 20 --warmup 5 --cameras 4`, `R3DGS_LIB=old` = the round-4 tree built beside)
+
+```
+{txt(f"{R}_ab_round4_vs_round5.txt")}```
 
 ## Kernels
 

@@ -44,6 +44,20 @@ for pair in "2M:$G2" "6M:$T6" "clustered_500k:$CL"; do
   done
   python tools/pmc_summary.py gpurun_out/pmc_summary_$tag.json pmc${tag}_ >> gpurun_out/pmc_summary.log 2>&1
 done
+# this round's library against the previous round's (R3DGS_LIB=old: tools/build_variant.py-style build of the round-4 tree),
+# same visit, alternating: the only comparison across rounds that a box-to-box spread of 1.4x leaves standing
+if [ -f reduced-3dgs_amd/libr3dgs_hip_old.so ]; then
+  : > gpurun_out/ab_rounds.txt
+  for wl in metric_500k_1600x1062 $CL $G2 $T6 garden_clustered_2M; do
+    for lib in old new; do
+      if [ $lib = old ]; then export R3DGS_LIB=old; else unset R3DGS_LIB; fi
+      line=$(timeout 300 python bench.py --workload $wl --steps 20 --warmup 5 --cameras 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], "it/s", d["ms_per_step"], "ms;", " / ".join("%s %.4f" % (k, v["avg_ms"]) for k, v in d["stages"].items()))')
+      echo "$wl [$lib] $line" >> gpurun_out/ab_rounds.txt
+    done
+  done
+  unset R3DGS_LIB
+  cat gpurun_out/ab_rounds.txt >> $S
+fi
 ( timeout 300 python tools/host_bound_bench.py 500 ) > gpurun_out/host_bound.log 2>&1; echo "host_bound rc=$? $(tail -1 gpurun_out/host_bound.log)" >> $S
 bash tools/other_workloads.sh > gpurun_out/other.log 2>&1
 if [ -f reduced-3dgs_amd/libr3dgs_hip_tl.so ]; then
