@@ -473,9 +473,12 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
     const int lane = threadIdx.x;
     uint32_t wg, seg = 0u, nseg = 1u, walk_log2 = 0u;
     if (a.tile_order) {
-        if (blockIdx.x >= a.tile_order[a.units_cap]) return;   // the grid covers the most units a pass of this shape can have
-        walk_log2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[a.units_cap + 1u]);   // segment length of this pass
-        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[blockIdx.x]);
+        // entry b / lists of list b % lists (each list is heaviest first; the grid covers the most units a pass may have)
+        const uint32_t g = blockIdx.x % kOrderLists, i = blockIdx.x / kOrderLists, per_list = a.units_cap / kOrderLists;
+        const uint32_t* trailer = a.tile_order + a.units_cap + 2u * g;
+        if (i >= trailer[0]) return;
+        walk_log2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)trailer[1]);   // segment length this list's units walk
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[g * per_list + i]);
         wg = u & ((1u << kUnitTileBits) - 1u);
         seg = (u >> kUnitTileBits) & 63u;
         nseg = u >> (kUnitTileBits + 6u);
@@ -717,13 +720,20 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     constexpr int kWalks = 4;   // segment lengths a pass may walk: S, 2 S, 4 S, 8 S (the first whose units fit the launch)
     __shared__ uint32_t s_max[kWalks + 1], s_units[kWalks];
     const uint32_t tid = threadIdx.x, lane_id = tid & 63u;
-    install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
+    if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
+    // One workgroup per LIST: workgroup g orders the tiles g, g + lists, g + 2 lists ... into list g (its own class counters, no
+    // word exchanged with the others); the blend kernel's workgroup b takes entry b / lists of list b % lists, so the lists
+    // are consumed side by side and the launch order is the interleaving of eight orders of statistically alike tile sets.
+    // (As ONE workgroup over all tiles the kernel was bound by the vector issue of the one compute unit it ran on: 18 us.)
+    const uint32_t list = blockIdx.x, all_tiles = v.blend.nblocks;
     const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(v.blend.quad_depth);
     const uint2* __restrict__ ranges = v.blend.ranges;
-    uint32_t* __restrict__ order = v.blend.tile_order;
-    const uint32_t n_tiles = v.blend.nblocks;   // one workgroup of the backward blend per tile at least
-    const uint32_t cap = v.blend.units_cap;
-    const uint32_t seg_log2 = (v.blend.segments != 0 && v.blend.ckpt != nullptr && n_tiles <= (1u << kUnitTileBits))
+    const uint32_t cap = v.blend.units_cap / kOrderLists;                 // slots of this list
+    uint32_t* __restrict__ order = v.blend.tile_order + list * cap;
+    uint32_t* __restrict__ trailer = v.blend.tile_order + v.blend.units_cap + 2u * list;
+    const uint32_t n_tiles = all_tiles > list ? (all_tiles - list + kOrderLists - 1u) / kOrderLists : 0u;   // tiles of this list
+    auto tile_of = [&](uint32_t j) { return j * kOrderLists + list; };   // local index -> tile
+    const uint32_t seg_log2 = (v.blend.segments != 0 && v.blend.ckpt != nullptr && all_tiles <= (1u << kUnitTileBits))
                                   ? v.blend.hdr->ckpt : 0u;   // 0: the forward left no checkpoints / segments are off
     const uint32_t thr = seg_log2 ? v.blend.hdr->ckpt_thr : 0xFFFFFFFFu;
     // Units of the shortest segments: every tile once plus at most (list length / S) more, i.e. <= tiles + pairs / S.  Only a
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     // from the pass's pair count, not from the capacity its binning blob happens to have: the exact-size path and the
     // reserved path of one view then walk the same segments and give the same bits.)
     const uint32_t pairs_s = v.blend.hdr->num_pairs >> kBwdSegMinLog2;
-    const uint32_t fit = min(cap, n_tiles + min(pairs_s, 8u * n_tiles));
+    const uint32_t fit = (all_tiles + min(pairs_s, 8u * all_tiles)) / kOrderLists;   // <= cap: the reservation holds the pairs
     const bool always_fits = n_tiles + pairs_s <= fit;
     s_count[tid] = 0u;
     if (tid <= kWalks) s_max[tid] = 0u;
@@ -747,8 +757,8 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         d = make_uint4(0u, 0u, 0u, 0u);
         l = 0u;
         if (t < n_tiles) {
-            d = qd[t];
-            const uint2 r = ranges[t];
+            d = qd[tile_of(t)];
+            const uint2 r = ranges[tile_of(t)];
             l = r.y - r.x;
         }
     };
@@ -758,9 +768,9 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         uint2 rr[kOrderKeep];
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
-            const uint32_t t = min(tid + (uint32_t)(k * kOrderThreads), n_tiles - 1u);
-            w[k] = qd[t];
-            rr[k] = ranges[t];
+            const uint32_t t = tile_of(min(tid + (uint32_t)(k * kOrderThreads), max(n_tiles, 1u) - 1u));
+            w[k] = qd[min(t, all_tiles - 1u)];
+            rr[k] = ranges[min(t, all_tiles - 1u)];
         }
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
@@ -907,12 +917,12 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     __syncthreads();
     s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
     if (tid == kOrderThreads - 1) {
-        order[cap] = before + incl;   // the units of this pass (<= cap by the choice of `walk`; whole tiles: <= tiles <= cap)
-        order[cap + 1u] = walk;       // log2 of the segment length they walk (0: whole tiles)
+        trailer[0] = before + incl;   // the units of this list (<= cap by the choice of `walk`; whole tiles: <= tiles <= cap)
+        trailer[1] = walk;            // log2 of the segment length they walk (0: whole tiles)
     }
     __syncthreads();
     auto place = [&](uint32_t t, const uint4& d, uint32_t n, uint32_t f, uint32_t base, uint32_t classes, bool cached) {
-        const uint32_t word = t | (n << (kUnitTileBits + 6u));
+        const uint32_t word = tile_of(t) | (n << (kUnitTileBits + 6u));
         for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
         for (uint32_t k = f; k < n; k++) {
             const uint32_t c = (cached && k - f < kCached) ? (classes >> (10u * (k - f))) & 1023u
@@ -953,7 +963,7 @@ static void launch_bwd(uint32_t nblocks, uint32_t units_cap, BwdPassArgs* dst, c
 {
     if (v.blend.tile_order) {
         static const int lds_pad = env_int("R3DGS_BWD_LDS_PAD", 0, 0, 65536);
-        hipLaunchKernelGGL(unit_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, dst, v);
+        hipLaunchKernelGGL(unit_order_kernel, dim3(kOrderLists), dim3(kOrderThreads), 0, s, dst, v);
         // one workgroup per unit the pass MAY have (those beyond its count leave at once)
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(units_cap), dim3(64), lds_pad, s, dst, v);
     } else {

@@ -1604,7 +1604,7 @@ int r3dgs_export_tile_order(int P, int R, int width, int height, char* binning_b
         if (unit_order) {
             if (!binning_buffer || R <= 0) throw Error("the unit order lives in the binning buffer");
             BinState bin = BinState::carve(binning_buffer, (size_t)R, pair_layout(P, Tn).wide, Tn);
-            R3_HIP(hipMemcpyAsync(unit_order, bin.unit_order, sizeof(uint32_t) * ((size_t)bwd_units_cap((uint32_t)R, Tn) + 2),
+            R3_HIP(hipMemcpyAsync(unit_order, bin.unit_order, sizeof(uint32_t) * ((size_t)bwd_units_cap((uint32_t)R, Tn) + 2 * kOrderLists),
                                   hipMemcpyDeviceToDevice, s));
         }
         check_launch("export", s, false);

@@ -113,10 +113,10 @@ inline int depth_bucket_count(size_t P)
 }
 struct DepthSortScratch {
     uint32_t depth_max, depth_inv_min;               // depth range of the visible Gaussians
-    uint32_t big_count, big_cursor;                  // buckets above one wave's capacity (big_list): dealt out over all the
+    uint32_t big_count, pad_;                        // buckets above one wave's capacity (big_list): dealt out over all the
                                                      // workgroups of the bucket-sort kernel (a real scene piles its foreground
                                                      // into a few hundred neighbouring buckets; cleared by the histogram
-                                                     // kernel, filled by the column scan; the cursor is unused)
+                                                     // kernel, filled by the column scan)
     unsigned long long total[kMaxDepthBuckets + 1];  // per bucket (tile sum << 24 | count); [nb] = culled
     uint32_t start[kMaxDepthBuckets + 2];            // exclusive scan of the bucket sizes
     uint32_t tile_base[kMaxDepthBuckets + 2];        // exclusive scan of the buckets' tiles_touched sums
@@ -268,10 +268,13 @@ R3_HD size_t ckpt_slot(uint32_t first, uint32_t k, uint32_t tile, uint32_t seg_l
 inline size_t ckpt_slots(size_t R, size_t Tn) { return (R >> kBwdSegMinLog2) + Tn + 2; }
 // workgroups of the backward blend = capacity of its unit order: every tile once, plus the extra segments a pass may have
 // (bounded by the lists: sum over tiles of len / S <= R / S; capped -- a pass that wants more walks longer segments)
+constexpr uint32_t kOrderLists = 8;   // the unit order is kept as this many lists, each made by a workgroup of its own from every
+                                      // 8th tile; workgroup b of the backward blend takes entry b / 8 of list b % 8
 inline uint32_t bwd_units_cap(uint32_t reserve, size_t Tn)
 {
     const size_t extra = (size_t)reserve >> kBwdSegMinLog2;
-    return (uint32_t)(Tn + (extra < 8 * Tn ? extra : 8 * Tn));
+    const size_t cap = Tn + (extra < 8 * Tn ? extra : 8 * Tn);
+    return (uint32_t)((cap + kOrderLists - 1) / kOrderLists * kOrderLists + kOrderLists);   // a multiple of the list count
 }
 int bwd_segment_log2();         // R3DGS_BWD_SEG_LEN = 128 (default) | 256 -> 7 | 8; capi.hip
 int bwd_segment_factor_pct();   // R3DGS_BWD_SEG_FACTOR: lists >= this percentage of the pass's mean length are split (75)
@@ -294,9 +297,10 @@ struct BinState {
     unsigned long long* quad_masks;  // [R/64 + Tn + 2][4] region pre-test of the forward blend, kept for the backward:
                                      // bit j of [slot][q] = entry j of a 64-entry chunk of a tile's list may reach 8x8
                                      // quadrant q; slot = quad_mask_slot(first pair of the tile, chunk, tile)
-    uint32_t* unit_order;            // [bwd_units_cap + 2] launch order of the backward blend's (tile, segment) units,
-                                     // heaviest first; [cap] = how many there are, [cap + 1] = log2 of the segment length
-                                     // the pass walks (blend.hip unit_order_kernel)
+    uint32_t* unit_order;            // [bwd_units_cap + 2 * kOrderLists] launch order of the backward blend's (tile, segment)
+                                     // units: kOrderLists lists of cap / kOrderLists slots, each heaviest first; behind
+                                     // them per list how many units it has and log2 of the segment length they walk
+                                     // (blend.hip unit_order_kernel)
     float4* ckpt;                    // [ckpt_slots][256] forward checkpoints of the segmented tiles: (T, C0, C1, C2) per pixel
     char* end;
     static BinState carve(char* base, size_t R, int wide, size_t Tn)
@@ -328,7 +332,7 @@ struct BinState {
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
         b.block_first = c.take<uint32_t>(R / kRadixBlock + 2);
-        b.unit_order = c.take<uint32_t>((size_t)bwd_units_cap((uint32_t)R, Tn) + 2);
+        b.unit_order = c.take<uint32_t>((size_t)bwd_units_cap((uint32_t)R, Tn) + 2 * kOrderLists);
         // LAST: only touched for the tiles a pass segments (32 B per pair + 4 KB per tile of address space)
         b.ckpt = c.take<float4>(ckpt_slots(R, Tn) * 256);
         b.end = c.p;
@@ -613,7 +617,7 @@ struct BlendBwdArgs {     // blend.hip
     const unsigned long long* quad_masks;   // BinState::quad_masks as the forward left them (null: recompute)
     uint32_t* tile_order;                   // BinState::unit_order: launch order of the (tile, segment) units, heaviest
                                             // first (null: one workgroup per tile, row-major bands, one per XCD)
-    uint32_t units_cap;                     // entries of tile_order (= workgroups launched); [units_cap] = units of this pass
+    uint32_t units_cap;                     // slots of the kOrderLists lists together (= workgroups launched)
     const uint32_t* quad_depth;             // ImageState::quad_depth, what the order is built from
     const float4* ckpt;                     // BinState::ckpt
     const GeomHeader* hdr;                  // hdr->ckpt / ckpt_thr: what the forward checkpointed (0: every tile is one unit)

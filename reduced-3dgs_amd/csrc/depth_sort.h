@@ -206,7 +206,7 @@ __device__ inline void depth_hist_role(const DepthArgs& a, const HeaderArgs& h, 
     const int P = a.P, nb = a.nb;
     for (int b = threadIdx.x; b <= nb; b += 256) hist[b] = 0;
     uint32_t dmax, dinv;
-    if (wg == 0 && threadIdx.x == 0) a.ds->big_count = a.ds->big_cursor = 0u;   // (the column scan and the bucket sort run later)
+    if (wg == 0 && threadIdx.x == 0) a.ds->big_count = 0u;   // (the column scan, which fills the list, runs later)
     if (a.fuse_header) {
         const PrePartial all = reduce_partials(h.parts, h.n_parts, s_red);
         if (wg == 0 && threadIdx.x == 0) write_header(h, all);

@@ -12,6 +12,7 @@ import threading
 import weakref
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -756,8 +757,9 @@ def bwd_segments():
 
 def export_tile_order(H, W, imageBuffer, P=0, num_rendered=0, binningBuffer=None):
     """Debug accessor (not in the reference): quad_depth int32[tiles, 4] (deepest contributor of each 8x8 quadrant, left by
-    the forward) and -- given the binning buffer, P and num_rendered of the pass -- `units`, the launch order of the last
-    backward over this state (heaviest first): dict(tile, segment, segments) int64 arrays of its (tile, list segment) units."""
+    the forward) and -- given the binning buffer, P and num_rendered of the pass -- the launch order of the last backward
+    over this state: `lists`, eight dicts (tile, segment, segments int64 arrays, each list heaviest first, and `walk`, the
+    entries per list segment its units walk, 0 = whole tiles), and `units`, their concatenation."""
     n = ((W + 15) // 16) * ((H + 15) // 16)
     qd = torch.empty((n, 4), dtype=torch.int32, device=imageBuffer.device)
     out = dict(quad_depth=qd)
@@ -766,17 +768,25 @@ def export_tile_order(H, W, imageBuffer, P=0, num_rendered=0, binningBuffer=None
         R = (num_rendered.capacity if isinstance(num_rendered, NumRendered) else
              _lib.r3dgs_binning_capacity(int(P), W, H, int(binningBuffer.numel())))
         cap = int(_lib.r3dgs_bwd_units_cap(R, W, H))
-        order = torch.empty((cap + 1,), dtype=torch.int32, device=imageBuffer.device)
+        order = torch.empty((cap + 2 * _ORDER_LISTS,), dtype=torch.int32, device=imageBuffer.device)
     with _on_device(imageBuffer.device):
         _check(_lib.r3dgs_export_tile_order(int(P), int(R), W, H, _ptr(binningBuffer) if order is not None else None,
                                             _ptr(imageBuffer), _ptr(qd), _ptr(order) if order is not None else None,
                                             _stream()), "export_tile_order")
     if order is not None:
         o = order.cpu().numpy().astype("int64") & 0xFFFFFFFF
-        cnt = int(o[-1])
-        u = o[:cnt]
-        out["units"] = dict(tile=u & 0xFFFFF, segment=(u >> 20) & 63, segments=u >> 26)
+        per = cap // _ORDER_LISTS
+        lists = []
+        for g in range(_ORDER_LISTS):   # list g: made from the tiles g, g + 8, ...; consumed as entries b // 8 of list b % 8
+            cnt, walk_log2 = int(o[cap + 2 * g]), int(o[cap + 2 * g + 1])
+            u = o[g * per:g * per + cnt]
+            lists.append(dict(tile=u & 0xFFFFF, segment=(u >> 20) & 63, segments=u >> 26, walk=(1 << walk_log2) if walk_log2 else 0))
+        out["lists"] = lists
+        out["units"] = {k: np.concatenate([l[k] for l in lists]) for k in ("tile", "segment", "segments")}
     return out
+
+
+_ORDER_LISTS = 8
 
 
 def rasterize_gaussians_counters(*args):

@@ -371,14 +371,18 @@ def test_backward_tile_order_changes_no_bit(C_, kw):
     want = nc.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5)).transpose(0, 2, 1, 3).reshape(gx * gy, 4)
     assert np.array_equal(st["quad_depth"].cpu().numpy().astype(np.int64), want)
     units = st["units"]
-    # one unit per tile that anything contributed to (tiles nothing reached are left out): a permutation of those tiles
+    # one unit per tile that anything contributed to (tiles nothing reached are left out): the eight lists -- list g made of
+    # the tiles g, g + 8, ... -- together are a permutation of those tiles, each list by decreasing weight class
     assert np.all(units["segments"] == 1) and np.all(units["segment"] == 0)
-    order = units["tile"]
-    assert np.array_equal(np.sort(order), np.nonzero(want.sum(axis=1) > 0)[0])
-    weight = want.sum(axis=1)[order]
-    klass = (weight.astype(np.float64) * 1023.0 / max(int(weight.max()), 1)).astype(np.int64)   # the kernel's 1024 classes
-    assert np.all(np.diff(klass) <= 1), "heavier classes must come first (one class of slack for the fp32 product)"
-    assert weight[0] == weight.max()
+    assert np.array_equal(np.sort(units["tile"]), np.nonzero(want.sum(axis=1) > 0)[0])
+    for g_, l in enumerate(st["lists"]):
+        assert l["walk"] == 0 and np.all(l["tile"] % 8 == g_)
+        weight = want.sum(axis=1)[l["tile"]]
+        if len(weight):
+            top = max(int(want.sum(axis=1)[g_::8].max()), 1)
+            klass = (weight.astype(np.float64) * 1023.0 / top).astype(np.int64)   # the kernel's 1024 classes
+            assert np.all(np.diff(klass) <= 1), "heavier classes must come first (one class of slack for the fp32 product)"
+            assert weight[0] == weight.max()
     for a, b in zip(heavy_first, row_major):
         assert torch.equal(a, b)
 
@@ -414,31 +418,41 @@ def test_backward_list_segments(C_, name):
     rng_ = ex["ranges"].cpu().numpy().astype(np.int64)
     length, deepest = rng_[:, 1] - rng_[:, 0], qd.max(axis=1)
     thr = max(256, int(fout[0].pairs) * 75 // len(length) // 100)   # R3DGS_BWD_SEG_FACTOR = 75 % of the mean list length
-    cap = len(length) + min(int(fout[0].pairs) >> 7, 8 * len(length))
-    assert cap <= int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H))
-    for walk in (128, 256, 512, 1024):   # the shortest segments whose units fit the launch
-        n_want = np.where((length >= thr) & (deepest > walk), np.minimum((deepest + walk - 1) // walk, 32), 1)
-        n_want[qd.sum(axis=1) == 0] = 0
-        if n_want.sum() <= cap:
-            break
-    else:
-        raise AssertionError("no segment length fits the launch")
+    Tn = len(length)
+    fit = (Tn + min(int(fout[0].pairs) >> 7, 8 * Tn)) // 8     # slots a list may use (from the pass's pair count)
+    assert fit <= int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H)) // 8
+    n_want = np.zeros(Tn, np.int64)
+    n_units = 0
+    for g_, l in enumerate(st["lists"]):   # list g: the tiles g, g + 8, ...; the shortest segments whose units fit its slots
+        mine = np.arange(g_, Tn, 8)
+        for walk in (128, 256, 512, 1024):
+            n_g = np.where((length[mine] >= thr) & (deepest[mine] > walk), np.minimum((deepest[mine] + walk - 1) // walk, 32), 1)
+            n_g[qd[mine].sum(axis=1) == 0] = 0
+            if n_g.sum() <= fit:
+                break
+        else:
+            raise AssertionError("no segment length fits the launch")
+        n_want[mine] = n_g
+        assert l["walk"] == walk
+        assert len(l["tile"]) == n_g.sum()
+        key = np.sort(l["tile"] * 64 + l["segment"])
+        assert np.array_equal(key, np.concatenate([[t * 64 + k for k in range(n)] for t, n in zip(mine, n_g) if n] or [[]]).astype(np.int64))
+        assert np.array_equal(l["segments"], n_want[l["tile"]])
+        lo = l["segment"] * walk
+        hi = np.where(l["segment"] + 1 < l["segments"], lo + walk, 1 << 40)
+        weight = (np.clip(qd[l["tile"]], lo[:, None], hi[:, None]) - lo[:, None]).sum(axis=1)
+        weight[l["segments"] == 1] = qd[l["tile"]].sum(axis=1)[l["segments"] == 1]
+        # the kernel's 1024 classes: of a bound of the heaviest unit a splitting pass knows without looking (a segment weighs
+        # at most 4 x its length, an unsplit tile is shorter than thr entries); a capped tile's last segment may exceed it
+        bound = max(4 * walk, 4 * thr)
+        klass = np.minimum((weight.astype(np.float64) * 1023.0 / bound).astype(np.int64), 1023)
+        assert np.all(np.diff(klass) <= 1) and (len(klass) == 0 or klass[0] == klass.max())
+        n_units += len(key)
     assert n_want.max() > 1, "the scene must have lists that are split"
-    assert len(u["tile"]) == n_want.sum()
-    key = np.sort(u["tile"] * 64 + u["segment"])
-    assert np.array_equal(key, np.concatenate([t * 64 + np.arange(n) for t, n in enumerate(n_want) if n]))
-    assert np.array_equal(u["segments"], n_want[u["tile"]])
-    lo = u["segment"] * walk
-    hi = np.where(u["segment"] + 1 < u["segments"], lo + walk, 1 << 40)
-    weight = (np.clip(qd[u["tile"]], lo[:, None], hi[:, None]) - lo[:, None]).sum(axis=1)
-    weight[u["segments"] == 1] = qd[u["tile"]].sum(axis=1)[u["segments"] == 1]
-    # the kernel's 1024 classes: of a bound of the heaviest unit a splitting pass knows without looking (a segment weighs at
-    # most 4 x its length, an unsplit tile is shorter than thr entries); the last segment of a capped tile may exceed it
-    bound = max(4 * walk, 4 * thr)
-    klass = np.minimum((weight.astype(np.float64) * 1023.0 / bound).astype(np.int64), 1023)
-    assert np.all(np.diff(klass) <= 1) and klass[0] == klass.max()
-    print(f"\n  {name}: {int((n_want > 0).sum())} tiles in {len(key)} units of up to {walk} entries (lists >= {thr}); deepest contributor {int(deepest.max())}, "
-          f"heaviest unit / mean unit {weight.max() / weight.mean():.2f} (per tile: {qd.sum(axis=1).max() / qd.sum(axis=1)[n_want > 0].mean():.2f})")
+    tile_w = qd.sum(axis=1)
+    print(f"\n  {name}: {int((n_want > 0).sum())} tiles in {n_units} units of up to {walk} entries (lists >= {thr}); deepest contributor "
+          f"{int(deepest.max())}, heaviest tile / mean tile {tile_w.max() / tile_w[n_want > 0].mean():.2f}, mean segments of a split tile "
+          f"{n_want[n_want > 1].mean():.1f}")
     again = hip_backward(C_, fargs, fout, dl, 0.0)
     for a, b in zip(split, again):
         assert torch.equal(a, b)
@@ -447,6 +461,7 @@ def test_backward_list_segments(C_, name):
         whole = hip_backward(C_, fargs, fout, dl, 0.0)
         st1 = C_.export_tile_order(H, W, fout[5], P, fout[0], fout[4])
         assert np.all(st1["units"]["segments"] == 1) and len(st1["units"]["tile"]) == int((n_want > 0).sum())
+        assert all(l["walk"] == 0 for l in st1["lists"])
         was_order = C_.set_tile_order(False)
         try:
             row_major = hip_backward(C_, fargs, fout, dl, 0.0)
