@@ -189,7 +189,8 @@ int r3dgs_set_bwd_segments(int on);
 
 /* Debug accessor: the forward's per-quadrant depths ([tiles][4] uint32: quadrant q = (x half) + 2 * (y half) of the
  * 16x16 tile) and, after a backward with the order on, the launch order it used: [cap + 16] uint32, cap =
- * r3dgs_bwd_units_cap(R, W, H) -- eight lists of cap / 8 slots (list g: the units of the tiles g, g + 8, ..., heaviest first;
+ * r3dgs_bwd_units_cap(R, W, H) -- eight lists of cap / 8 slots (list g: the units of the 4 x 4 tile blocks g, g + 8, ... of the image, blocks counted
+ * row-major, heaviest first;
  * entry = tile | segment << 20 | segments of the tile << 26), then per list the number of its units and log2 of the segment
  * length they walk (0: whole tiles).  Workgroup b of the backward blend takes entry b / 8 of list b % 8.  P, R: as given to
  * the backward.  Device arrays, either may be NULL. */

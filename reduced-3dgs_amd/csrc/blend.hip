@@ -721,18 +721,20 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     __shared__ uint32_t s_max[kWalks + 1], s_units[kWalks];
     const uint32_t tid = threadIdx.x, lane_id = tid & 63u;
     if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
-    // One workgroup per LIST: workgroup g orders the tiles g, g + lists, g + 2 lists ... into list g (its own class counters, no
-    // word exchanged with the others); the blend kernel's workgroup b takes entry b / lists of list b % lists, so the lists
-    // are consumed side by side and the launch order is the interleaving of eight orders of statistically alike tile sets.
+    // One workgroup per LIST: workgroup g orders the tiles of list g (common.h TileGrid: the 4 x 4 tile blocks g, g + lists, ...
+    // of the image) with its own class counters, no word exchanged with the others; the blend kernel's workgroup b takes entry
+    // b / lists of list b % lists, so the lists are consumed side by side and the launch order is the interleaving of eight
+    // orders of statistically alike tile sets.
     // (As ONE workgroup over all tiles the kernel was bound by the vector issue of the one compute unit it ran on: 18 us.)
     const uint32_t list = blockIdx.x, all_tiles = v.blend.nblocks;
+    const TileGrid grid{(uint32_t)v.blend.gx, all_tiles / (uint32_t)v.blend.gx};
     const uint4* __restrict__ qd = reinterpret_cast<const uint4*>(v.blend.quad_depth);
     const uint2* __restrict__ ranges = v.blend.ranges;
     const uint32_t cap = v.blend.units_cap / kOrderLists;                 // slots of this list
     uint32_t* __restrict__ order = v.blend.tile_order + list * cap;
     uint32_t* __restrict__ trailer = v.blend.tile_order + v.blend.units_cap + 2u * list;
-    const uint32_t n_tiles = all_tiles > list ? (all_tiles - list + kOrderLists - 1u) / kOrderLists : 0u;   // tiles of this list
-    auto tile_of = [&](uint32_t j) { return j * kOrderLists + list; };   // local index -> tile
+    const uint32_t n_tiles = grid.list_slots(list);   // slots of this list; a slot of a block at the image's edge may hold no tile
+    auto tile_of = [&](uint32_t j) { return grid.list_tile(list, j); };   // slot -> tile (~0: none)
     const uint32_t seg_log2 = (v.blend.segments != 0 && v.blend.ckpt != nullptr && all_tiles <= (1u << kUnitTileBits))
                                   ? v.blend.hdr->ckpt : 0u;   // 0: the forward left no checkpoints / segments are off
     const uint32_t thr = seg_log2 ? v.blend.hdr->ckpt_thr : 0xFFFFFFFFu;
@@ -741,8 +743,8 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     // from the pass's pair count, not from the capacity its binning blob happens to have: the exact-size path and the
     // reserved path of one view then walk the same segments and give the same bits.)
     const uint32_t pairs_s = v.blend.hdr->num_pairs >> kBwdSegMinLog2;
-    const uint32_t fit = (all_tiles + min(pairs_s, 8u * all_tiles)) / kOrderLists;   // <= cap: the reservation holds the pairs
-    const bool always_fits = n_tiles + pairs_s <= fit;
+    const uint32_t fit = bwd_list_fit(v.blend.hdr->num_pairs, grid);   // <= cap: the reservation holds the pairs
+    const bool always_fits = grid.list_tiles_max() + pairs_s <= fit;   // (a pass with fewer than 8 S pairs)
     s_count[tid] = 0u;
     if (tid <= kWalks) s_max[tid] = 0u;
     if (tid < kWalks) s_units[tid] = 0u;
@@ -752,13 +754,14 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     constexpr int kOrderKeep = 8;
     const bool keep = n_tiles <= (uint32_t)(kOrderKeep * kOrderThreads);
     uint4 w[kOrderKeep];
-    uint32_t len[kOrderKeep];
+    uint32_t len[kOrderKeep], tl[kOrderKeep];   // weights, list length and tile of the kept slots
     auto load = [&](uint32_t t, uint4& d, uint32_t& l) {
         d = make_uint4(0u, 0u, 0u, 0u);
         l = 0u;
-        if (t < n_tiles) {
-            d = qd[tile_of(t)];
-            const uint2 r = ranges[tile_of(t)];
+        const uint32_t tile = t < n_tiles ? tile_of(t) : 0xFFFFFFFFu;
+        if (tile != 0xFFFFFFFFu) {
+            d = qd[tile];
+            const uint2 r = ranges[tile];
             l = r.y - r.x;
         }
     };
@@ -768,13 +771,14 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         uint2 rr[kOrderKeep];
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
-            const uint32_t t = tile_of(min(tid + (uint32_t)(k * kOrderThreads), max(n_tiles, 1u) - 1u));
-            w[k] = qd[min(t, all_tiles - 1u)];
-            rr[k] = ranges[min(t, all_tiles - 1u)];
+            const uint32_t j = tid + (uint32_t)(k * kOrderThreads);
+            tl[k] = j < n_tiles ? tile_of(j) : 0xFFFFFFFFu;
+            w[k] = qd[min(tl[k], all_tiles - 1u)];
+            rr[k] = ranges[min(tl[k], all_tiles - 1u)];
         }
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
-            const bool in = tid + (uint32_t)(k * kOrderThreads) < n_tiles;
+            const bool in = tl[k] != 0xFFFFFFFFu;
             if (!in) w[k] = make_uint4(0u, 0u, 0u, 0u);
             len[k] = in ? rr[k].y - rr[k].x : 0u;
         }
@@ -917,12 +921,12 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     __syncthreads();
     s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
     if (tid == kOrderThreads - 1) {
-        trailer[0] = before + incl;   // the units of this list (<= cap by the choice of `walk`; whole tiles: <= tiles <= cap)
+        trailer[0] = before + incl;   // the units of this list (<= cap by the choice of `walk`; whole tiles: <= list_tiles_max)
         trailer[1] = walk;            // log2 of the segment length they walk (0: whole tiles)
     }
     __syncthreads();
-    auto place = [&](uint32_t t, const uint4& d, uint32_t n, uint32_t f, uint32_t base, uint32_t classes, bool cached) {
-        const uint32_t word = tile_of(t) | (n << (kUnitTileBits + 6u));
+    auto place = [&](uint32_t tile, const uint4& d, uint32_t n, uint32_t f, uint32_t base, uint32_t classes, bool cached) {
+        const uint32_t word = tile | (n << (kUnitTileBits + 6u));
         for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
         for (uint32_t k = f; k < n; k++) {
             const uint32_t c = (cached && k - f < kCached) ? (classes >> (10u * (k - f))) & 1023u
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         uint32_t base = full_base(fsum);
 #pragma unroll
         for (int k = 0; k < kOrderKeep; k++) {
-            place(tid + (uint32_t)(k * kOrderThreads), w[k], nf[k] & 255u, nf[k] >> 8, base, pc[k], true);
+            place(tl[k], w[k], nf[k] & 255u, nf[k] >> 8, base, pc[k], true);
             base += nf[k] >> 8;
         }
     } else {
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
             uint32_t l;
             load(t0 + tid, d, l);
             const uint32_t n = segs(d, l), f = full_segments(d, n);
-            place(t0 + tid, d, n, f, full_base(f), 0u, false);
+            place(t0 + tid < n_tiles ? tile_of(t0 + tid) : 0u, d, n, f, full_base(f), 0u, false);
         }
     }
 }

@@ -949,9 +949,9 @@ int forward_exact(r3dgs_alloc_fn geometryBuffer, void* geometry_user, r3dgs_allo
     // r3dgs_export_binning as R, and both carve the blob with it.  Grids are sized by the pairs.
     plan.reserve = R_ref ? R_ref : 1u;
     plan.grid_pairs = R ? R : 1u;     // exact size: one block per chunk
-    char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy), binning_user);
+    char* bptr = binningBuffer(required_bytes<BinState>((size_t)plan.reserve, plan.layout.wide, TileGrid{(uint32_t)plan.gx, (uint32_t)plan.gy}), binning_user);
     if (!bptr) throw Error("binning allocator returned NULL");
-    BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
+    BinState bin = BinState::carve(bptr, (size_t)plan.reserve, plan.layout.wide, TileGrid{(uint32_t)plan.gx, (uint32_t)plan.gy});
     fill_fwd_args(args, plan, c, geom, &bin, img, info_dev, ticket, false);
     launch_write_args(d_args, args, s);   // the completed block (binning pointers, pair capacity)
     issue_forward(plan, d_args, args, s, 2, hooks, &geom);
@@ -974,7 +974,7 @@ long long forward_reserved(char* geom_buffer, char* binning_buffer, char* image_
     const size_t depth_temp = cached_depth_temp((size_t)c.P);
     GeomState geom = GeomState::carve(geom_buffer, (size_t)c.P, depth_temp);
     ImageState img = ImageState::carve(image_buffer, (size_t)c.width * c.height, (size_t)plan.gx * plan.gy);
-    BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
+    BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, TileGrid{(uint32_t)plan.gx, (uint32_t)plan.gy});
     PassInfo* info_dev = nullptr;
     const uint64_t ticket = new_ticket(dev, c, plan.reserve, !plan.generic_depth_sort, &info_dev);
     try {
@@ -1108,7 +1108,7 @@ size_t r3dgs_binning_bytes(int P, int width, int height, int reserve)
         g_last_error.clear();
         const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
         const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
-        return r3::required_bytes<r3::BinState>((size_t)(reserve > 0 ? reserve : 1), l.wide, (size_t)gx * gy);
+        return r3::required_bytes<r3::BinState>((size_t)(reserve > 0 ? reserve : 1), l.wide, r3::TileGrid{(uint32_t)gx, (uint32_t)gy});
     } catch (const std::exception& e) {
         g_last_error = e.what();
         return 0;
@@ -1124,13 +1124,13 @@ int r3dgs_binning_capacity(int P, int width, int height, size_t bytes)
     return guarded([&]() {
         const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
         const r3::PairLayout l = r3::pair_layout(P, (size_t)gx * gy);
-        if (r3::required_bytes<r3::BinState>((size_t)1, l.wide, (size_t)gx * gy) > bytes) return 0;
+        if (r3::required_bytes<r3::BinState>((size_t)1, l.wide, r3::TileGrid{(uint32_t)gx, (uint32_t)gy}) > bytes) return 0;
         // largest R whose layout fits: every array size is monotone in R, so any R with the same total has the same
         // offsets -- the capacity recovered from a blob's size reproduces the carve the forward used
         long long lo = 1, hi = 0x7fffffffLL;
         while (lo < hi) {
             const long long mid = (lo + hi + 1) / 2;
-            if (r3::required_bytes<r3::BinState>((size_t)mid, l.wide, (size_t)gx * gy) <= bytes)
+            if (r3::required_bytes<r3::BinState>((size_t)mid, l.wide, r3::TileGrid{(uint32_t)gx, (uint32_t)gy}) <= bytes)
                 lo = mid;
             else
                 hi = mid - 1;
@@ -1386,12 +1386,12 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         plan.reserve = R > 0 ? (uint32_t)R : 1u;
         plan.grid_pairs = grid_pairs_for(plan.reserve);
         plan.has_pairs = binning_buffer != nullptr ? 1 : 0;
-        plan.units_cap = bwd_units_cap(plan.reserve, (size_t)plan.gx * plan.gy);
+        plan.units_cap = bwd_units_cap(plan.reserve, TileGrid{(uint32_t)plan.gx, (uint32_t)plan.gy});
         plan.f64_chain = f64_chain();
         const int dev = current_device();
         GeomState geom = GeomState::carve(geom_buffer, (size_t)P, cached_depth_temp((size_t)P));
         ImageState img = ImageState::carve(image_buffer, (size_t)width * height, (size_t)plan.gx * plan.gy);
-        BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, (size_t)plan.gx * plan.gy);
+        BinState bin = BinState::carve(binning_buffer, (size_t)plan.reserve, plan.layout.wide, TileGrid{(uint32_t)plan.gx, (uint32_t)plan.gy});
         if (!radii) radii = geom.radii_internal;
 
         BwdPassArgs a;
@@ -1571,7 +1571,7 @@ int r3dgs_export_binning(int P, int R, int count, int width, int height, char* g
         if (count > R) throw Error("count exceeds the blob's pair capacity");
         if (count > 0 && binning_buffer) {
             const PairLayout l = pair_layout(P, Tn);
-            BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide, Tn);
+            BinState bin = BinState::carve(binning_buffer, (size_t)R, l.wide, TileGrid{(uint32_t)gx, (uint32_t)gy});
             if (keys) launch_export_keys(P, count, R, Tn, bin, geom, keys, s);
             if (point_list) {
                 // entries beyond the pairs the pass binned (a caller holding only the reference's num_rendered may ask for
@@ -1603,8 +1603,8 @@ int r3dgs_export_tile_order(int P, int R, int width, int height, char* binning_b
         if (quad_depth) R3_HIP(hipMemcpyAsync(quad_depth, img.quad_depth, sizeof(uint32_t) * 4 * Tn, hipMemcpyDeviceToDevice, s));
         if (unit_order) {
             if (!binning_buffer || R <= 0) throw Error("the unit order lives in the binning buffer");
-            BinState bin = BinState::carve(binning_buffer, (size_t)R, pair_layout(P, Tn).wide, Tn);
-            R3_HIP(hipMemcpyAsync(unit_order, bin.unit_order, sizeof(uint32_t) * ((size_t)bwd_units_cap((uint32_t)R, Tn) + 2 * kOrderLists),
+            BinState bin = BinState::carve(binning_buffer, (size_t)R, pair_layout(P, Tn).wide, TileGrid{(uint32_t)gx, (uint32_t)gy});
+            R3_HIP(hipMemcpyAsync(unit_order, bin.unit_order, sizeof(uint32_t) * ((size_t)bwd_units_cap((uint32_t)R, TileGrid{(uint32_t)gx, (uint32_t)gy}) + 2 * kOrderLists),
                                   hipMemcpyDeviceToDevice, s));
         }
         check_launch("export", s, false);
@@ -1615,7 +1615,7 @@ int r3dgs_export_tile_order(int P, int R, int width, int height, char* binning_b
 int r3dgs_bwd_units_cap(int R, int width, int height)
 {
     const int gx = (width + r3::kTile - 1) / r3::kTile, gy = (height + r3::kTile - 1) / r3::kTile;
-    return (int)r3::bwd_units_cap((uint32_t)(R > 0 ? R : 1), (size_t)gx * gy);
+    return (int)r3::bwd_units_cap((uint32_t)(R > 0 ? R : 1), r3::TileGrid{(uint32_t)gx, (uint32_t)gy});
 }
 
 }  // extern "C"

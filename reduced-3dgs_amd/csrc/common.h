@@ -266,16 +266,45 @@ constexpr int kFwdCkptMax = 256;       // checkpoints per tile at most (a pass m
 constexpr uint32_t kUnitTileBits = 20; // a unit word of the backward's launch order: tile | segment << 20 | segments << 26
 R3_HD size_t ckpt_slot(uint32_t first, uint32_t k, uint32_t tile, uint32_t seg_log2) { return (size_t)(first >> seg_log2) + tile + k; }
 inline size_t ckpt_slots(size_t R, size_t Tn) { return (R >> kBwdSegMinLog2) + Tn + 2; }
-// workgroups of the backward blend = capacity of its unit order: every tile once, plus the extra segments a pass may have
-// (bounded by the lists: sum over tiles of len / S <= R / S; capped -- a pass that wants more walks longer segments)
-constexpr uint32_t kOrderLists = 8;   // the unit order is kept as this many lists, each made by a workgroup of its own from every
-                                      // 8th tile; workgroup b of the backward blend takes entry b / 8 of list b % 8
-inline uint32_t bwd_units_cap(uint32_t reserve, size_t Tn)
+// The unit order of the backward blend is kept as kOrderLists lists, each made by a workgroup of its own; workgroup b of the
+// backward blend takes entry b / 8 of list b % 8, and the hardware deals consecutive workgroups over the eight XCDs -- list g
+// is what XCD g walks.  List g holds the kListBlock x kListBlock TILE BLOCKS g, g + 8, ... of the image (blocks row-major):
+// neighbouring tiles share most of their Gaussians, so a record is fetched into few L2s (as every 8th TILE per list the
+// kernel's FETCH_SIZE was 220 MB on the metric shape, as 4 x 4 blocks 162 MB, WRITE_SIZE 132 -> 119 MB; time equal or 0.5 %
+// better: profiles/r05_exp_list_blocks.txt), and 425 blocks dealt over 8 lists are still statistically alike tile sets.
+constexpr uint32_t kOrderLists = 8, kListBlock = 4, kListBlockTiles = kListBlock * kListBlock;
+struct TileGrid {
+    uint32_t gx, gy;
+    R3_HD size_t n() const { return (size_t)gx * gy; }
+    R3_HD uint32_t blocks_x() const { return (gx + kListBlock - 1) / kListBlock; }
+    R3_HD uint32_t blocks() const { return blocks_x() * ((gy + kListBlock - 1) / kListBlock); }
+    // slots of list `list` (a block at the image's edge has slots without a tile), and the tile of slot j (~0: none)
+    R3_HD uint32_t list_slots(uint32_t list) const
+    {
+        return blocks() > list ? (blocks() - list + kOrderLists - 1) / kOrderLists * kListBlockTiles : 0u;
+    }
+    R3_HD uint32_t list_tile(uint32_t list, uint32_t j) const
+    {
+        const uint32_t k = j / kListBlockTiles * kOrderLists + list, o = j % kListBlockTiles, bx = blocks_x();
+        const uint32_t tx = k % bx * kListBlock + o % kListBlock, ty = k / bx * kListBlock + o / kListBlock;
+        return tx < gx && ty < gy ? ty * gx + tx : 0xFFFFFFFFu;
+    }
+    // no list holds more tiles than this
+    R3_HD uint32_t list_tiles_max() const
+    {
+        const size_t m = (size_t)((blocks() + kOrderLists - 1) / kOrderLists) * kListBlockTiles;
+        return (uint32_t)(m < n() ? m : n());
+    }
+};
+// workgroups of the backward blend = capacity of its unit order: per list its tiles once, plus its share of the extra
+// segments a pass may have (bounded by the lists: sum over tiles of len / S <= R / S; capped -- a list that wants more
+// walks longer segments)
+R3_HD uint32_t bwd_list_fit(uint32_t pairs, const TileGrid& g)   // units a list may hold in a pass of `pairs` pairs
 {
-    const size_t extra = (size_t)reserve >> kBwdSegMinLog2;
-    const size_t cap = Tn + (extra < 8 * Tn ? extra : 8 * Tn);
-    return (uint32_t)((cap + kOrderLists - 1) / kOrderLists * kOrderLists + kOrderLists);   // a multiple of the list count
+    const size_t extra = (size_t)pairs >> kBwdSegMinLog2, most = 8 * g.n();
+    return g.list_tiles_max() + (uint32_t)((extra < most ? extra : most) / kOrderLists);
 }
+inline uint32_t bwd_units_cap(uint32_t reserve, const TileGrid& g) { return (bwd_list_fit(reserve, g) + 1u) * kOrderLists; }
 int bwd_segment_log2();         // R3DGS_BWD_SEG_LEN = 128 (default) | 256 -> 7 | 8; capi.hip
 int bwd_segment_factor_pct();   // R3DGS_BWD_SEG_FACTOR: lists >= this percentage of the pass's mean length are split (75)
 
@@ -303,8 +332,9 @@ struct BinState {
                                      // (blend.hip unit_order_kernel)
     float4* ckpt;                    // [ckpt_slots][256] forward checkpoints of the segmented tiles: (T, C0, C1, C2) per pixel
     char* end;
-    static BinState carve(char* base, size_t R, int wide, size_t Tn)
+    static BinState carve(char* base, size_t R, int wide, const TileGrid& grid)
     {
+        const size_t Tn = grid.n();
         Carver c(base);
         BinState b;
         b.point_list = c.take<uint32_t>(R);
@@ -332,7 +362,7 @@ struct BinState {
         b.radix_total = c.take<uint32_t>(kMaxRadixPasses * kMaxRadixBins);
         b.quad_masks = c.take<unsigned long long>((R / 64 + Tn + 2) * 4);
         b.block_first = c.take<uint32_t>(R / kRadixBlock + 2);
-        b.unit_order = c.take<uint32_t>((size_t)bwd_units_cap((uint32_t)R, Tn) + 2 * kOrderLists);
+        b.unit_order = c.take<uint32_t>((size_t)bwd_units_cap((uint32_t)R, grid) + 2 * kOrderLists);
         // LAST: only touched for the tiles a pass segments (32 B per pair + 4 KB per tile of address space)
         b.ckpt = c.take<float4>(ckpt_slots(R, Tn) * 256);
         b.end = c.p;

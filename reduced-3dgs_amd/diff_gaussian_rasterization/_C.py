@@ -777,7 +777,7 @@ def export_tile_order(H, W, imageBuffer, P=0, num_rendered=0, binningBuffer=None
         o = order.cpu().numpy().astype("int64") & 0xFFFFFFFF
         per = cap // _ORDER_LISTS
         lists = []
-        for g in range(_ORDER_LISTS):   # list g: made from the tiles g, g + 8, ...; consumed as entries b // 8 of list b % 8
+        for g in range(_ORDER_LISTS):   # list g: made from the 4 x 4 tile blocks g, g + 8, ...; consumed as entries b // 8 of list b % 8
             cnt, walk_log2 = int(o[cap + 2 * g]), int(o[cap + 2 * g + 1])
             u = o[g * per:g * per + cnt]
             lists.append(dict(tile=u & 0xFFFFF, segment=(u >> 20) & 63, segments=u >> 26, walk=(1 << walk_log2) if walk_log2 else 0))

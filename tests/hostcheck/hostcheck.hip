@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "../../reduced-3dgs_amd/csrc/blend_math.h"
-#include "../../reduced-3dgs_amd/csrc/gauss_math.h"
+#include "../../reduced-3dgs_amd/csrc/common.h"   // (includes gauss_math.h)
 
 using namespace r3;
 
@@ -468,6 +468,20 @@ void hc_preprocess_bwd(int P, int M, const int* degs, const float* means, const 
         }
         dL_dopacity[i] = opacity_backward(dL_dopacity[i], conic_op[4 * i + 3]);
     }
+}
+
+// The backward blend's unit lists (common.h TileGrid): tiles[j] = tile of slot j of list `list` (-1: a slot of an edge block
+// without a tile); info = {slots, list_tiles_max, bwd_list_fit(pairs), bwd_units_cap(reserve)}.  Returns the slot count.
+int hc_unit_list(int gx, int gy, int list, int* tiles, int tiles_cap, unsigned pairs, unsigned reserve, int* info)
+{
+    const TileGrid g{(uint32_t)gx, (uint32_t)gy};
+    const uint32_t n = g.list_slots((uint32_t)list);
+    for (uint32_t j = 0; j < n && (int)j < tiles_cap; j++) tiles[j] = (int)g.list_tile((uint32_t)list, j);
+    info[0] = (int)n;
+    info[1] = (int)g.list_tiles_max();
+    info[2] = (int)bwd_list_fit(pairs, g);
+    info[3] = (int)bwd_units_cap(reserve, g);
+    return (int)n;
 }
 
 }  // extern "C"

@@ -335,6 +335,25 @@ def test_reference_binning_mode_lists_are_the_references_bit_for_bit(C_, kw):
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-30, n
 
 
+def unit_list_tiles(g_, gx, gy, block=4, lists=8):
+    """Tiles of unit list g_ of the backward blend (common.h TileGrid): the block x block tile blocks g_, g_ + lists, ... of
+    the image (blocks row-major, tiles row-major inside a block, tiles outside the image left out)."""
+    bx, by = (gx + block - 1) // block, (gy + block - 1) // block
+    out = []
+    for k in range(g_, bx * by, lists):
+        for o in range(block * block):
+            tx, ty = k % bx * block + o % block, k // bx * block + o // block
+            if tx < gx and ty < gy:
+                out.append(ty * gx + tx)
+    return np.array(out, np.int64)
+
+
+def unit_list_fit(pairs, gx, gy, block=4, lists=8):
+    """Units a list may hold in a pass of `pairs` pairs (common.h bwd_list_fit)."""
+    bx, by = (gx + block - 1) // block, (gy + block - 1) // block
+    return min((bx * by + lists - 1) // lists * block * block, gx * gy) + min(pairs >> 7, 8 * gx * gy) // lists
+
+
 @pytest.mark.parametrize("kw", [
     dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02),
     dict(P=3_000, W=333, H=77, f=200.0, cam_seed=None, gseed=1, degree_mode="all3", scale_mu=0.05),
@@ -372,14 +391,15 @@ def test_backward_tile_order_changes_no_bit(C_, kw):
     assert np.array_equal(st["quad_depth"].cpu().numpy().astype(np.int64), want)
     units = st["units"]
     # one unit per tile that anything contributed to (tiles nothing reached are left out): the eight lists -- list g made of
-    # the tiles g, g + 8, ... -- together are a permutation of those tiles, each list by decreasing weight class
+    # the 4 x 4 tile blocks g, g + 8, ... -- together are a permutation of those tiles, each list by decreasing weight class
     assert np.all(units["segments"] == 1) and np.all(units["segment"] == 0)
     assert np.array_equal(np.sort(units["tile"]), np.nonzero(want.sum(axis=1) > 0)[0])
     for g_, l in enumerate(st["lists"]):
-        assert l["walk"] == 0 and np.all(l["tile"] % 8 == g_)
+        mine = unit_list_tiles(g_, gx, gy)
+        assert l["walk"] == 0 and np.all(np.isin(l["tile"], mine))
         weight = want.sum(axis=1)[l["tile"]]
         if len(weight):
-            top = max(int(want.sum(axis=1)[g_::8].max()), 1)
+            top = max(int(want.sum(axis=1)[mine].max()), 1)
             klass = (weight.astype(np.float64) * 1023.0 / top).astype(np.int64)   # the kernel's 1024 classes
             assert np.all(np.diff(klass) <= 1), "heavier classes must come first (one class of slack for the fp32 product)"
             assert weight[0] == weight.max()
@@ -419,12 +439,13 @@ def test_backward_list_segments(C_, name):
     length, deepest = rng_[:, 1] - rng_[:, 0], qd.max(axis=1)
     thr = max(256, int(fout[0].pairs) * 75 // len(length) // 100)   # R3DGS_BWD_SEG_FACTOR = 75 % of the mean list length
     Tn = len(length)
-    fit = (Tn + min(int(fout[0].pairs) >> 7, 8 * Tn)) // 8     # slots a list may use (from the pass's pair count)
-    assert fit <= int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H)) // 8
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    fit = unit_list_fit(int(fout[0].pairs), gx, gy)     # slots a list may use (from the pass's pair count)
+    assert fit < int(C_._lib.r3dgs_bwd_units_cap(fout[0].capacity, W, H)) // 8
     n_want = np.zeros(Tn, np.int64)
     n_units = 0
-    for g_, l in enumerate(st["lists"]):   # list g: the tiles g, g + 8, ...; the shortest segments whose units fit its slots
-        mine = np.arange(g_, Tn, 8)
+    for g_, l in enumerate(st["lists"]):   # list g: the tile blocks g, g + 8, ...; the shortest segments whose units fit its slots
+        mine = unit_list_tiles(g_, gx, gy)
         for walk in (128, 256, 512, 1024):
             n_g = np.where((length[mine] >= thr) & (deepest[mine] > walk), np.minimum((deepest[mine] + walk - 1) // walk, 32), 1)
             n_g[qd[mine].sum(axis=1) == 0] = 0
@@ -436,7 +457,7 @@ def test_backward_list_segments(C_, name):
         assert l["walk"] == walk
         assert len(l["tile"]) == n_g.sum()
         key = np.sort(l["tile"] * 64 + l["segment"])
-        assert np.array_equal(key, np.concatenate([[t * 64 + k for k in range(n)] for t, n in zip(mine, n_g) if n] or [[]]).astype(np.int64))
+        assert np.array_equal(key, np.sort(np.concatenate([[t * 64 + k for k in range(n)] for t, n in zip(mine, n_g) if n] or [[]]).astype(np.int64)))
         assert np.array_equal(l["segments"], n_want[l["tile"]])
         lo = l["segment"] * walk
         hi = np.where(l["segment"] + 1 < l["segments"], lo + walk, 1 << 40)

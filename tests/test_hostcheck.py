@@ -19,7 +19,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 def _lib():
-    hdrs = [os.path.join(HERE, "..", "reduced-3dgs_amd", "csrc", h) for h in ("gauss_math.h", "blend_math.h")]
+    hdrs = [os.path.join(HERE, "..", "reduced-3dgs_amd", "csrc", h) for h in ("gauss_math.h", "blend_math.h", "common.h")]
     newest = max(os.path.getmtime(p) for p in [SRC] + hdrs)
     if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
         if not os.path.exists(HIPCC):
@@ -290,3 +290,42 @@ def test_opacity_aware_rects_needle_scene(kw):
     bad, left = orc.culled_tile_violations(ref["state"], rects)
     assert bad == 0, f"{bad} pixels of left-out tiles would have been blended by the reference"
     assert left > 0.4 * ref["num_rendered"]
+
+
+def test_unit_lists_cover_every_tile_once():
+    """The backward blend's eight unit lists (common.h TileGrid: list g = the 4 x 4 tile blocks g, g + 8, ... of the image):
+    together every tile exactly once, none longer than list_tiles_max, the per-list fit of a pass below the per-list capacity
+    of any reservation that holds its pairs -- for grids with ragged edges, strips, and fewer blocks than lists."""
+    lib = _lib()
+    lib.hc_unit_list.restype = C.c_int
+    rng = np.random.default_rng(0)
+    shapes = [(1, 1), (1, 9), (9, 1), (3, 3), (4, 4), (5, 5), (8, 8), (100, 67), (120, 68), (129, 69), (7, 300), (1024, 1024)]
+    shapes += [tuple(int(v) for v in rng.integers(1, 200, 2)) for _ in range(20)]
+    for gx, gy in shapes:
+        Tn = gx * gy
+        seen = np.zeros(Tn, np.int64)
+        info = np.zeros(4, np.int32)
+        pairs = int(rng.integers(0, 40 * Tn + 1))
+        reserve = pairs + int(rng.integers(0, 3 * Tn + 1))
+        longest = 0
+        for g_ in range(8):
+            tiles = np.full(Tn + 16 * 8, -2, np.int32)
+            n = lib.hc_unit_list(gx, gy, g_, p(tiles), len(tiles), C.c_uint(pairs), C.c_uint(max(reserve, 1)), p(info))
+            t = tiles[:n]
+            assert n % 16 == 0 and np.all(t >= -1) and np.all(t < Tn)
+            valid = t[t >= 0]
+            np.add.at(seen, valid, 1)
+            longest = max(longest, len(valid))
+            # a block is 4 x 4 neighbouring tiles: the 16 slots of a block lie in one 4-aligned square
+            for b in range(n // 16):
+                v = t[16 * b:16 * b + 16]
+                v = v[v >= 0]
+                if len(v):
+                    assert len(set((v % gx) // 4)) == 1 and len(set((v // gx) // 4)) == 1
+                    k = (v[0] // gx // 4) * ((gx + 3) // 4) + (v[0] % gx) // 4
+                    assert k % 8 == g_ and k // 8 == b
+        assert np.all(seen == 1), (gx, gy)
+        slots, tiles_max, fit, cap = (int(v) for v in info)
+        assert longest <= tiles_max <= Tn
+        assert fit == tiles_max + min(pairs >> 7, 8 * Tn) // 8
+        assert cap % 8 == 0 and fit < cap // 8    # a list's units fit its slots whatever segment length it has to take
