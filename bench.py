@@ -81,7 +81,7 @@ STAGE_KERNELS = {
                      ("r3::radix_hist_kernel<", 1, False),
                      ("r3::tile_ranges_kernel<", 1, True)],
     "blend_fwd": [("r3::blend_fwd_kernel<1, false>", 1, True)],
-    # (the one-workgroup kernel that orders the tiles heaviest first runs inside this stage's events too)
+    # (the kernel that orders the backward's (tile, segment) units heaviest first runs inside this stage's events too)
     "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
                   ("r3::unit_order_kernel", 1, False)],
     "preprocess_bwd": [("r3::preprocess_bwd_kernel<", 1, False)],   # <dense degree-3 rows?, covariance chain in double?>
