@@ -687,14 +687,14 @@ extern "C" int r3dgs_debug_timeline(unsigned long long* host, int n)
 // the metric shape).  A unit is a tile, or one segment of a tile whose list is long and deep (common.h):
 // on a scene with the load of a real capture the heaviest tile walks three times the mean and the kernel was as long as
 // that walk.  Weight of a unit = sum over the four quadrants of the entries it will visit there (ImageState::quad_depth
-// clamped to the segment).  Tiles nothing contributed to are left out.  One workgroup, counting sort over 1024 weight
-// classes (64 classes: +2 us for the stage, 16: +10, 4: +22); the order inside a class is whatever the LDS atomics make it
-// -- every unit's arithmetic is its own, so the gradients do not depend on the order (tests/test_gpu_parity.py compares
-// the two orders bit for bit).  The hardware deals consecutive workgroups over the eight XCDs, i.e. every XCD gets every
-// eighth unit of the sorted list: equal work per XCD as well -- and every XCD's L2 now sees every Gaussian's record (the
-// kernel's FETCH_SIZE went from 62 to 150 MB; 1.6 TB/s in total, nowhere near a bound).  Keeping each XCD on its band of
-// the image and ordering inside the band only (FETCH_SIZE 74 MB) measured 0.315 ms against 0.305 ms for the stage: balance
-// between the XCDs is worth more here than the locality.
+// clamped to the segment).  Tiles nothing contributed to are left out.  Counting sort over 1024 weight classes (64
+// classes: +2 us for the stage, 16: +10, 4: +22), one workgroup per unit list (below); the order inside a class is whatever
+// the LDS atomics make it -- every unit's arithmetic is its own, so the gradients do not depend on the order
+// (tests/test_gpu_parity.py compares the two orders bit for bit).  The hardware deals consecutive workgroups over the eight
+// XCDs: as ONE sorted list every XCD got every eighth unit -- equal work per XCD, and every XCD's L2 saw every Gaussian's
+// record (FETCH_SIZE 62 -> 150 MB); keeping each XCD on a BAND of the image and ordering inside the band only (74 MB)
+// measured 0.315 ms against 0.305 ms for the stage.  The eight lists of 4 x 4 tile blocks (common.h TileGrid) are the
+// middle: each XCD walks blocks from all over the image, heaviest first, and neighbouring tiles stay on one XCD.
 constexpr int kOrderThreads = 1024, kOrderClasses = 1024;
 
 // segments of 2^walk entries the backward walks a tile in: 1 unless the forward left checkpoints for it (list length)

@@ -1411,8 +1411,10 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         bb.pair_grad = bin.pair_grad;
         bb.pair_flag = bin.pair_flag;
         bb.quad_masks = binning_buffer && keep_quad_masks() ? bin.quad_masks : nullptr;
-        // the unit order lives in the binning blob: a pass without one (no pair was reserved) has nothing to order
-        bb.tile_order = (heaviest_tiles_first() && plan.has_pairs) ? bin.unit_order : nullptr;
+        // the unit order lives in the binning blob: a pass without one (no pair was reserved) has nothing to order; a unit
+        // word holds kUnitTileBits of tile index (an image of more than 2^20 tiles -- 268 Mpix -- is walked row-major)
+        bb.tile_order = (heaviest_tiles_first() && plan.has_pairs && (size_t)plan.gx * plan.gy <= ((size_t)1 << kUnitTileBits))
+                            ? bin.unit_order : nullptr;
         bb.units_cap = plan.units_cap;
         bb.quad_depth = img.quad_depth;
         bb.ckpt = plan.has_pairs ? bin.ckpt : nullptr;
