@@ -341,6 +341,89 @@ void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* p
         }
 }
 
+// The backward blend walked in LIST SEGMENTS of S entries from the forward's checkpoints, pixel by pixel, with the kernels'
+// own per-lane functions and the kernels' own arithmetic for the state at a segment's end (blend.hip: blend_fwd_kernel parks
+// (T, C0, C1, C2) in front of entry k S of a tile's list and the colour it ends with; a unit of blend_bwd_kernel that ends in
+// front of a pixel's last contributor starts it from the checkpoint at its end).  A tile deeper than S is walked in
+// n = min(ceil(deepest contributor / S), max_seg) segments, the last one taking the rest; the segments run in ascending order
+// here (any order gives the same sums: every entry belongs to one segment).  acc as hc_blend_bwd; *n_split = pixels that
+// started at least one segment from a checkpoint.
+void hc_blend_bwd_segments(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
+                           const float* xy, const float* conic_op, const float* rgb, const float* final_T,
+                           const unsigned* n_contrib, const float* dL_dpix, double* acc, int S, int max_seg, long* n_split)
+{
+    (void)P;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const size_t plane = (size_t)W * H;
+    const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+    *n_split = 0;
+    std::vector<float> ck;   // checkpoints of one pixel: 4 floats per k >= 1
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
+            unsigned deepest = 0;
+            for (int py = ty * kTile; py < (ty + 1) * kTile && py < H; py++)
+                for (int px = tx * kTile; px < (tx + 1) * kTile && px < W; px++)
+                    deepest = n_contrib[(size_t)W * py + px] > deepest ? n_contrib[(size_t)W * py + px] : deepest;
+            unsigned nseg = deepest > (unsigned)S ? (deepest + (unsigned)S - 1u) / (unsigned)S : 1u;
+            if (nseg > (unsigned)max_seg) nseg = (unsigned)max_seg;
+            for (int py = ty * kTile; py < (ty + 1) * kTile && py < H; py++)
+                for (int px = tx * kTile; px < (tx + 1) * kTile && px < W; px++) {
+                    const size_t pix = (size_t)W * py + px;
+                    const unsigned last = n_contrib[pix];
+                    // the forward of this pixel, leaving its checkpoints
+                    FwdPix f;
+                    fwd_pix_init(f, true);
+                    ck.assign(4 * ((size_t)last / (size_t)S + 2), 0.f);
+                    for (unsigned pos = 0; pos < last; pos++) {
+                        if (pos != 0 && pos % (unsigned)S == 0) {
+                            float* c = &ck[4 * (pos / (unsigned)S)];
+                            c[0] = f.T; c[1] = f.C0; c[2] = f.C1; c[3] = f.C2;
+                        }
+                        const Splat s = splat_of(xy, conic_op, rgb, point_list[ranges[2 * tile] + pos]);
+                        float tb;
+                        fwd_step(s, (float)px, (float)py, pos + 1u, f, &tb);
+                    }
+                    const float g0 = dL_dpix[pix], g1 = dL_dpix[plane + pix], g2 = dL_dpix[2 * plane + pix];
+                    bool from_ckpt = false;
+                    for (unsigned k = 0; k < nseg; k++) {
+                        const unsigned lo = k * (unsigned)S;
+                        const unsigned hi = k + 1u < nseg ? lo + (unsigned)S : 0xFFFFFFFFu;
+                        if (lo >= last) break;
+                        BwdPix p;
+                        bwd_pix_init(p, final_T[pix], last, g0, g1, g2, bg[0] * g0 + bg[1] * g1 + bg[2] * g2);
+                        unsigned top = last;
+                        if (hi < last) {   // passes through this segment's end: blend_bwd_kernel's checkpoint start
+                            const float* c = &ck[4 * (hi / (unsigned)S)];
+                            p.A = ((f.C0 - c[1]) * p.g0 + (f.C1 - c[2]) * p.g1 + (f.C2 - c[3]) * p.g2 + p.T * p.A) * R3_RCP(c[0]);
+                            p.T = c[0];
+                            top = hi;
+                            from_ckpt = true;
+                        }
+                        for (long pos = (long)top - 1; pos >= (long)lo; pos--) {
+                            const unsigned id = point_list[ranges[2 * tile] + pos];
+                            const Splat s = splat_of(xy, conic_op, rgb, id);
+                            SplatGrad g;
+                            g.mx = g.my = g.cA = g.cB = g.cC = g.op = g.r = g.g = g.b = 0.f;
+                            if (bwd_step(s, (float)px, (float)py, (unsigned)pos, p, g)) {
+                                double* a = acc + 9 * (size_t)id;
+                                a[0] += (double)(g.mx * half_w);
+                                a[1] += (double)(g.my * half_h);
+                                a[2] += g.cA;
+                                a[3] += g.cB;
+                                a[4] += g.cC;
+                                a[5] += g.op;
+                                a[6] += g.r;
+                                a[7] += g.g;
+                                a[8] += g.b;
+                            }
+                        }
+                    }
+                    *n_split += from_ckpt ? 1 : 0;
+                }
+        }
+}
+
 // Fuzz the conservativeness of region_may_contribute(): random (also extremely anisotropic) splats against
 // random 8x8 pixel blocks; a violation = the pre-test says "skip" although some pixel's fwd_step would blend.
 // Returns the number of violations; *n_skip counts skipped blocks, *n_tight blocks kept with no contributor.

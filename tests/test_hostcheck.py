@@ -329,3 +329,56 @@ def test_unit_lists_cover_every_tile_once():
         assert longest <= tiles_max <= Tn
         assert fit == tiles_max + min(pairs >> 7, 8 * Tn) // 8
         assert cap % 8 == 0 and fit < cap // 8    # a list's units fit its slots whatever segment length it has to take
+
+
+@pytest.mark.parametrize("S,max_seg", [(128, 32), (256, 32), (128, 2)], ids=["S128", "S256", "S128_capped_at_2"])
+def test_backward_in_list_segments_from_forward_checkpoints(S, max_seg):
+    """The list split of the backward blend on the CPU (blend.hip: tiles with long lists are walked in segments of S entries
+    by several workgroups, each from the (T, accumulated colour) checkpoint the forward left at its end): the kernels' own
+    per-lane functions and the kernel's own start-from-checkpoint arithmetic, pixel by pixel, against the whole-list walk of
+    the same functions.  Every entry belongs to one segment, so the per-Gaussian sums must agree to rounding (the state at
+    a segment's end is the forward's running product and a colour difference instead of the backward's division chain);
+    a scene with lists several segments deep, the segment cap (the last segment takes the rest), and both against the
+    oracle's backward at the parity bar."""
+    L = _lib()
+    W, H, P = 64, 48, 8000
+    cam = ss.make_camera(W, H, 55.0, 3)
+    g = ss.make_gaussians(P, cam, seed=12, degree_mode="all0", scale_mu=0.03, zmin=2.0, zmax=6.0)
+    g["opacity"] -= 2.5    # weak entries: the pixels stay live deep into the lists
+    bg = np.array([0.2, 0.3, 0.1], np.float32)
+    out = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None, cam.world_view_transform,
+                      cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"], g["degrees"], cam.camera_center,
+                      want_ambig=True)
+    st = out["state"]
+    assert st["n_contrib"].max() > 3 * S or max_seg == 2, "the scene must have lists several segments deep"
+    N = W * H
+    amb = out["ambig"].reshape(-1) != 0
+    dl = (ss.upstream_grad(W, H, seed=9) * N).reshape(3, -1)
+    dl[:, amb] = 0.0    # (threshold-ambiguous pixels take no part in a comparison with the oracle)
+    dl = np.ascontiguousarray(dl.reshape(3, H, W))
+    args = (C.c_int(P), C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(bg), p(st["xy"]),
+            p(st["conic_op"]), p(st["rgb"]), p(st["final_T"]), p(st["n_contrib"]), p(dl))
+    whole = np.zeros((P, 9), np.float64)
+    L.hc_blend_bwd(*args, p(whole), C.c_int(0))
+    split = np.zeros((P, 9), np.float64)
+    n_split = C.c_long(0)
+    L.hc_blend_bwd_segments(*args, p(split), C.c_int(S), C.c_int(max_seg), C.byref(n_split))
+    assert n_split.value > 0.3 * N, "most pixels must pass through at least one segment end"
+    names = ["dmean2D.x", "dmean2D.y", "dconic.a", "dconic.b", "dconic.c", "dopacity", "dcolor.r", "dcolor.g", "dcolor.b"]
+    worst = 0.0
+    for k, n in enumerate(names):
+        scale = np.abs(whole[:, k]).max() + 1e-30
+        err = np.abs(split[:, k] - whole[:, k]).max() / scale
+        worst = max(worst, err)
+        assert err <= 2e-5, f"{n}: segments vs whole list {err:.2e} of the tensor's maximum"
+    assert worst > 0.0   # (it IS a different rounding: an exact match would mean nothing was started from a checkpoint)
+    gr = orc.backward(st, dl, 0.0)
+    for name, ref, got in (("dmean2D", gr["dL_dmeans2D"][:, :2], split[:, :2]), ("dconic", gr["dL_dconic"][:, [0, 1, 3]], split[:, 2:5]),
+                           ("dcolor", gr["dL_dcolors"], split[:, 6:9])):
+        err = np.abs(ref - got).max() / (np.abs(ref).max() + 1e-30)
+        assert err <= 1e-4, f"{name}: segment walk vs the oracle {err:.2e}"
+    # one segment per tile IS the whole-list walk (the double accumulators add the pixels tile by tile here, row by row there)
+    one = np.zeros((P, 9), np.float64)
+    L.hc_blend_bwd_segments(*args, p(one), C.c_int(1 << 20), C.c_int(max_seg), C.byref(n_split))
+    assert n_split.value == 0
+    np.testing.assert_allclose(one, whole, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
