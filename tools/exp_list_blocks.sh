@@ -1,7 +1,9 @@
 #!/bin/bash
 # One visit: the backward's eight unit lists as interleaved tiles (the build) against lists of 2x2 / 4x4 tile blocks (variants
 # libr3dgs_hip_blk2/blk4.so built from a patched unit_order_kernel): bench lines alternating, then FETCH_SIZE / WRITE_SIZE of
-# the backward blend kernel for each.
+# the backward blend kernel for each.  (Record of the experiment behind common.h kListBlock = 4; the variants were the tree of
+# that time with unit_order_kernel's tile_of() patched, built as tools/build_variant.py does.  To repeat it on today's tree: build
+# libr3dgs_hip_blk<N>.so with kListBlock = N in a copy of common.h; N = 1 is the every-eighth-tile assignment.)
 set -u
 mkdir -p gpurun_out
 export PYTHONPATH=$PWD:$PWD/reduced-3dgs_amd

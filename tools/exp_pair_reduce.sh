@@ -1,6 +1,8 @@
 #!/bin/bash
 # One visit: pair_reduce_kernel with the Gaussian id of every pair loaded up front (pr1), the slab rows loaded without
-# waiting for the flags (pr2), both (pr3), against the build: kernel traces of bench.py, alternating.
+# waiting for the flags (pr2), both (pr3), against the build: kernel traces of bench.py, alternating.  (Record of an experiment
+# that changed nothing -- profiles/r05_exp_pair_reduce_latency.txt; the variants were patched copies of preprocess_bwd.hip built
+# as tools/build_variant.py does and are not in the tree.)
 set -u
 mkdir -p gpurun_out
 export PYTHONPATH=$PWD:$PWD/reduced-3dgs_amd TMPDIR=/tmp
