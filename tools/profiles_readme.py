@@ -151,6 +151,7 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | `{R}_lane_utilisation.txt` | `tools/lane_utilisation.py` (CPU, the kernels' own per-lane functions): useful lanes per evaluated (entry, quadrant) pair of both blend kernels, and what a 4×4-granular pre-test with per-row lists would evaluate |
 | `{R}_kernel_resources.txt` | `tools/kernel_resources.py` (no GPU: the compiler's metadata for this tree's build): registers, static LDS, scratch and the waves per SIMD they allow, for every kernel of the library |
 | `{R}_exp_list_blocks.txt`, `{R}_exp_list_blocks2.txt` | `tools/exp_list_blocks.sh`, `tools/exp_list_blocks2.sh` (the follow-up on the final tree: 2×2 / 8×8 against the build's 4×4): the backward's unit lists as every eighth tile / 2×2 / 4×4 tile blocks, three builds alternating in one visit, with the blend kernels' `FETCH_SIZE` / `WRITE_SIZE` (4×4 is the build) |
+| `{R}_exp_unit_order.txt` | `tools/exp_unit_order.sh`: the unit order kernel without its first pass and with two instead of eight register slots per thread (variant builds, not in the tree): 12.7 → 11.4 → 7.5 µs |
 | `{R}_exp_pair_reduce_latency.txt`, `{R}_sweep_depth_bucket_load.txt` | one-visit A/Bs that changed nothing and are recorded as such: `pair_reduce` with its loads hoisted (one memory round trip instead of three), depth-sort bucket loads of 64 … 512 |
 | `{R}_valu_rate.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 25 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD, now with `v_fma_f64 / v_mul_f64 / v_add_f64` |
 | `{R}_gpu_tests.txt` | `pytest tests -m gpu -s`: every gradient distance measured (HIP vs the fp32 oracle, HIP vs the double evaluation, fp32 oracle vs the double evaluation, the fp32-chain mode, segments vs whole lists), the own-loop report |
