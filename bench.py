@@ -66,6 +66,42 @@ def stage_bytes(P, R, N, Tn, Kbar):
     }
 
 
+def own_stage_bytes(P, Pb, Rb, N, Tn, Kbar, word_bytes=4, key_bytes=4, passes=2, sh_ddir=True, sparsity=False):
+    """Bytes the BUILD's own algorithm has to move per launch of each stage -- the counterpart of
+    stage_bytes(), which prices the REFERENCE's algorithm: no 64-bit key sort, no per-Gaussian fills, the pairs this library
+    actually bins (Rb <= R, opacity-aware rects) and the Gaussians that own pairs (Pb <= P).  A stage's counter_bytes divided
+    by this is its wasted traffic; alg_GBps may exceed the HBM peak, own_alg_GBps cannot.
+      preprocess_fwd   read means 12 + scales 12 + rotations 16 + opacity 4; write the 48-B record, radius 4, depth key 4,
+                       rect 8, tiles 4
+      depth_sort_scan  histogram reads the key (4 P); scatter reads key + rect (12 P), writes one 16-B record (16 P); bucket sort
+                       reads it (16 P), writes order 4 + scan 4 + depth-ordered rect 8; the colour stream reads the SH row
+                       12 K + mean 12 + degree 4, writes 16 B into the record and (training forward) 36 B of direction derivatives
+      tile_binning     emission reads order + rect (12 Pb) and writes pair_start (4 Pb) and the pair words; every radix pass
+                       reads and writes the words, the second digit's histogram and the range kernel read the keys; ids end in
+                       point_list (the last pass writes them there), 1-byte flags cleared, 8 B per tile of ranges
+      blend_fwd        per list entry 4 (id) + 48 (record) once per tile + 32 B of region masks per 64 entries; per pixel 12
+                       colour + 4 T + 4 n_contrib written
+      blend_bwd        per list entry 4 + 48 + the masks read back; per pixel 12 dL + 4 T + 4 n_contrib read; per CONTRIBUTING
+                       pair a 48-B slab row written and read by pair_reduce (counted for every binned pair: an upper bound,
+                       ~45 % of them contribute) + its id 4 + flag 1; 48 B per Gaussian of sums written
+      preprocess_bwd   read mean 12, record 48, sums 48, tiles 4, radius 4, scale 12, rotation 16, degree 4, direction
+                       derivatives 36 (or the SH row 12 K with a sparsity term); write the nine outputs 12 K + 108"""
+    return {
+        "preprocess_fwd": P * 44 + P * 68,
+        "depth_sort_scan": P * (4 + 12 + 16 + 16 + 16) + P * (12 * Kbar + 16 + 16 + (36 if sh_ddir else 0)),
+        "tile_binning": Pb * 16 + Rb * (word_bytes + passes * 2 * word_bytes + 2 * key_bytes + 1) + Tn * 8,
+        "blend_fwd": Rb * 52.5 + N * 20,
+        "blend_bwd": Rb * 52.5 + N * 20 + Rb * (48 + 48 + 5) + Pb * 48,
+        "preprocess_bwd": P * (148 + (12 * Kbar if sparsity else 36)) + P * (12 * Kbar + 108),
+    }
+
+
+# the stages bound by VALU issue (DESIGN.md section 4): their speed of light is the calibrated issue floor of their main
+# kernel (pmc_valu), not a byte count; every other stage's is the bytes it has to move at the achievable HBM rate
+VALU_BOUND_STAGES = ("blend_fwd", "blend_bwd")
+HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s peak
+
+
 # kernels that make up each stage (name PREFIXES as rocprofv3 reports them, without arguments: the pair-word policy
 # IoNarrow / IoSplit / IoWide and the digit width depend on the workload), launches per stage, and whether the kernel's
 # loads are wide (16 B / lane): the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (x2) applies to those only.
@@ -88,13 +124,23 @@ STAGE_KERNELS = {
 }
 
 
+AMBIGUOUS_KERNELS = []   # prefixes that matched several instantiations of a table (reported in the bench line)
+
+
 def find_kernel(table, prefix):
-    """The entry of a {kernel name: ...} table whose name starts with `prefix` (exact name first), or None."""
+    """The entry of a {kernel name: ...} table whose name is `prefix`, else the ONE entry whose name starts with it.
+    Several matches (a PMC or kernel-stats file holding, say, digit widths 6 and 7 of radix_scatter_kernel, or both chain
+    instantiations of preprocess_bwd_kernel) are NOT resolved by picking one -- the counters of the wrong instantiation
+    would be cited silently: None is returned and the prefix is noted in AMBIGUOUS_KERNELS."""
     if prefix in table:
         return table[prefix]
-    for k in table:
-        if k.startswith(prefix):
-            return table[k]
+    hits = [k for k in table if k.startswith(prefix)]
+    if len(hits) == 1:
+        return table[hits[0]]
+    if len(hits) > 1:
+        if prefix not in AMBIGUOUS_KERNELS:
+            AMBIGUOUS_KERNELS.append(prefix)
+        return None
     renamed = {"r3::unit_order_kernel": "r3::tile_order_kernel"}   # name of the same kernel in the round-4 profiles
     if prefix in renamed:
         return find_kernel(table, renamed[prefix])
@@ -166,7 +212,7 @@ def committed_kernel_ms(kernel, path=None):
     return find_kernel(rows, kernel)
 
 
-def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):
+def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4, kernel_ms_events=None):
     """VALU-issue view of the stage's first (main) kernel from the committed PMC passes: the two blend kernels are bound
     by VALU issue, which an HBM fraction cannot express.  floor_ms = the time 1024 SIMDs need to
     issue the kernel's VALU instructions at the per-class rates measured by tools/valu_rate.hip.  The stage timer of this
@@ -187,6 +233,8 @@ def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):
     others = [committed_kernel_ms(n) for n, _, _ in STAGE_KERNELS[stage][1:]]
     committed = committed_kernel_ms(k)
     kernel_ms = stage_ms - sum(others) if (stage_ms and all(o is not None for o in others)) else stage_ms
+    if kernel_ms_events:   # round 6: the kernel alone between its own HIP events of THIS run (stage blend_bwd_kernel)
+        kernel_ms = kernel_ms_events
     out = {"kernel": k, "insts": int(c["SQ_INSTS_VALU"]),
            "insts_by_class": {n.replace("SQ_INSTS_VALU_", "").lower(): int(v) for n, v in classes.items()} | {"other": int(other)},
            "cycles_per_class": {n.replace("SQ_INSTS_VALU_", "").lower(): v for n, v in VALU_CYCLES.items()},
@@ -194,6 +242,8 @@ def pmc_valu(stage, workload, stage_ms, path=None, simds=1024, ghz=2.4):
            "kernel_ms_committed_profile": round(committed, 4) if committed else None,
            "frac": round(floor_ms / kernel_ms, 3) if kernel_ms else None,
            "frac_of_stage": round(floor_ms / stage_ms, 3) if stage_ms else None,
+           "kernel_ms_source": "HIP events around the kernel alone, this run" if kernel_ms_events else
+                               "this run's stage time minus the other kernels' committed averages",
            "assumes": f"{simds} SIMDs at {ghz} GHz", "source": f"{PMC_SUMMARY}, {VALU_RATE}"}
     if "SQ_ACTIVE_INST_VALU" in c:   # what the SQ itself reports per instruction (quad-cycles, per wave: >= 4)
         out["sq_active_cycles_per_inst"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2)
@@ -377,10 +427,14 @@ def main():
     # a second, untimed instrumented pass below and only the backward blend is timed here.
     dom_stage = os.environ.get("R3DGS_BENCH_DOM_STAGE", "blend_bwd")
     prof_mode = os.environ.get("R3DGS_BENCH_PROFILE", "dominant")  # dominant | all | off  (A/B of the timer cost)
+    # blend_bwd_kernel: the backward blend kernel ALONE (nested inside the blend_bwd stage's events) -> roofline.kernel_frac
+    stage_names = [_C._lib.r3dgs_profile_stage_name(k).decode() for k in range(_C._lib.r3dgs_profile_stage_count())]
+    timed_stages = [dom_stage] + (["blend_bwd_kernel"] if dom_stage == "blend_bwd" and "blend_bwd_kernel" in stage_names
+                                  else [])   # (an R3DGS_LIB=<older build> A/B run has no such timer)
     if prof_mode == "all":
         _C.profile_enable(True)
     elif prof_mode == "dominant":
-        _C.profile_enable(True, only=[dom_stage])
+        _C.profile_enable(True, only=timed_stages)
     _C.profile_read()
     overflow0 = _C.reserve_overflow_events()
     stats0 = _C.pass_stats()
@@ -468,8 +522,9 @@ def main():
         dist.all_reduce(t_o, op=dist.ReduceOp.MAX)
         overlapped_ms_per_step = 1e3 * float(t_o.item()) / args.steps
         overlap[0] = False
-    if prof_timed.get(dom_stage, (0, 0))[1]:
-        prof[dom_stage] = prof_timed[dom_stage]  # the roofline kernel's time is the one from the timed region
+    for st_ in timed_stages:
+        if prof_timed.get(st_, (0, 0))[1]:
+            prof[st_] = prof_timed[st_]  # the roofline kernel's time is the one from the timed region
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -517,41 +572,126 @@ def main():
                     "ms_per_step": round(1e3 * el_s / args.steps, 4),
                     "stages_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in prof_s.items() if cnt}}
 
+    # The configuration whose RESULTS are the reference's: the reference's 3-sigma tile squares
+    # (set_tight_rects(False): lists identical to rasterizer_impl.cu:78-117's) and its fp32 covariance chain
+    # (set_f64_chain(False): backward.cu:228-306, 311-374).  The same K steps, the same cameras; a second number, `value`
+    # stays the default mode.  (the driver's record then holds the rate of the mode a CUDA build can be
+    # compared with at 1e-4.)
+    reference_mode = None
+    if world == 1:
+        was_tight, was_f64 = _C.set_tight_rects(False), _C.set_f64_chain(False)
+        try:
+            with torch.no_grad():   # the longer lists' pair counts, per camera (and the reservation learns them)
+                for s_ in settings:
+                    _C.rasterize_gaussians(s_.bg, leaves["means3D"], empty, leaves["opacity"], leaves["scales"],
+                                           leaves["rotations"], 1.0, empty, s_.viewmatrix, s_.projmatrix, s_.tanfovx,
+                                           s_.tanfovy, H, W, leaves["sh"], degrees, s_.campos, False, False)
+            for i in range(max(args.warmup, 2 * len(settings))):
+                train_step(i)
+            torch.cuda.synchronize()
+            stats_r0 = _C.pass_stats()
+            ts0 = time.perf_counter()
+            for i in range(args.steps):
+                train_step(args.warmup + i)
+            e1 = torch.cuda.Event()
+            e1.record()
+            while not e1.query():
+                time.sleep(5e-5)
+            torch.cuda.synchronize()
+            el_r = time.perf_counter() - ts0
+            stats_r1 = _C.pass_stats()
+            _C.profile_enable(True)
+            _C.profile_read()
+            for i in range(min(args.steps, 20)):
+                train_step(args.warmup + i)
+            torch.cuda.synchronize()
+            prof_r = _C.profile_read()
+            _C.profile_enable(False)
+            reference_mode = {"tight_rects": _C.tight_rects(), "f64_covariance_chain": _C.f64_chain(),
+                              "value": round(args.steps / el_r, 2), "unit": "iters/s",
+                              "ms_per_step": round(1e3 * el_r / args.steps, 4),
+                              "passes": {k: stats_r1[k] - stats_r0[k] for k in ("reserved_passes", "exact_passes", "redone_passes")},
+                              "stages_ms": {k: round(ms / cnt, 4) for k, (ms, cnt) in prof_r.items() if cnt},
+                              "what": "same K steps and cameras with set_tight_rects(False) + set_f64_chain(False): the "
+                                      "reference's tile lists and fp32 covariance chain (the mode to compare a CUDA build with)"}
+        finally:
+            _C.set_tight_rects(was_tight)
+            _C.set_f64_chain(was_f64)
+
     used = [cam_index(args.warmup + i) for i in range(args.steps)]
     R_mean = float(np.mean([Rs[k] for k in used]))
     V_mean = float(np.mean([Vs[k] for k in used]))
     pairs_mean = float(np.mean([Ps[k] for k in used]))
     sb = stage_bytes(P, R_mean, N, Tn, Kbar)
+    id_bits, tile_bits = max(1, int(np.ceil(np.log2(max(P, 2))))), max(1, int(np.ceil(np.log2(max(Tn, 2)))))
+    word_bytes, key_bytes = (4, 4) if id_bits + tile_bits <= 32 else ((6, 2) if Tn <= 65536 else (8, 8))
+    own = own_stage_bytes(P, V_mean, pairs_mean, N, Tn, Kbar, word_bytes, key_bytes,
+                          passes=2 if tile_bits <= 14 else -(-tile_bits // 8))
+    kernel_ms_events = None   # the backward blend kernel alone, HIP events of the timed region
+    if prof.get("blend_bwd_kernel", (0, 0))[1]:
+        kernel_ms_events = prof["blend_bwd_kernel"][0] / prof["blend_bwd_kernel"][1]
     stages = {}
     for name, (ms, cnt) in prof.items():
-        if cnt:
+        if cnt and name != "blend_bwd_kernel":
             avg_ms = ms / cnt
             b = sb.get(name, 0)   # "sh_color" only exists as a stage of its own on the generic-sort path
             # alg_GBps: SURVEY 8d's reference-algorithm bytes of the stage / its time.  NOT a bandwidth: bytes the library
             # never moves (the reference's 64-bit key sort, its per-Gaussian fills) count, so it can exceed the HBM peak;
             # counter_GBps: the bytes the committed rocprofv3 counters of this workload saw move / this run's time
             tr = pmc_traffic(name, args.workload)
+            ob = own.get(name)
             stages[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt, "alg_bytes": int(b),
                             "alg_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1),
+                            # own_alg_*: the bytes THIS build's algorithm has to move (own_stage_bytes: pairs binned, no 64-bit
+                            # sort, no fills) -- a rate that cannot exceed the HBM peak; alg_* is the reference's algorithm
+                            "own_alg_bytes": int(ob) if ob is not None else None,
+                            "own_alg_GBps": round(ob / (avg_ms * 1e-3) / 1e9, 1) if ob is not None else None,
                             "counter_bytes": tr,
-                            "counter_GBps": round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr is not None else None}
+                            "counter_GBps": round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr is not None else None,
+                            "counter_over_own_alg": round(tr / ob, 2) if (tr is not None and ob) else None}
     dom = max(stages, key=lambda k: stages[k]["avg_ms"]) if stages else None
     roofline = None
     if dom:
         A = stages[dom]["alg_GBps"]
         traffic = pmc_traffic(dom, args.workload)
+        # kernel_frac: SURVEY 8d's bytes of the dominant KERNEL alone (R * 76 + N * 20 for the backward blend) over the
+        # kernel's own duration between HIP events of this run's timed region -- what a reader recomputes from the
+        # rocprofv3 kernel trace; frac: the whole stage's bytes over the stage's events (unit order + kernel + pair reduction)
+        kernel_alg = R_mean * 76 + N * 20 if dom == "blend_bwd" else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(A / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(A / HBM_PEAK_GBS, 4),
+                    "kernel_name": STAGE_KERNELS[dom][0][0] if dom in STAGE_KERNELS else None,
+                    "kernel_ms": round(kernel_ms_events, 4) if (kernel_ms_events and dom == "blend_bwd") else None,
+                    "kernel_alg_bytes": int(kernel_alg) if kernel_alg else None,
+                    "kernel_achieved": (round(kernel_alg / (kernel_ms_events * 1e-3) / 1e9, 1)
+                                        if (kernel_alg and kernel_ms_events and dom == "blend_bwd") else None),
+                    "kernel_frac": (round(kernel_alg / (kernel_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                    if (kernel_alg and kernel_ms_events and dom == "blend_bwd") else None),
+                    "traffic": traffic,
                     "traffic_source": (PMC_SUMMARIES[args.workload] + " (committed rocprofv3 --pmc passes of this command; "
                                        "not collected in this run)") if traffic is not None else None,
                     "traffic_collected_on_this_build": pmc_matches_build(pmc_path(args.workload)) if traffic is not None else None,
                     "duration_source": "HIP events around the stage on its stream, inside the timed region",
-                    "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"])}
+                    "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"],
+                                     kernel_ms_events=kernel_ms_events if dom == "blend_bwd" else None)}
     iters_per_s = args.steps * world / elapsed
     B_iter = P * (718 + 36 * Kbar) + R_mean * 280 + N * 40
     gpu_ms = sum(v["avg_ms"] for v in stages.values())
     per_stage_traffic = [pmc_traffic(k, args.workload) for k in STAGE_KERNELS]
     counter_bytes = int(sum(per_stage_traffic)) if all(t is not None for t in per_stage_traffic) else None
+    # speed of light of this build's own algorithm: the VALU-bound stages at the calibrated issue floor of their main
+    # kernel, every other stage at the bytes it has to move (own_stage_bytes) over the achievable HBM rate
+    sol_parts, sol_ok = {}, bool(stages)
+    for name in stages:
+        if name in VALU_BOUND_STAGES:
+            v_ = pmc_valu(name, args.workload, stages[name]["avg_ms"])
+            if v_ is None:
+                sol_ok = False
+            else:
+                sol_parts[name] = v_["floor_ms"]
+        elif stages[name]["own_alg_bytes"] is not None:
+            sol_parts[name] = stages[name]["own_alg_bytes"] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+    sol_ms = sum(sol_parts.values()) if sol_ok else None
     hs = sorted(host_ms)
     host = {"cpus_visible": os.cpu_count(), "cpus_effective": ncpu,
             "loadavg": [round(x, 1) for x in os.getloadavg()],
@@ -611,9 +751,19 @@ def main():
                           "counter_traffic_bytes": counter_bytes,
                           "frac_counter_traffic": (round(counter_bytes * iters_per_s / world / 8e12, 4)
                                                    if counter_bytes else None),
-                          "counter_traffic_source": PMC_SUMMARIES.get(args.workload) if counter_bytes else None},
+                          "counter_traffic_source": PMC_SUMMARIES.get(args.workload) if counter_bytes else None,
+                          # sum over the stages of: the VALU issue floor (blend kernels) / own-algorithm bytes at 6.3 TB/s
+                          "speed_of_light_ms": round(sol_ms, 4) if sol_ms else None,
+                          "speed_of_light_parts_ms": {k: round(v, 4) for k, v in sol_parts.items()} if sol_ms else None,
+                          "frac_of_speed_of_light": round(sol_ms / (1e3 * elapsed / args.steps), 3) if sol_ms else None,
+                          "own_alg_bytes": int(sum(v["own_alg_bytes"] or 0 for v in stages.values())),
+                          "speed_of_light_assumes": f"{HBM_ACHIEVABLE_GBS / 1e3} TB/s for the HBM-bound stages; "
+                                                    f"VALU floors from {PMC_SUMMARIES.get(args.workload)}"},
         "value_sh_sparsity": sparsity["value"] if sparsity else None,
         "sh_sparsity": sparsity,
+        "value_reference_mode": reference_mode["value"] if reference_mode else None,
+        "reference_mode": reference_mode,
+        "ambiguous_profile_kernels": AMBIGUOUS_KERNELS or None,
         "stages": stages,
         "stages_note": f"{dom_stage}: HIP events inside the timed region; other stages: separate instrumented pass",
         "host": host,

@@ -180,8 +180,12 @@ int r3dgs_set_f64_chain(int on);
 void r3dgs_forward_hint(int will_backward);
 
 /* r3dgs_set_bwd_segments(0): the backward blend walks every tile's list with ONE workgroup; 1 (default): a list of at
- * least max(256, the mean list length of the pass) entries is walked in segments of 128 by several workgroups, each starting from the per-pixel state the forward
- * blend checkpointed there (real scenes have tiles many times heavier than the mean).  The forward
+ * least thr = max(2 S, 75 % of the pass's mean list length) entries whose deepest contributor lies behind entry S is walked
+ * in ceil(deepest / S) segments (at most 32) of S = 128 entries by several workgroups, each starting from the per-pixel
+ * state the forward blend checkpointed there (real scenes have tiles many times heavier than the mean; DESIGN.md section
+ * 6).  A pass whose segments would exceed what it launches (tiles + min(pairs / 128, 8 x tiles) units) walks 2 S, 4 S or
+ * 8 S instead.  R3DGS_BWD_SEG_LEN=128|256 sets S, R3DGS_BWD_SEG_FACTOR=<percent> the factor (75); thr is written into the
+ * pass header by the forward (depth_sort.h, where the header is written; common.h bwd_segment_factor_pct).  The forward
  * and the backward of a state must run under the same setting only in the sense that a forward issued with segments off
  * leaves no checkpoints and its backward then never splits (the pass header says which).  Returns the previous setting (a
  * negative argument only queries).  Also R3DGS_BWD_SEG=0. */
@@ -256,7 +260,10 @@ int r3dgs_colour_variance_accumulate(int P, const int* D, int M, int max_sh_deg,
  * stage s.  A pass with a timed stage is issued with direct launches instead of its graph (the events sit between
  * its kernels), so time only what you need: bench.py times the dominant stage alone inside its timed region.
  * r3dgs_profile_read() waits for the recorded events, writes per-stage total milliseconds and launch counts
- * (arrays of r3dgs_profile_stage_count() entries, host memory) and resets the counters. */
+ * (arrays of r3dgs_profile_stage_count() entries, host memory) and resets the counters.
+ * Stages: preprocess_fwd, depth_sort_scan, tile_binning, blend_fwd, blend_bwd (unit order + blend kernel + pair
+ * reduction), preprocess_bwd, sh_color (generic-sort route only) and blend_bwd_kernel -- the backward blend kernel ALONE,
+ * nested inside blend_bwd's events (round 6: the duration a per-kernel roofline divides by). */
 int r3dgs_profile_enable(int on);
 int r3dgs_profile_stage_count(void);
 const char* r3dgs_profile_stage_name(int stage);

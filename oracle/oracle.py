@@ -58,7 +58,7 @@ TILE = 16
 
 def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modifier, cov3D_precomp,
             viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degrees, campos,
-            ragged=None, counter_mode=False, want_ambig=False, ambig_rel=1e-4, rects=None):
+            ragged=None, counter_mode=False, want_ambig=False, ambig_rel=1e-4, rects=None, geometry_only=False):
     """Oracle of `_C.rasterize_gaussians` (and `_variableSH_bands` when `ragged`
     = (coeffs_num, per_band_count, cumsum_count) and `sh` is the flat ragged buffer).
     Absent optional inputs: None or empty arrays.  Returns a dict with the public
@@ -66,7 +66,9 @@ def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modif
     `backward` / bit-exact binning checks (keys, point_list, ranges, n_contrib, final_T...).
     rects ([P,4] tile rects x0, y0, x1, y1 with exclusive maxima): bin every visible Gaussian into THAT rect instead of
     the reference's 3-sigma square (see orc_bin_rects); `culled_tile_violations` says whether the rects are admissible.
-    num_rendered stays the reference's count, state["pairs"] is the length of the lists."""
+    num_rendered stays the reference's count, state["pairs"] is the length of the lists.
+    geometry_only: stop after the per-Gaussian stage and the pair COUNT (radii, tiles_touched, depths, conics, colours and
+    num_rendered are valid; no lists, no image) -- what the 5 M / 6 M property tests compare element-wise."""
     L = lib()
     means3D = _f32(means3D)
     P = 0 if means3D is None else means3D.shape[0]
@@ -111,6 +113,9 @@ def forward(bg, means3D, colors_precomp, opacity, scales, rotations, scale_modif
                          _p(conic_op), _p(rgb), _p(clamped), _p(tiles))
         R = int(L.orc_bin(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),
                           None, None, None))
+    if P and geometry_only:
+        pairs = R
+    elif P:
         if rects is not None:
             rects = np.ascontiguousarray(rects, dtype=np.uint16).reshape(P, 4)
         pairs = int(L.orc_bin_rects(C.c_int(P), C.c_int(W), C.c_int(H), _p(radii), _p(xy), _p(depths), _p(tiles),

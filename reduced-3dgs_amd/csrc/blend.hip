@@ -713,12 +713,18 @@ __device__ __forceinline__ uint32_t unit_weight(const uint4& d, uint32_t s, uint
     return part(d.x) + part(d.y) + part(d.z) + part(d.w);
 }
 
+// KEEP: tiles a thread holds in registers between the passes.  Since the order became kOrderLists lists a thread of the metric
+// shape holds ONE tile (864 slots per list), and every further slot still issued its (clamped) loads and its unrolled counting
+// code: 12.7 us with eight slots, 7.5 with two (profiles/r05_exp_unit_order.txt); the launch takes the smallest that covers
+// the image's longest list (1: <= 1024 slots per list, i.e. up to ~8 k tiles; 2; 8: up to 64 k tiles, beyond that the
+// passes re-read).
+template <int KEEP>
 __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* dst, BwdPassArgs v)
 {
     __shared__ uint32_t s_count[kOrderClasses];
     __shared__ uint32_t s_scan[kOrderThreads / 64];
     constexpr int kWalks = 4;   // segment lengths a pass may walk: S, 2 S, 4 S, 8 S (the first whose units fit the launch)
-    __shared__ uint32_t s_max[kWalks + 1], s_units[kWalks];
+    __shared__ uint32_t s_max;
     const uint32_t tid = threadIdx.x, lane_id = tid & 63u;
     if (blockIdx.x == 0) install_block_from_kernarg(dst, (int)tid, kOrderThreads);   // first kernel of the backward: the pass block
     // One workgroup per LIST: workgroup g orders the tiles of list g (common.h TileGrid: the 4 x 4 tile blocks g, g + lists, ...
@@ -738,23 +744,17 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     const uint32_t seg_log2 = (v.blend.segments != 0 && v.blend.ckpt != nullptr && all_tiles <= (1u << kUnitTileBits))
                                   ? v.blend.hdr->ckpt : 0u;   // 0: the forward left no checkpoints / segments are off
     const uint32_t thr = seg_log2 ? v.blend.hdr->ckpt_thr : 0xFFFFFFFFu;
-    // Units of the shortest segments: every tile once plus at most (list length / S) more, i.e. <= tiles + pairs / S.  Only a
-    // pass whose lists are so long that this exceeds what it may launch has to look at longer segments.  (The bound is taken
-    // from the pass's pair count, not from the capacity its binning blob happens to have: the exact-size path and the
-    // reserved path of one view then walk the same segments and give the same bits.)
-    const uint32_t pairs_s = v.blend.hdr->num_pairs >> kBwdSegMinLog2;
+    // Units a list may hold.  The bound is taken from the pass's pair count, not from the capacity its binning blob happens
+    // to have: the exact-size path and the reserved path of one view then walk the same segments and give the same bits.
     const uint32_t fit = bwd_list_fit(v.blend.hdr->num_pairs, grid);   // <= cap: the reservation holds the pairs
-    const bool always_fits = grid.list_tiles_max() + pairs_s <= fit;   // (a pass with fewer than 8 S pairs)
     s_count[tid] = 0u;
-    if (tid <= kWalks) s_max[tid] = 0u;
-    if (tid < kWalks) s_units[tid] = 0u;
+    if (tid == 0) s_max = 0u;
     __syncthreads();
-    // up to kOrderKeep tiles per thread stay in registers between the passes (one memory round trip instead of four: the
+    // up to KEEP tiles per thread stay in registers between the passes (one memory round trip instead of four: the
     // kernel is a chain of latencies, 9.5 us when every pass went back to memory); a larger grid re-reads
-    constexpr int kOrderKeep = 8;
-    const bool keep = n_tiles <= (uint32_t)(kOrderKeep * kOrderThreads);
-    uint4 w[kOrderKeep];
-    uint32_t len[kOrderKeep], tl[kOrderKeep];   // weights, list length and tile of the kept slots
+    const bool keep = n_tiles <= (uint32_t)(KEEP * kOrderThreads);
+    uint4 w[KEEP];
+    uint32_t len[KEEP], tl[KEEP];   // weights, list length and tile of the kept slots
     auto load = [&](uint32_t t, uint4& d, uint32_t& l) {
         d = make_uint4(0u, 0u, 0u, 0u);
         l = 0u;
@@ -767,97 +767,22 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     };
     if (keep) {
         // every load in flight before the first use (written as `load` per tile the compiler reused one register pair for the
-        // ranges and waited for each of the eight loads in turn: 12 us of the kernel's 22)
-        uint2 rr[kOrderKeep];
+        // ranges and waited for each of the loads in turn: 12 us of the kernel's 22)
+        uint2 rr[KEEP];
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
+        for (int k = 0; k < KEEP; k++) {
             const uint32_t j = tid + (uint32_t)(k * kOrderThreads);
             tl[k] = j < n_tiles ? tile_of(j) : 0xFFFFFFFFu;
             w[k] = qd[min(tl[k], all_tiles - 1u)];
             rr[k] = ranges[min(tl[k], all_tiles - 1u)];
         }
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
+        for (int k = 0; k < KEEP; k++) {
             const bool in = tl[k] != 0xFFFFFFFFu;
             if (!in) w[k] = make_uint4(0u, 0u, 0u, 0u);
             len[k] = in ? rr[k].y - rr[k].x : 0u;
         }
     }
-    uint32_t walk = seg_log2;
-    if (seg_log2 && !always_fits) {
-        // pass 0 (rare: tens of millions of pairs): units of every candidate segment length
-        uint32_t units[kWalks];
-#pragma unroll
-        for (int m = 0; m < kWalks; m++) units[m] = 0u;
-        auto look = [&](const uint4& d, uint32_t l) {
-            if (d.x + d.y + d.z + d.w == 0u) return;
-            const uint32_t deepest = max(max(d.x, d.y), max(d.z, d.w));
-#pragma unroll
-            for (int m = 0; m < kWalks; m++) units[m] += unit_segments(l, deepest, thr, seg_log2 + m);
-        };
-        if (keep) {
-#pragma unroll
-            for (int k = 0; k < kOrderKeep; k++) look(w[k], len[k]);
-        } else {
-            for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
-                uint4 d;
-                uint32_t l;
-                load(t, d, l);
-                look(d, l);
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int m = 0; m < kWalks; m++) units[m] += (uint32_t)__shfl_xor((int)units[m], off);
-        if (lane_id == 0u)
-#pragma unroll
-            for (int m = 0; m < kWalks; m++) atomicAdd(&s_units[m], units[m]);
-        __syncthreads();
-        int m = 0;
-        while (m < kWalks && s_units[m] > fit) m++;
-        walk = m < kWalks ? seg_log2 + (uint32_t)m : 0u;   // none fits: whole tiles
-    }
-    auto segs = [&](const uint4& d, uint32_t l) -> uint32_t {
-        if (d.x + d.y + d.z + d.w == 0u) return 0u;   // nothing contributed to this tile: no unit
-        return walk ? unit_segments(l, max(max(d.x, d.y), max(d.z, d.w)), thr, walk) : 1u;
-    };
-    // Leading segments of a split tile that all four quadrants walk in full: they all weigh 4 x the segment length -- one
-    // class, thousands of units in a deep scene, and one LDS counter they would all queue on (the kernel took 52 us at
-    // 2 M Gaussians that way).  A tile's FULL segments are therefore counted and placed as a group, and the groups of the
-    // tiles a wave holds at the same step add up among themselves (a shuffle scan): one atomic per wave and step.
-    auto full_segments = [&](const uint4& d, uint32_t n) -> uint32_t {
-        if (n <= 1u) return 0u;
-        const uint32_t f = min(min(d.x, d.y), min(d.z, d.w)) >> walk;
-        return min(f, n == (uint32_t)kBwdSegMax ? n - 1u : n);   // (a capped tile's last segment takes the rest: not "full")
-    };
-    // The heaviest unit.  A pass that splits knows a bound without looking: a whole tile is shorter than `thr` entries (or it
-    // would be split) and no deeper than its list, a segment weighs at most 4 x its length -- only the last segment of a tile
-    // capped at kBwdSegMax can be heavier, and lands in the heaviest class.  Without segments: one more pass over the tiles.
-    if (walk) {
-        if (tid == 0) s_max[0] = max(4u << walk, 4u * min(thr, 1u << 20));
-    } else {
-        uint32_t kmax = 0u;
-        if (keep) {
-#pragma unroll
-            for (int k = 0; k < kOrderKeep; k++) kmax = max(kmax, w[k].x + w[k].y + w[k].z + w[k].w);
-        } else {
-            for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
-                uint4 d;
-                uint32_t l;
-                load(t, d, l);
-                kmax = max(kmax, d.x + d.y + d.z + d.w);
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
-        if (lane_id == 0u) atomicMax(&s_max[0], kmax);
-    }
-    __syncthreads();
-    const float scale = (float)(kOrderClasses - 1) / (float)max(s_max[0], 1u);
-    // class 0 = the heaviest
-    auto klass = [&](uint32_t wt) {
-        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)wt * scale), (uint32_t)(kOrderClasses - 1));
-    };
-    const uint32_t full_class = klass(4u << walk);
     auto wave_prefix = [&](uint32_t x, uint32_t* total) {   // exclusive prefix and total of x over the wave
         uint32_t incl = x;
         for (int off = 1; off < 64; off <<= 1) {
@@ -867,64 +792,127 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
         *total = (uint32_t)__shfl((int)incl, 63);
         return incl - x;
     };
-    // (the kernel runs on ONE compute unit and is bound by its vector-instruction issue -- 2700 instructions per wave, 16
-    // waves, integer min / max at half rate: 19 us -- so nothing is worked out twice: segment counts and the classes of a
-    // tile's first three partial segments wait in registers for the placement pass)
+    // (the kernel runs on ONE compute unit per list and is bound by its vector-instruction issue -- integer min / max at half
+    // rate -- so nothing is worked out twice: segment counts and the classes of a tile's first three partial segments wait in
+    // registers for the placement pass)
     constexpr uint32_t kCached = 3u;
-    // (a) the partial units of a tile: one LDS atomic each; (b) its full segments: the lanes of a wave add theirs up (one
-    // shuffle scan per pass over the sum of a thread's tiles) and send one atomic.  Measured: loads 5.6 us, counting 5.5, scan
-    // 1.0, placing 6.9 with a scan per tile.
-    auto count_partials = [&](const uint4& d, uint32_t n, uint32_t f, uint32_t* classes) {
-        uint32_t packed = 0u;
-        for (uint32_t k = f; k < n; k++) {
-            const uint32_t c = klass(unit_weight(d, k, n, walk));
-            atomicAdd(&s_count[c], 1u);
-            if (k - f < kCached) packed |= c << (10u * (k - f));
-        }
-        *classes = packed;
-    };
-    uint32_t nf[kOrderKeep], pc[kOrderKeep];   // segments | full segments << 8, and the cached classes, of the kept tiles
-    if (keep) {
-        uint32_t fsum = 0u, total;
+    uint32_t nf[KEEP], pc[KEEP];   // segments | full segments << 8, and the cached classes, of the kept tiles
+    // The segment length is settled by TRYING: the counting pass runs with the shortest segments (2^seg_log2 entries) and its
+    // class scan says how many units that makes; only a pass whose lists are so long that they exceed what the list may
+    // launch (tens of millions of pairs: fit = tiles + min(pairs / S, 8 tiles) / lists) counts again with 2 S, 4 S, 8 S and
+    // finally whole tiles.  (Round 5 counted the units of all four candidate lengths in a pass of their own before the
+    // counting pass, on every backward: 1.3 of the kernel's 12.7 us)
+    uint32_t walk = seg_log2, total_units = 0u, full_class = 0u;
+    float scale = 0.f;
+    for (;;) {
+        // The heaviest unit.  A pass that splits knows a bound without looking: a whole tile is shorter than `thr` entries (or it
+        // would be split) and no deeper than its list, a segment weighs at most 4 x its length -- only the last segment of a tile
+        // capped at kBwdSegMax can be heavier, and lands in the heaviest class.  Without segments: one more pass over the tiles.
+        uint32_t heaviest;
+        if (walk) {
+            heaviest = max(4u << walk, 4u * min(thr, 1u << 20));
+        } else {
+            uint32_t kmax = 0u;
+            if (keep) {
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
-            const uint32_t n = segs(w[k], len[k]), f = full_segments(w[k], n);
-            nf[k] = n | (f << 8);
-            fsum += f;
-            count_partials(w[k], n, f, &pc[k]);
+                for (int k = 0; k < KEEP; k++) kmax = max(kmax, w[k].x + w[k].y + w[k].z + w[k].w);
+            } else {
+                for (uint32_t t = tid; t < n_tiles; t += kOrderThreads) {
+                    uint4 d;
+                    uint32_t l;
+                    load(t, d, l);
+                    kmax = max(kmax, d.x + d.y + d.z + d.w);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+            if (lane_id == 0u) atomicMax(&s_max, kmax);
+            __syncthreads();
+            heaviest = s_max;
         }
-        wave_prefix(fsum, &total);
-        if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
-    } else {
-        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {   // uniform trip count: the wave scan needs every lane
-            uint4 d;
-            uint32_t l, unused, total;
-            load(t0 + tid, d, l);
-            const uint32_t n = segs(d, l), f = full_segments(d, n);
-            count_partials(d, n, f, &unused);
-            wave_prefix(f, &total);
+        scale = (float)(kOrderClasses - 1) / (float)max(heaviest, 1u);
+        // class 0 = the heaviest
+        auto klass = [&](uint32_t wt) {
+            return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)wt * scale), (uint32_t)(kOrderClasses - 1));
+        };
+        full_class = klass(4u << walk);
+        auto segs = [&](const uint4& d, uint32_t l) -> uint32_t {
+            if (d.x + d.y + d.z + d.w == 0u) return 0u;   // nothing contributed to this tile: no unit
+            return walk ? unit_segments(l, max(max(d.x, d.y), max(d.z, d.w)), thr, walk) : 1u;
+        };
+        // Leading segments of a split tile that all four quadrants walk in full: they all weigh 4 x the segment length -- one
+        // class, thousands of units in a deep scene, and one LDS counter they would all queue on (the kernel took 52 us at
+        // 2 M Gaussians that way).  A tile's FULL segments are therefore counted and placed as a group, and the groups of the
+        // tiles a wave holds at the same step add up among themselves (a shuffle scan): one atomic per wave and step.
+        auto full_segments = [&](const uint4& d, uint32_t n) -> uint32_t {
+            if (n <= 1u) return 0u;
+            const uint32_t f = min(min(d.x, d.y), min(d.z, d.w)) >> walk;
+            return min(f, n == (uint32_t)kBwdSegMax ? n - 1u : n);   // (a capped tile's last segment takes the rest: not "full")
+        };
+        // (a) the partial units of a tile: one LDS atomic each; (b) its full segments: the lanes of a wave add theirs up (one
+        // shuffle scan per pass over the sum of a thread's tiles) and send one atomic.
+        auto count_partials = [&](const uint4& d, uint32_t n, uint32_t f, uint32_t* classes) {
+            uint32_t packed = 0u;
+            for (uint32_t k = f; k < n; k++) {
+                const uint32_t c = klass(unit_weight(d, k, n, walk));
+                atomicAdd(&s_count[c], 1u);
+                if (k - f < kCached) packed |= c << (10u * (k - f));
+            }
+            *classes = packed;
+        };
+        if (keep) {
+            uint32_t fsum = 0u, total;
+#pragma unroll
+            for (int k = 0; k < KEEP; k++) {
+                const uint32_t n = segs(w[k], len[k]), f = full_segments(w[k], n);
+                nf[k] = n | (f << 8);
+                fsum += f;
+                count_partials(w[k], n, f, &pc[k]);
+            }
+            wave_prefix(fsum, &total);
             if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
+        } else {
+            for (uint32_t t0 = 0; t0 < n_tiles; t0 += kOrderThreads) {   // uniform trip count: the wave scan needs every lane
+                uint4 d;
+                uint32_t l, unused, total;
+                load(t0 + tid, d, l);
+                const uint32_t n = segs(d, l), f = full_segments(d, n);
+                count_partials(d, n, f, &unused);
+                wave_prefix(f, &total);
+                if (lane_id == 0u && total) atomicAdd(&s_count[full_class], total);
+            }
         }
+        __syncthreads();
+        // exclusive scan of the class counts (one class per thread)
+        const uint32_t mine = s_count[tid];
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if (lane_id >= (uint32_t)off) incl += up;
+        }
+        if (lane_id == 63u) s_scan[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0u;
+        total_units = 0u;
+        for (uint32_t k = 0; k < (uint32_t)(kOrderThreads / 64); k++) {
+            const uint32_t c = s_scan[k];
+            if (k < (tid >> 6)) before += c;
+            total_units += c;
+        }
+        __syncthreads();
+        const bool fits = walk == 0u || total_units <= fit;   // the same for every thread
+        s_count[tid] = fits ? before + incl - mine : 0u;       // first slot of the class, then its cursor / cleared for the retry
+        if (tid == 0) s_max = 0u;
+        __syncthreads();
+        if (fits) break;
+        walk = walk + 1u < seg_log2 + (uint32_t)kWalks ? walk + 1u : 0u;   // longer segments; none fits: whole tiles
     }
-    __syncthreads();
-    // exclusive scan of the class counts (one class per thread)
-    const uint32_t mine = s_count[tid];
-    uint32_t incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-        if (lane_id >= (uint32_t)off) incl += up;
+    if (tid == 0) {
+        trailer[0] = total_units;   // the units of this list (<= cap by the choice of `walk`; whole tiles: <= list_tiles_max)
+        trailer[1] = walk;          // log2 of the segment length they walk (0: whole tiles)
     }
-    if (lane_id == 63u) s_scan[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t before = 0u;
-    for (uint32_t k = 0; k < (tid >> 6); k++) before += s_scan[k];
-    __syncthreads();
-    s_count[tid] = before + incl - mine;   // first slot of the class, then its cursor
-    if (tid == kOrderThreads - 1) {
-        trailer[0] = before + incl;   // the units of this list (<= cap by the choice of `walk`; whole tiles: <= list_tiles_max)
-        trailer[1] = walk;            // log2 of the segment length they walk (0: whole tiles)
-    }
-    __syncthreads();
+    auto klass = [&](uint32_t wt) {
+        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)((float)wt * scale), (uint32_t)(kOrderClasses - 1));
+    };
     auto place = [&](uint32_t tile, const uint4& d, uint32_t n, uint32_t f, uint32_t base, uint32_t classes, bool cached) {
         const uint32_t word = tile | (n << (kUnitTileBits + 6u));
         for (uint32_t k = 0; k < f; k++) order[base + k] = word | (k << kUnitTileBits);
@@ -944,10 +932,10 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
     if (keep) {
         uint32_t fsum = 0u;
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) fsum += nf[k] >> 8;
+        for (int k = 0; k < KEEP; k++) fsum += nf[k] >> 8;
         uint32_t base = full_base(fsum);
 #pragma unroll
-        for (int k = 0; k < kOrderKeep; k++) {
+        for (int k = 0; k < KEEP; k++) {
             place(tl[k], w[k], nf[k] & 255u, nf[k] >> 8, base, pc[k], true);
             base += nf[k] >> 8;
         }
@@ -956,7 +944,13 @@ __global__ __launch_bounds__(kOrderThreads) void unit_order_kernel(BwdPassArgs* 
             uint4 d;
             uint32_t l;
             load(t0 + tid, d, l);
-            const uint32_t n = segs(d, l), f = full_segments(d, n);
+            const uint32_t n = d.x + d.y + d.z + d.w == 0u ? 0u
+                               : (walk ? unit_segments(l, max(max(d.x, d.y), max(d.z, d.w)), thr, walk) : 1u);
+            uint32_t f = 0u;
+            if (n > 1u) {
+                f = min(min(d.x, d.y), min(d.z, d.w)) >> walk;
+                f = min(f, n == (uint32_t)kBwdSegMax ? n - 1u : n);
+            }
             place(t0 + tid < n_tiles ? tile_of(t0 + tid) : 0u, d, n, f, full_base(f), 0u, false);
         }
     }
@@ -967,12 +961,25 @@ static void launch_bwd(uint32_t nblocks, uint32_t units_cap, BwdPassArgs* dst, c
 {
     if (v.blend.tile_order) {
         static const int lds_pad = env_int("R3DGS_BWD_LDS_PAD", 0, 0, 65536);
-        hipLaunchKernelGGL(unit_order_kernel, dim3(kOrderLists), dim3(kOrderThreads), 0, s, dst, v);
         // one workgroup per unit the pass MAY have (those beyond its count leave at once)
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, false>), dim3(units_cap), dim3(64), lds_pad, s, dst, v);
     } else {
         hipLaunchKernelGGL((blend_bwd_kernel<4, REUSE, true>), dim3(nblocks), dim3(64), 0, s, dst, v);
     }
+}
+
+// the launch order of the backward blend's units (and the pass block: this is then the first kernel of the backward)
+void issue_unit_order(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)
+{
+    if (!v.blend.tile_order) return;
+    // slots of the longest list decide how many tiles a thread of the order kernel keeps in registers
+    const uint32_t slots = TileGrid{(uint32_t)p.gx, (uint32_t)p.gy}.list_slots(0);
+    if (slots <= (uint32_t)kOrderThreads)
+        hipLaunchKernelGGL(unit_order_kernel<1>, dim3(kOrderLists), dim3(kOrderThreads), 0, s, dst, v);
+    else if (slots <= 2u * (uint32_t)kOrderThreads)
+        hipLaunchKernelGGL(unit_order_kernel<2>, dim3(kOrderLists), dim3(kOrderThreads), 0, s, dst, v);
+    else
+        hipLaunchKernelGGL(unit_order_kernel<8>, dim3(kOrderLists), dim3(kOrderThreads), 0, s, dst, v);
 }
 
 void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s)

@@ -195,7 +195,7 @@ struct Profiler {
     }
 } g_prof;
 constexpr unsigned kFwdStages = (1u << kPre) | (1u << kDepthSort) | (1u << kBinning) | (1u << kBlendFwd) | (1u << kColor);
-constexpr unsigned kBwdStages = (1u << kBlendBwd) | (1u << kPreBwd);
+constexpr unsigned kBwdStages = (1u << kBlendBwd) | (1u << kPreBwd) | (1u << kBlendBwdKernel);
 
 struct StageRun {   // direct-issue mode: events and / or debug synchronisation around each stage
     bool debug;
@@ -555,7 +555,10 @@ void issue_backward(const BwdPlan& p, BwdPassArgs* d, const BwdPassArgs& args, h
     // the pair flags are all zero here: the forward's tile_ranges kernel clears them and pair_reduce puts every
     // flag it consumed back to zero, so neither pass pays for a fill of its own
     if (p.has_pairs) {
+        issue_unit_order(p, d, args, s);
+        h.begin(kBlendBwdKernel, s);
         issue_blend_backward(p, d, args, s);
+        h.end(kBlendBwdKernel, "blend backward kernel", s);
         issue_pair_reduce(p, &d->reduce, s);
     } else {
         launch_write_args(d, args, s);
@@ -1532,7 +1535,7 @@ int r3dgs_profile_stage_count(void) { return kNumStages; }
 const char* r3dgs_profile_stage_name(int stage)
 {
     static const char* names[kNumStages] = {"preprocess_fwd", "depth_sort_scan", "tile_binning", "blend_fwd",
-                                            "blend_bwd",      "preprocess_bwd",  "sh_color"};
+                                            "blend_bwd",      "preprocess_bwd",  "sh_color",        "blend_bwd_kernel"};
     return (stage >= 0 && stage < kNumStages) ? names[stage] : "";
 }
 

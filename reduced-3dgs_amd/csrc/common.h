@@ -726,7 +726,9 @@ struct BwdPlan {
 };
 
 // stage ids of the optional per-stage timers (capi.hip)
-enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kNumStages };
+// kBlendBwdKernel: the backward blend kernel ALONE, inside kBlendBwd's events (which also cover the unit order and the pair
+// reduction): the duration bench.py's roofline.kernel_frac divides by
+enum Stage { kPre = 0, kDepthSort, kBinning, kBlendFwd, kBlendBwd, kPreBwd, kColor, kBlendBwdKernel, kNumStages };
 
 // ---- per-stage issue functions (one per translation unit).  `a` points INTO the device pass block. ----------------
 // The first kernel of a pass also installs the pass block: it receives the block BY VALUE (its workgroups read their own
@@ -746,7 +748,8 @@ void launch_export_keys(int P, int R, int cap, size_t n_tiles, const BinState& b
 void launch_export_point_list(int count, const uint32_t* point_list, const GeomHeader* hdr, uint32_t* out, hipStream_t s);
 
 void issue_blend_forward(const FwdPlan& p, const BlendFwdArgs* a, hipStream_t s);
-void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s);   // installs the block too
+void issue_unit_order(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s);   // installs the block (if it runs)
+void issue_blend_backward(const BwdPlan& p, BwdPassArgs* dst, const BwdPassArgs& v, hipStream_t s);   // installs the block otherwise
 void issue_pair_reduce(const BwdPlan& p, const PairReduceArgs* a, hipStream_t s);
 void issue_preprocess_backward(const BwdPlan& p, const PreBwdArgs* a, hipStream_t s);
 

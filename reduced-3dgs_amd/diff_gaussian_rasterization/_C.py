@@ -744,8 +744,9 @@ def tile_order():
 
 
 def set_bwd_segments(on):
-    """True (default): the backward blend walks a long tile list (>= 768 entries) in segments of 256, several workgroups per
-    tile, from checkpoints the forward leaves; False: one workgroup per tile.  Gradients agree to rounding (the state at a
+    """True (default): the backward blend walks a long tile list -- at least max(2 S, 75 % of the pass's mean list length)
+    entries, S = 128 (R3DGS_BWD_SEG_LEN, R3DGS_BWD_SEG_FACTOR; include/r3dgs_rasterizer.h) -- in segments of S entries, several
+    workgroups per tile, from checkpoints the forward leaves; False: one workgroup per tile.  Gradients agree to rounding (the state at a
     segment's end is the forward's running product instead of the backward's own division chain).  A forward issued while
     this is off leaves no checkpoints, and its backward never splits.  Returns the previous setting."""
     return bool(_lib.r3dgs_set_bwd_segments(int(bool(on))))

@@ -46,3 +46,34 @@ def test_cgroup_probe_never_raises():
     cg = bench.cgroup_cpu()
     assert cg is None or {"quota_cpus", "nr_throttled", "throttled_usec", "usage_usec"} <= set(cg)
     assert bench.effective_cpus() >= 1
+
+
+def test_find_kernel_refuses_an_ambiguous_prefix():
+    """a profile holding several instantiations behind one open prefix must not be resolved by picking the first."""
+    import bench
+    table = {"r3::radix_scatter_kernel<r3::IoNarrow, 7>": {"FETCH_SIZE": 1.0},
+             "r3::radix_scatter_kernel<r3::IoNarrow, 8>": {"FETCH_SIZE": 2.0},
+             "r3::unit_order_kernel<1>": {"FETCH_SIZE": 3.0}, "r3::pair_reduce_kernel": {"FETCH_SIZE": 4.0}}
+    del bench.AMBIGUOUS_KERNELS[:]
+    assert bench.find_kernel(table, "r3::radix_scatter_kernel<") is None
+    assert bench.AMBIGUOUS_KERNELS == ["r3::radix_scatter_kernel<"]
+    assert bench.find_kernel(table, "r3::radix_scatter_kernel<r3::IoNarrow, 7>")["FETCH_SIZE"] == 1.0   # exact name wins
+    assert bench.find_kernel(table, "r3::unit_order_kernel")["FETCH_SIZE"] == 3.0                        # one match
+    assert bench.find_kernel(table, "r3::pair_reduce_kernel")["FETCH_SIZE"] == 4.0
+    assert bench.find_kernel({"r3::tile_order_kernel": {"x": 1}}, "r3::unit_order_kernel") == {"x": 1}    # round-4 name
+    assert bench.find_kernel(table, "r3::nothing") is None
+    del bench.AMBIGUOUS_KERNELS[:]
+
+
+def test_own_algorithm_bytes_stay_below_the_reference_algorithms():
+    """own_stage_bytes prices what THIS build has to move: with fewer pairs binned than the reference counts and no 64-bit key
+    sort, the binning stage must come out far below SURVEY 8d's figure, and no stage may be negative or missing."""
+    import bench
+    P, R, Rb, N, Tn, K = 500_000, 3_650_000, 2_370_000, 1600 * 1062, 100 * 67, 16.0
+    ref, own = bench.stage_bytes(P, R, N, Tn, K), bench.own_stage_bytes(P, 0.9 * P, Rb, N, Tn, K)
+    assert set(own) == set(ref) and all(v > 0 for v in own.values())
+    assert own["tile_binning"] < 0.25 * ref["tile_binning"]          # 29 B per binned pair against 164 B per reference pair
+    assert own["preprocess_bwd"] < ref["preprocess_bwd"]              # no 300 P of fills
+    assert own["blend_fwd"] < ref["blend_fwd"] * 1.05
+    split = bench.own_stage_bytes(2_000_000, 1_800_000, 14_000_000, N, Tn, 9.0, word_bytes=6, key_bytes=2)
+    assert split["tile_binning"] > 14_000_000 * 30

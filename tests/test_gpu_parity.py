@@ -8,8 +8,8 @@ Bars (BASELINE.json north_star), exactly as asserted below:
     lists themselves), n_contrib on the pixels that are not threshold-ambiguous;
   * threshold-ambiguous pixels: the sequential blend takes three hard decisions per (pixel, Gaussian) (power > 0,
     alpha < 1/255, T (1 - alpha) < 1e-4); a pixel where the ORACLE came within 1e-5 (relative) of one of them may
-    legitimately fall on the other side with another exp.  The oracle flags them; at most 0.5 % may be flagged (measured:
-    0.02-0.05 %), image checks run on the others, and `mask_ambiguous` removes them from the upstream gradient of BOTH
+    legitimately fall on the other side with another exp.  The oracle flags them; at most 0.1 % may be flagged (measured:
+    0.02-0.06 %, printed per test), image checks run on the others, and `mask_ambiguous` removes them from the upstream gradient of BOTH
     sides of a gradient comparison (a flipped decision changes gradients at O(1), not at rounding level);
   * rendered RGB and final T: <= 1e-5 abs on the non-ambiguous pixels;
   * gradients (check_backward): every tensor max |err| <= 1e-4 * max |ref| (GRAD_REL) AND per element
@@ -44,6 +44,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COLOR_ATOL = 1e-5
 GRAD_REL = 1e-4
 AMBIG_REL = 1e-5
+# threshold-ambiguous pixels the oracle may flag at most (measured 0.02-0.06 %; the gate was 0.5 % until round 5): every
+# test prints its fraction and test_zz_report lists them
+AMBIG_MAX_FRACTION = 1e-3
+ambig_seen = {}             # test id -> largest flagged fraction
+
+
+def _ambig_note(frac):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    ambig_seen[test] = max(ambig_seen.get(test, 0.0), float(frac))
+    print(f"[ambiguous pixels] {test}: {100.0 * frac:.4f} % masked (gate {100.0 * AMBIG_MAX_FRACTION:.2f} %)")
 
 
 @pytest.fixture(scope="module")
@@ -122,7 +132,8 @@ def check_forward(C_, fout, ref, H, W, P):
     np.testing.assert_array_equal(ex["point_list"].cpu().numpy().view(np.uint32), st["point_list"])
     np.testing.assert_array_equal(ex["ranges"].cpu().numpy().view(np.uint32), st["ranges"])
     ok = ref["ambig"].reshape(-1) == 0
-    assert ok.mean() > 0.995, f"too many threshold-ambiguous pixels: {1 - ok.mean():.4f}"
+    _ambig_note(1.0 - ok.mean())
+    assert 1.0 - ok.mean() <= AMBIG_MAX_FRACTION, f"too many threshold-ambiguous pixels: {1 - ok.mean():.5f}"
     np.testing.assert_array_equal(ex["n_contrib"].cpu().numpy().view(np.uint32)[ok], st["n_contrib"][ok])
     c = color.cpu().numpy().reshape(3, -1)
     err = np.abs(c - ref["color"].reshape(3, -1))
@@ -140,7 +151,8 @@ def mask_ambiguous(dl, ref):
     """dL/d(out_color) with the oracle's threshold-ambiguous pixels zeroed: what both sides of a gradient comparison get."""
     d = np.array(dl, dtype=np.float32, copy=True)
     amb = ref["ambig"].reshape(-1) != 0
-    assert amb.mean() < 0.005, f"too many threshold-ambiguous pixels: {amb.mean():.4f}"
+    _ambig_note(amb.mean())
+    assert amb.mean() <= AMBIG_MAX_FRACTION, f"too many threshold-ambiguous pixels: {amb.mean():.5f}"
     d.reshape(3, -1)[:, amb] = 0.0
     return d
 
@@ -149,6 +161,25 @@ def _note(name, err, bad):
     a = achieved.get(name, [0.0, 0.0, ""])
     test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
     achieved[name] = [max(a[0], err), max(a[1], bad), test if err > a[0] else a[2]]
+
+
+def chain_offenders(name, r32, got, r64, rel):
+    """Which elements of a covariance-chain tensor are further than rel * max |ref| from the fp32 oracle, and how
+    ill-conditioned each is: kappa = |fp32 oracle - exact| / (2^-24 max |exact|), the number of fp32 roundings of the tensor's
+    maximum the REFERENCE's own arithmetic lost on that element.  Printed when the reference-arithmetic bar fails, so that
+    the failure names its elements instead of widening the bar."""
+    got = (got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)).reshape(r32.shape).astype(np.float64)
+    scale = np.abs(r32).max() + 1e-30
+    e = np.abs(got - r32)
+    idx = np.argwhere(e > rel * scale)
+    lines = [f"{name}: {len(idx)} of {e.size} elements outside {rel:.1e} x max |ref| = {rel * scale:.3e}"]
+    s64 = np.abs(r64).max() + 1e-30
+    for row in idx[np.argsort(-e[tuple(idx.T)])][:12]:
+        t = tuple(row)
+        kappa = abs(float(r32[t]) - float(r64[t])) / (2.0 ** -24 * s64)
+        lines.append(f"   element {t}: hip {got[t]:+.6e}  fp32 oracle {float(r32[t]):+.6e}  exact {float(r64[t]):+.6e}  "
+                     f"|hip - oracle| / max = {e[t] / scale:.2e}  kappa = {kappa:.0f}")
+    return "\n".join(lines)
 
 
 def grads_close(name, ref, got, rel=GRAD_REL, per_element=True, check=True, elem_mask=None):
@@ -225,8 +256,10 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, c
                 grads_close(name + tag, r32, got, rel, per_element)
             grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
         else:
-            grads_close(name + tag, r32, got, max(rel, chain_fp32_rel) if in_chain else rel,
-                        per_element and not in_chain)
+            bar = max(rel, chain_fp32_rel) if in_chain else rel
+            if in_chain and np.abs(r32 - got.cpu().numpy().reshape(r32.shape)).max() > bar * (np.abs(r32).max() + 1e-30):
+                print(chain_offenders(name + tag, r32, got, r64, bar))
+            grads_close(name + tag, r32, got, bar, per_element and not in_chain)
             grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element,
                         check=not in_chain)
         grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
@@ -851,11 +884,10 @@ def metric_scene(request):
     return ss.make_workload(request.param)
 
 
-def test_full_size_properties(C_, metric_scene):
-    w, cam, g = metric_scene
-    W, H, P = w["W"], w["H"], w["P"]
-    black, white = np.zeros(3, np.float32), np.ones(3, np.float32)
-    fargs, fout = hip_forward(C_, black, g, cam, H, W)
+def check_list_properties(C_, fout, W, H, P):
+    """Size-independent properties of the binned lists of a finished forward (no oracle): a checksum of checksums, key
+    sortedness, ranges partitioning the list, the index tie-break, one rectangle of tiles per binned Gaussian, no pair
+    twice.  -> (the exported arrays, pairs binned)."""
     R, color, radii, geom, binning, img = fout
     ex = C_.export_binning(P, R, H, W, geom, binning, img)
     keys = ex["keys"]
@@ -889,6 +921,16 @@ def test_full_size_properties(C_, metric_scene):
     assert bool((count == ex["tiles_touched"].to(torch.int64)).all())
     assert bool((((x1 - x0 + 1) * (y1 - y0 + 1))[seen] == count[seen]).all())
     assert int(torch.unique(keys >> 32 << 32 | pl).numel()) == R                   # no (tile, Gaussian) pair twice
+    return ex, R
+
+
+def test_full_size_properties(C_, metric_scene):
+    w, cam, g = metric_scene
+    W, H, P = w["W"], w["H"], w["P"]
+    black, white = np.zeros(3, np.float32), np.ones(3, np.float32)
+    fargs, fout = hip_forward(C_, black, g, cam, H, W)
+    _, color, radii, geom, binning, img = fout
+    ex, R = check_list_properties(C_, fout, W, H, P)
     # idempotence / determinism of the forward
     _, fout2 = hip_forward(C_, black, g, cam, H, W)
     assert fout2[0] == int(fout[0]) and fout2[0].pairs == R and torch.equal(fout2[1], color) and torch.equal(fout2[2], radii)
@@ -942,17 +984,26 @@ def fp32_chain(C_):
 
 
 @pytest.mark.parametrize("case", ["golden_a", "golden_b", "golden_c", "cfg0_10k", "20k_mixed_sparsity", "lego_like_300k",
-                                  "metric_500k"])
+                                  "metric_500k", "clustered_500k", "garden_like_2M"])
 def test_reference_arithmetic_chain_mode(C_, fp32_chain, case):
     """`set_f64_chain(False)`: the only product mode that restates the reference's fp32 arithmetic for conic -> cov2D ->
-    cov3D -> (scale, quaternion) (backward.cu:228-306, 311-374).  All nine gradient tensors against the fp32 oracle at
-    1e-4 (the benchmark shape: the three chain tensors at 1.5e-4, everything else at 1e-4); the same pass through the
+    cov3D -> (scale, quaternion) (backward.cu:228-306, 311-374).  ALL nine gradient tensors against the fp32 oracle at
+    1e-4 -- the golden cases, configs[0], the 20 k / 300 k cases, the benchmark shape (measured 5.7e-5 on the chain tensors
+    in round 5; the bar was 1.5e-4 then), and the two scenes where the chain is worst-conditioned: the clustered 500 k scene
+    (large anisotropic background splats) and the 2 M stand-in of configs[2].  A chain tensor that misses the bar prints its
+    offending elements and their conditioning (chain_offenders) before the assertion fails.  The same pass through the
     reserved (graph) path and the exact path bit for bit, so both issue routes of this kernel instantiation run."""
     chain_rel = GRAD_REL
     if case.startswith("golden_"):
         kw = CASES[{"golden_a": "a_deg3_black", "golden_b": "b_mixed_white_sparsity", "golden_c": "c_deg0_rand"}[case]]
         cam, g, bg, dl = case_inputs(kw)
         H, W, P, lam = kw["H"], kw["W"], kw["P"], kw["lam"]
+    elif case in ("clustered_500k", "garden_like_2M"):
+        w, cam, g = ss.make_workload({"clustered_500k": "clustered_500k_1600x1062",
+                                      "garden_like_2M": "garden_like_2M_1600x1062"}[case])
+        W, H, P, lam = w["W"], w["H"], w["P"], 0.1
+        bg = np.zeros(3, np.float32)
+        dl = ss.upstream_grad(W, H, seed=1) * (W * H)
     else:
         kw = {"cfg0_10k": dict(P=10_000, W=400, H=400, f=300.0, cam_seed=None, gseed=0, degree_mode="all0", lam=0.0),
               "20k_mixed_sparsity": dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed",
@@ -965,8 +1016,6 @@ def test_reference_arithmetic_chain_mode(C_, fp32_chain, case):
         g = ss.make_gaussians(P, cam, seed=kw["gseed"], degree_mode=kw["degree_mode"], scale_mu=kw.get("scale_mu", 0.012))
         bg = np.array([0.1, 0.4, 0.9], np.float32) if case != "metric_500k" else np.zeros(3, np.float32)
         dl = ss.upstream_grad(W, H, seed=2 if case != "metric_500k" else 1) * (W * H)
-        if case == "metric_500k":
-            chain_rel = 1.5e-4
     ref = oracle_forward(bg, g, cam, H, W)
     dl = mask_ambiguous(dl, ref)
     gr, gr64 = oracle_backward(ref, dl, lam)
@@ -992,6 +1041,61 @@ def test_reference_arithmetic_chain_mode(C_, fp32_chain, case):
     for k in (0, 1, 2, 5, 8):   # means2D, colours, opacity, sh, conic: not touched by the chain
         assert torch.equal(bout[k], bout64[k]), k
     assert not torch.equal(bout[7], bout64[7])
+
+
+@pytest.mark.parametrize("name", ["cfg0_10k_400", "lego_like_300k_800", "garden_like_2M_1600x1062",
+                                  "bicycle_like_5M_1600x1062", "train_like_6M_1920x1080"])
+def test_reference_mode_every_output_at_every_config(C_, fp32_chain, name):
+    """The configuration whose RESULTS are the reference's: `set_tight_rects(False)` (the
+    reference's 3-sigma squares: rasterizer_impl.cu:78-117, auxiliary.h:46-56) + `set_f64_chain(False)` (the reference's fp32
+    covariance chain: backward.cu:228-306, 311-374) + the exact-size path (`r3dgs_forward`: rasterizer_impl.cu:441-450's
+    contract), at the synthetic stand-in of each of BASELINE.json's five configs.
+      * <= 2 M Gaussians: every public output and every exported integer list element-wise against the oracle -- radii,
+        num_rendered, tiles_touched, the sorted (tile << 32 | depth) keys, point list, ranges, n_contrib bit for bit, colour and
+        final T at 1e-5, all nine gradient tensors at 1e-4 against the fp32 oracle;
+      * 5 M / 6 M (configs[3] / [4] stand-ins; the CPU oracle's lists and blend take minutes there): radii, tiles_touched and
+        num_rendered element-wise against the oracle's per-Gaussian stage, the lists through the size-independent properties
+        (sortedness, partition, one rectangle per Gaussian, tie-break), pairs binned == num_rendered."""
+    w, cam, g = ss.make_workload(name)
+    W, H, P = w["W"], w["H"], w["P"]
+    bg = np.zeros(3, np.float32)
+    lam = 0.1 if name != "cfg0_10k_400" else 0.0
+    was = C_.set_tight_rects(False)
+    try:
+        assert not C_.tight_rects() and not C_.f64_chain()
+        fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
+        assert fout[0].ticket == 0 and fout[0].pairs == int(fout[0])
+        if P <= 2_000_000:
+            ref = oracle_forward(bg, g, cam, H, W)
+            check_forward(C_, fout, ref, H, W, P)
+            dl = mask_ambiguous(ss.upstream_grad(W, H, seed=1) * (W * H), ref)
+            gr, gr64 = oracle_backward(ref, dl, lam)
+            bout = hip_backward(C_, fargs, fout, dl, lam)
+            check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", tag=" {reference mode}")
+        else:
+            ref = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
+                              cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"],
+                              g["degrees"], cam.camera_center, geometry_only=True)
+            assert int(fout[0]) == ref["num_rendered"]
+            np.testing.assert_array_equal(fout[2].cpu().numpy(), ref["radii"])
+            ex, R = check_list_properties(C_, fout, W, H, P)
+            assert R == ref["num_rendered"]
+            np.testing.assert_array_equal(ex["tiles_touched"].cpu().numpy().astype(np.uint32), ref["state"]["tiles_touched"])
+            # the depth half of every key is the oracle's depth of the Gaussian the list names there
+            kd = (ex["keys"] & 0xFFFFFFFF).to(torch.int64)
+            dep = torch.from_numpy(ref["state"]["depths"].view(np.uint32).astype(np.int64)).cuda()
+            assert bool((kd == dep[ex["point_list"].to(torch.int64)]).all())
+            del ex
+            dl = ss.upstream_grad(W, H, seed=1) * (W * H)
+            b1 = hip_backward(C_, fargs, fout, dl, lam)
+            b2 = hip_backward(C_, fargs, fout, dl, lam)
+            for a, b in zip(b1, b2):
+                assert torch.equal(a, b)   # no float atomics in this mode either
+            assert all(bool(torch.isfinite(t).all()) for t in b1[:8])
+            inv = fout[2] == 0
+            assert bool((b1[3][inv] == 0).all()) and bool((b1[5][inv] == 0).all())
+    finally:
+        C_.set_tight_rects(was)
 
 
 def test_repeated_backward_and_pair_sort_path(C_):
@@ -1317,3 +1421,6 @@ def test_zz_report_achieved_errors(C_):
     for k in sorted(achieved):
         print(f"  {k:<38s} max-normalised err {achieved[k][0]:.2e}   elements outside the per-element bar "
               f"{achieved[k][1]:.2e}   worst in {achieved[k][2]}")
+    print(f"threshold-ambiguous pixels masked per test (gate {100.0 * AMBIG_MAX_FRACTION:.2f} %):")
+    for k in sorted(ambig_seen):
+        print(f"  {k:<90s} {100.0 * ambig_seen[k]:.4f} %")
