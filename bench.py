@@ -350,8 +350,8 @@ def main():
                 for c in cams]
     # all-to-all + local combine + all-gather needs RCCL; the single-device gloo dry run falls back to all-reduces
     two_phase = os.environ.get("R3DGS_BENCH_BACKEND", "nccl") == "nccl"
-    exch = ViewParallelExchange({"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)},
-                                P, device, two_phase=two_phase) if world > 1 else None
+    GRAD_SHAPES = {"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)}
+    exch = ViewParallelExchange(GRAD_SHAPES, P, device, two_phase=two_phase) if world > 1 else None
     if exch is not None and os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
         _C.set_gradient_arena(exch.arena)   # parameter gradients are written straight into the exchange buffer
 
@@ -428,9 +428,9 @@ def main():
     dom_stage = os.environ.get("R3DGS_BENCH_DOM_STAGE", "blend_bwd")
     prof_mode = os.environ.get("R3DGS_BENCH_PROFILE", "dominant")  # dominant | all | off  (A/B of the timer cost)
     # blend_bwd_kernel: the backward blend kernel ALONE (nested inside the blend_bwd stage's events) -> roofline.kernel_frac
-    stage_names = [_C._lib.r3dgs_profile_stage_name(k).decode() for k in range(_C._lib.r3dgs_profile_stage_count())]
-    timed_stages = [dom_stage] + (["blend_bwd_kernel"] if dom_stage == "blend_bwd" and "blend_bwd_kernel" in stage_names
-                                  else [])   # (an R3DGS_LIB=<older build> A/B run has no such timer)
+    # (the kernel-only timer `blend_bwd_kernel` -> roofline.kernel_frac runs in the instrumented pass BEHIND the timed region:
+    # two more event packets between the backward's kernels cost the timed step ~5 us, measured in round 6's first visit)
+    timed_stages = [dom_stage]
     if prof_mode == "all":
         _C.profile_enable(True)
     elif prof_mode == "dominant":
@@ -482,7 +482,7 @@ def main():
     _C.profile_enable(False)
     # N > 1: the exchange alone (events around a synchronous exchange), whether every replica ended up with the same
     # bits, and the same K steps in the overlapped (one-step-late) form
-    exchange_ms = overlapped_ms_per_step = replicas_identical = None
+    exchange_ms = overlapped_ms_per_step = replicas_identical = exchange_forms = None
     if exch is not None:
         n_x = min(args.steps, 10)
         xa, xb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -506,6 +506,59 @@ def main():
         dist.all_gather(allsums, mine)
         replicas_identical = all(bool(torch.equal(allsums[0], t)) for t in allsums)
         assert replicas_identical, "view-parallel exchange: the ranks' summed gradients differ"
+        # The compact transports (multiview.py, round 6): visible-union rows and / or bfloat16 for the higher SH bands --
+        # each measured as the dense form was (events around synchronous exchanges of a freshly packed step) with its bytes
+        # and the model's prediction beside it.  `value` stays the dense fp32 form: north_star's all-reduce.  Wrapped: a
+        # failure here must not cost the run its headline number.
+        dense_ex = exch
+        try:
+            from multiview import exchange_model
+            step_compute_ms = max(1e3 * elapsed / args.steps - exchange_ms, 1e-3)
+            exchange_forms = {"dense_fp32": {"exchange_ms": round(exchange_ms, 4), "bytes_per_rank": exch.bytes_per_rank(),
+                                             "rows": P, "model": exchange_model(P, world, step_compute_ms)}}
+            for tag, kw in (("visible_union", dict(sparse=True)), ("bf16_sh_rest", dict(sh_rest_bf16=True)),
+                            ("visible_union_bf16_sh_rest", dict(sparse=True, sh_rest_bf16=True))):
+                ex2 = ViewParallelExchange(GRAD_SHAPES, P, device, two_phase=True, **kw)
+                exch = ex2
+                if os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
+                    _C.set_gradient_arena(ex2.arena)
+                times = []
+                for i in range(min(args.steps, 6)):
+                    for t_ in leaves.values():
+                        t_.grad = None
+                    m2 = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0
+                    m2.retain_grad()
+                    c_, r_ = dgr.rasterize_gaussians(leaves["means3D"], m2, leaves["sh"], degrees, empty, leaves["opacity"],
+                                                     leaves["scales"], leaves["rotations"], empty,
+                                                     settings[cam_index(args.warmup + i)], 0.0)
+                    c_.backward(dl)
+                    ex2.pack({k: v.grad for k, v in leaves.items()}, m2.grad, r_)
+                    barrier()
+                    torch.cuda.synchronize()
+                    xa.record()
+                    ex2.exchange()
+                    xb.record()
+                    torch.cuda.synchronize()
+                    if i:
+                        times.append(xa.elapsed_time(xb))
+                t_ms = torch.tensor([sum(times) / max(len(times), 1)], dtype=torch.float64, device=device)
+                dist.all_reduce(t_ms, op=dist.ReduceOp.MAX)
+                rows = int(ex2.last["rows"])
+                exchange_forms[tag] = {"exchange_ms": round(float(t_ms.item()), 4), "bytes_per_rank": ex2.last["bytes"],
+                                       "rows": rows, "form": ex2.last["form"],
+                                       "model": exchange_model(P, world, step_compute_ms, union_frac=rows / P,
+                                                               sparse=bool(kw.get("sparse")),
+                                                               sh_rest_bf16=bool(kw.get("sh_rest_bf16")))}
+                exchange_forms[tag]["serialised_iters_per_s_with_this_form"] = round(
+                    world / ((step_compute_ms + exchange_forms[tag]["exchange_ms"]) * 1e-3), 2)
+            exch = dense_ex
+            if os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
+                _C.set_gradient_arena(exch.arena)
+        except Exception as e:   # noqa: BLE001
+            exchange_forms = {"error": repr(e)}
+            exch = dense_ex
+            if os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
+                _C.set_gradient_arena(exch.arena)
         overlap[0] = True
         for i in range(3):
             train_step(i)
@@ -627,7 +680,7 @@ def main():
     word_bytes, key_bytes = (4, 4) if id_bits + tile_bits <= 32 else ((6, 2) if Tn <= 65536 else (8, 8))
     own = own_stage_bytes(P, V_mean, pairs_mean, N, Tn, Kbar, word_bytes, key_bytes,
                           passes=2 if tile_bits <= 14 else -(-tile_bits // 8))
-    kernel_ms_events = None   # the backward blend kernel alone, HIP events of the timed region
+    kernel_ms_events = None   # the backward blend kernel alone, HIP events of the instrumented pass
     if prof.get("blend_bwd_kernel", (0, 0))[1]:
         kernel_ms_events = prof["blend_bwd_kernel"][0] / prof["blend_bwd_kernel"][1]
     stages = {}
@@ -672,6 +725,7 @@ def main():
                                        "not collected in this run)") if traffic is not None else None,
                     "traffic_collected_on_this_build": pmc_matches_build(pmc_path(args.workload)) if traffic is not None else None,
                     "duration_source": "HIP events around the stage on its stream, inside the timed region",
+                    "kernel_ms_source": "HIP events around the kernel alone, instrumented pass of this run (behind the timed region)",
                     "valu": pmc_valu(dom, args.workload, stages[dom]["avg_ms"],
                                      kernel_ms_events=kernel_ms_events if dom == "blend_bwd" else None)}
     iters_per_s = args.steps * world / elapsed
@@ -737,7 +791,10 @@ def main():
         "value_overlapped": round(args.steps * world / (overlapped_ms_per_step * 1e-3 * args.steps), 2)
         if overlapped_ms_per_step else None,
         "exchange_ms": round(exchange_ms, 4) if exchange_ms is not None else None,
-        "exchange_bytes_per_rank": (exch.flat.numel() * 4) if exch is not None else None,
+        # bytes ONE rank sends per step (both phases, all peers); exchange_forms: the same for the opt-in compact transports,
+        # measured the same way, each with the bytes / time model's prediction (multiview.exchange_model)
+        "exchange_bytes_per_rank": exch.bytes_per_rank() if exch is not None else None,
+        "exchange_forms": exchange_forms,
         "step_ms_exchange_overlapped": round(overlapped_ms_per_step, 4) if overlapped_ms_per_step is not None else None,
         "overlap_frac": (round(max(0.0, min(1.0, (1e3 * elapsed / args.steps - overlapped_ms_per_step) / exchange_ms)), 3)
                          if exchange_ms and overlapped_ms_per_step else None),

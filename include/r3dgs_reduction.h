@@ -91,6 +91,12 @@ int r3dgs_pack_view_stats(int P, const float* viewspace_grad, const int* radii, 
  * (radii).  out: [shard].  The combination order is the rank order, so all replicas compute identical bits. */
 int r3dgs_reduce_shards(int world, long long shard, long long shard_begin, long long sum_len, const float* recv,
                         float* out, void* stream);
+/* The same for a buffer with a reduced-precision middle region (round 6, the opt-in bfloat16 transport of the higher-band
+ * SH gradients): elements [sum_len, half_end) of the buffer are 4-byte words holding TWO bfloat16 each; every half is
+ * widened, summed in fp32 in rank order and rounded once (to nearest even) back to bfloat16.  Elements below sum_len are
+ * fp32 SUM, elements from half_end on int32 MAX, as above.  half_end == sum_len makes it r3dgs_reduce_shards. */
+int r3dgs_reduce_shards_mixed(int world, long long shard, long long shard_begin, long long sum_len, long long half_end,
+                              const float* recv, float* out, void* stream);
 
 #ifdef __cplusplus
 }

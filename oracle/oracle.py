@@ -17,13 +17,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# R3_ORACLE_VARIANT=fma: the restatement built with FMA contraction allowed (Makefile; tools/contraction_flips.py runs the
+# two builds in two processes).  Every test uses the default: one rounding per operation.
+_VARIANT = os.environ.get("R3_ORACLE_VARIANT", "")
+_SO = "libraster_oracle.so" if not _VARIANT else f"libraster_oracle_{_VARIANT}.so"
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libraster_oracle.so")
+    so = os.path.join(_HERE, _SO)
     srcs = [os.path.join(_HERE, f) for f in ("raster_oracle.c", "backward_f64.c", "Makefile")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libraster_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", _SO], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -219,6 +223,32 @@ def backward(st, dL_dout_color, lambda_sh_sparsity=0.0):
                              _p(dsh), _p(dscale), _p(drot), _p(dopac), C.c_float(lambda_sh_sparsity))
     return dict(dL_dmeans2D=dmean2D, dL_dcolors=dcolor, dL_dopacity=dopac, dL_dmeans3D=dmean3D,
                 dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale, dL_drotations=drot, dL_dconic=dconic)
+
+
+def preprocess_bwd_from(st, dL_dmeans2D, dL_dconic, dL_dcolors, lambda_sh_sparsity=0.0):
+    """The per-Gaussian half of `backward` alone (backward.cu:177-434 as restated in orc_preprocess_bwd), fed GIVEN 2D-stage
+    sums instead of the oracle's own: dL_dmeans2D [P,3], dL_dconic [P,4] (A, B, -, C), dL_dcolors [P,3].  What a test uses to
+    separate the covariance chain's arithmetic from the rounding of its inputs: the chain amplifies a relative 1e-6 on the
+    2D-stage sums of an anisotropic splat to 1e-4 .. 1e-3 on dL_drotations, so two correct fp32 pipelines whose blend stages
+    sum in different orders disagree there, while the chain itself, fed the same numbers, must agree to rounding.
+    (dL_dopacity is not an input of anything returned here.)"""
+    L = lib()
+    P, M, W, H = st["P"], st["M"], st["W"], st["H"]
+    dmean2D = np.ascontiguousarray(dL_dmeans2D, dtype=np.float32).reshape(P, 3).copy()
+    dconic = np.ascontiguousarray(dL_dconic, dtype=np.float32).reshape(P, 4).copy()
+    dcolor = np.ascontiguousarray(dL_dcolors, dtype=np.float32).reshape(P, 3).copy()
+    dopac = np.zeros((P, 1), np.float32)
+    dmean3D, dcov3D = np.zeros((P, 3), np.float32), np.zeros((P, 6), np.float32)
+    dsh, dscale, drot = np.zeros((P, M, 3), np.float32), np.zeros((P, 3), np.float32), np.zeros((P, 4), np.float32)
+    if P:
+        cov = st["cov3D_precomp"] if st["cov3D_precomp"] is not None else st["cov3D"]
+        L.orc_preprocess_bwd(C.c_int(P), C.c_int(M), _p(st["degrees"]), _p(st["means3D"]), _p(st["radii"]),
+                             _p(st["sh"]), _p(st["clamped"]), _p(st["scales"]), _p(st["rotations"]),
+                             C.c_float(st["mod"]), _p(cov), _p(st["vm"]), _p(st["pm"]), _p(st["campos"]),
+                             C.c_int(W), C.c_int(H), C.c_float(st["tan_fovx"]), C.c_float(st["tan_fovy"]),
+                             _p(dmean2D), _p(st["conic_op"]), _p(dconic), _p(dmean3D), _p(dcolor), _p(dcov3D),
+                             _p(dsh), _p(dscale), _p(drot), _p(dopac), C.c_float(lambda_sh_sparsity))
+    return dict(dL_dmeans3D=dmean3D, dL_dcov3D=dcov3D, dL_dsh=dsh, dL_dscales=dscale, dL_drotations=drot)
 
 
 def _f64(a):

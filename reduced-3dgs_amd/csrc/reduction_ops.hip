@@ -178,6 +178,46 @@ __global__ __launch_bounds__(kBlock) void reduce_shards_kernel(const float* __re
     }
 }
 
+// The same with a middle region of bfloat16 PAIRS (the opt-in reduced-precision transport of the 45 higher-band SH
+// gradients per Gaussian, multiview.py sh_rest_bf16): words [sum_len, half_end) of the buffer hold two bfloat16 each;
+// every half is widened, summed in fp32 in rank order and rounded once to nearest-even -- the value every replica,
+// the owner of the shard included, continues with.
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;   // NaN stays NaN (quiet)
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(kBlock) void reduce_shards_mixed_kernel(const float* __restrict__ recv, int world, long long shard,
+                                                                     long long shard_begin, long long sum_len,
+                                                                     long long half_end, float* __restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= shard) return;
+    const long long e = shard_begin + j;
+    if (e < sum_len) {
+        float acc = recv[j];
+        for (int w = 1; w < world; w++) acc += recv[(long long)w * shard + j];
+        out[j] = acc;
+    } else if (e < half_end) {
+        const uint32_t* ru = reinterpret_cast<const uint32_t*>(recv);
+        uint32_t v = ru[j];
+        float lo = bf16_to_f32(v & 0xFFFFu), hi = bf16_to_f32(v >> 16);
+        for (int w = 1; w < world; w++) {
+            v = ru[(long long)w * shard + j];
+            lo += bf16_to_f32(v & 0xFFFFu);
+            hi += bf16_to_f32(v >> 16);
+        }
+        reinterpret_cast<uint32_t*>(out)[j] = f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
+    } else {
+        const int* ri = reinterpret_cast<const int*>(recv);
+        int m = ri[j];
+        for (int w = 1; w < world; w++) m = max(m, ri[(long long)w * shard + j]);
+        reinterpret_cast<int*>(out)[j] = m;
+    }
+}
+
 int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -265,6 +305,19 @@ int r3dgs_reduce_shards(int world, long long shard, long long shard_begin, long 
         hipStream_t s = static_cast<hipStream_t>(stream);
         reduce_shards_kernel<<<grid_for(shard), kBlock, 0, s>>>(recv, world, shard, shard_begin, sum_len, out);
         r3::check_launch("reduce shards", s, false);
+        return 0;
+    });
+}
+
+int r3dgs_reduce_shards_mixed(int world, long long shard, long long shard_begin, long long sum_len, long long half_end,
+                              const float* recv, float* out, void* stream)
+{
+    return r3::guarded_call([&]() {
+        if (shard <= 0) return 0;
+        if (world < 1 || !recv || !out || half_end < sum_len) throw r3::Error("reduce_shards_mixed: bad arguments");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        reduce_shards_mixed_kernel<<<grid_for(shard), kBlock, 0, s>>>(recv, world, shard, shard_begin, sum_len, half_end, out);
+        r3::check_launch("reduce shards (mixed)", s, false);
         return 0;
     });
 }

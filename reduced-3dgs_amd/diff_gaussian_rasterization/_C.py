@@ -106,6 +106,8 @@ _lib.r3dgs_pack_view_stats.restype = _i
 _lib.r3dgs_pack_view_stats.argtypes = [_i] + [_vp] * 6
 _lib.r3dgs_reduce_shards.restype = _i
 _lib.r3dgs_reduce_shards.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
+_lib.r3dgs_reduce_shards_mixed.restype = _i
+_lib.r3dgs_reduce_shards_mixed.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
 _lib.r3dgs_profile_enable.argtypes = [_i]
 _lib.r3dgs_profile_stage_name.restype = C.c_char_p
 _lib.r3dgs_profile_stage_name.argtypes = [_i]
@@ -968,3 +970,15 @@ def reduce_shards(recv, world, shard_begin, sum_len, out):
     with _on_device(dev):
         _check(_lib.r3dgs_reduce_shards(int(world), shard, int(shard_begin), int(sum_len), recv.data_ptr(),
                                         out.data_ptr(), _stream()), "reduce_shards")
+
+
+def reduce_shards_mixed(recv, world, shard_begin, sum_len, half_end, out):
+    """r3dgs_reduce_shards_mixed (include/r3dgs_reduction.h): as reduce_shards, with the words [sum_len, half_end) of the
+    buffer holding bfloat16 pairs (fp32 accumulation in rank order, one rounding to nearest even)."""
+    dev = _need_gpu(recv, "reduce_shards_mixed")
+    shard = int(out.numel())
+    if recv.numel() != world * shard or not recv.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("reduce_shards_mixed: recv must be a contiguous [world, shard] buffer")
+    with _on_device(dev):
+        _check(_lib.r3dgs_reduce_shards_mixed(int(world), shard, int(shard_begin), int(sum_len), int(half_end),
+                                              recv.data_ptr(), out.data_ptr(), _stream()), "reduce_shards_mixed")

@@ -23,6 +23,19 @@ its own stream and the buffers are double-buffered: the rasterizer's backward of
 straight into buffer k % 2 (`arena`), `exchange_async()` starts moving it, and step k+1's forward / backward
 proceed meanwhile on buffer (k+1) % 2; `wait()` is called where the optimizer needs the sums.
 
+Two opt-in transports cut the bytes a step puts on the links (round 6; DESIGN.md section 7 has the bytes / time model):
+  * `sparse=True | "auto"`: VISIBLE-UNION rows only.  The ranks all-gather their visibility bitmaps (P / 8 bytes each), OR
+    them, and exchange a compact buffer holding the rows of the Gaussians at least one rank saw -- every other row is an
+    exact zero on every rank by the rasterizer's contract (gradients, statistics and radii of a culled Gaussian are
+    written as zeros), so its sum is the zero the dense buffer already holds.  The combination order per element is
+    the rank order in both forms: sparse == dense BIT FOR BIT.  Costs one small collective and one host read of the
+    union's size per step ("auto": falls back to the dense form for the step when the union exceeds 85 % of P --
+    eight unrelated cameras of one scene usually see nearly all of it; neighbouring cameras do not).
+  * `sh_rest_bf16=True`: the 45 higher-band SH gradients of a Gaussian (3/4 of the buffer) travel as bfloat16 in both
+    phases, accumulated in fp32 in rank order and rounded once (r3dgs_reduce_shards_mixed); every replica -- the owner of
+    a shard included -- continues with the rounded sums, so replicas stay bit-identical.  248 -> 158 bytes per Gaussian.
+    Not the reference's arithmetic (a relative 2^-8 per rounding on those gradients): opt-in.
+
 Camera-sharded statistics of the pruning / culling passes (SURVEY.md 8e tier 2):
   * `merge_colour_variance`: per-rank partial results of calculate_colours_variance over disjoint camera subsets
     -> the statistics over all cameras (plain sums for the weights and distance accumulators, pairwise
@@ -35,9 +48,18 @@ import torch.distributed as dist
 
 
 class ViewParallelExchange:
-    def __init__(self, shapes, P, device, two_phase=True, buffers=2):
+    def __init__(self, shapes, P, device, two_phase=True, buffers=2, sparse=False, sh_rest_bf16=False,
+                 sparse_threshold=0.85):
         """shapes: dict name -> per-Gaussian trailing shape of each gradient tensor, e.g.
-        {"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)}."""
+        {"means3D": (3,), "sh": (16, 3), "opacity": (1,), "scales": (3,), "rotations": (4,)}.
+        sparse: False (dense buffer, zero-copy with the gradient arena) | True (visible-union rows) | "auto" (visible-union
+        rows when the union is below `sparse_threshold` of P, the dense form otherwise).  sh_rest_bf16: bands >= 1 of the
+        "sh" gradient travel as bfloat16 (needs a tensor named "sh" of shape (M, 3), M > 1)."""
+        assert sparse in (False, True, "auto")
+        self.sparse = sparse
+        self.sparse_threshold = float(sparse_threshold)
+        self.sh_rest_bf16 = bool(sh_rest_bf16) and "sh" in shapes and len(shapes["sh"]) == 2 and shapes["sh"][0] > 1
+        self.last = {"form": "dense", "rows": int(P), "bytes": None}   # what the last exchange put on the links
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = torch.device(device)
@@ -70,6 +92,52 @@ class ViewParallelExchange:
         if self.two_phase:   # receive / combine scratch, allocated once per layout
             self.recv = torch.empty(self.world * self.shard, dtype=torch.float32, device=self.device)
             self.mine = torch.empty(self.shard, dtype=torch.float32, device=self.device)
+        # compact transport (visible-union rows and / or bfloat16 SH bands): its own buffer, sized for all P rows once
+        self.xbuf = None
+        if self.compact:
+            self.xbuf = torch.zeros(self._xlayout(P)["padded"], dtype=torch.float32, device=self.device)
+        w8 = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=self.device)
+        self._bit_weights = w8
+
+    @property
+    def compact(self):
+        return bool(self.sparse) or self.sh_rest_bf16
+
+    def _xlayout(self, U):
+        """Layout of the compact exchange buffer for U rows, in 4-byte words: [fp32 SUM | bfloat16 pairs SUM | int32 MAX],
+        tensor after tensor inside each region (a Gaussian's row is `words_per_row` words in total)."""
+        off, parts = 0, {}
+        half = 0
+        for name, shp in self.shapes.items():
+            n = 1
+            for s_ in shp:
+                n *= s_
+            if self.sh_rest_bf16 and name == "sh":
+                ch = shp[1]
+                parts[name] = (off, off + U * ch, n - ch)      # the DC band stays fp32; n - ch halves per row follow
+                off += U * ch
+                half = U * (n - ch)
+            else:
+                parts[name] = (off, off + U * n, 0)
+                off += U * n
+        stat = off
+        sum_len = off + 2 * U
+        half_words = (half + 1) // 2
+        half_end = sum_len + half_words
+        total = half_end + U
+        pad = (-total) % max(self.world, 1)
+        return {"parts": parts, "stat": stat, "sum_len": sum_len, "half": half, "half_end": half_end, "total": total,
+                "padded": total + pad, "shard": (total + pad) // max(self.world, 1)}
+
+    def bytes_per_rank(self, rows=None):
+        """Bytes ONE rank sends per step: (world - 1) / world of the buffer in each of the two phases (all-to-all, then
+        all-gather), plus -- sparse forms -- its visibility bitmap to every peer.  rows: the rows exchanged (default P)."""
+        w = max(self.world, 1)
+        if not self.compact:
+            return int(2 * (w - 1) * self.shard * 4)
+        x = self._xlayout(self.P if rows is None else rows)
+        bitmap = (w - 1) * ((self.P + 7) // 8) if self.sparse else 0
+        return int(2 * (w - 1) * x["shard"] * 4 + bitmap)
 
     def resize(self, P):
         """The Gaussian count changed (densification / pruning, train.py:132-147): every exchange in flight is waited
@@ -137,7 +205,147 @@ class ViewParallelExchange:
         if n_sum < self.shard:
             self.mine[n_sum:].view(torch.int32).copy_(r[:, n_sum:].contiguous().view(torch.int32).view(self.world, -1).amax(0))
 
+    # ---- compact transport ----------------------------------------------------------------------------------------
+    def _staged(self):
+        """GPU tensors over a backend that only moves host memory (the single-GPU gloo dry run of bench.py's N > 1 path,
+        tools/dryrun_2rank.py): the two collectives of the compact form go through host copies.  Functional only."""
+        return self.on_gpu and dist.get_backend() != "nccl"
+
+    def _all_to_all(self, recv, send):
+        if self._staged():
+            r, s_ = recv.cpu(), send.cpu()
+            dist.all_to_all_single(r, s_)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send)
+
+    def _all_gather(self, out, inp):
+        if self._staged():
+            o, i_ = out.cpu(), inp.cpu()
+            dist.all_gather_into_tensor(o, i_)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
+    def _union_rows(self, k):
+        """Indices of the Gaussians at least one rank saw this step (radii > 0 anywhere), ascending; None = all rows."""
+        if not self.sparse:
+            return None
+        P = self.P
+        vis = self._radii_view(k) > 0
+        nb = (P + 7) // 8
+        bits = torch.zeros(nb * 8, dtype=torch.uint8, device=self.device)
+        bits[:P] = vis.to(torch.uint8)
+        packed = (bits.view(nb, 8) * self._bit_weights).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+        if self.world > 1:
+            allb = torch.empty(self.world * nb, dtype=torch.uint8, device=self.device)
+            self._all_gather(allb, packed)
+            allb = allb.view(self.world, nb)
+            union = allb[0]
+            for w in range(1, self.world):
+                union = union | allb[w]
+        else:
+            union = packed
+        mask = ((union.view(nb, 1) & self._bit_weights) != 0).view(-1)[:P]
+        idx = torch.nonzero(mask).squeeze(1)          # (the one host read of the step: the union's size)
+        if self.sparse == "auto" and idx.numel() > self.sparse_threshold * P:
+            return None
+        return idx
+
+    def _pack_compact(self, k, idx):
+        flat, xb = self.flats[k], self.xbuf
+        U = self.P if idx is None else int(idx.numel())
+        x = self._xlayout(U)
+        rows = (lambda t: t) if idx is None else (lambda t: t.index_select(0, idx))
+        for name, (a, b, shape) in self.slices.items():
+            xa, xe, halves = x["parts"][name]
+            r = rows(flat[a:b].view(shape))
+            if halves:
+                xb[xa:xe] = r[:, 0, :].reshape(-1)
+                hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)
+                hv[:U * halves] = r[:, 1:, :].reshape(-1).to(torch.bfloat16)
+                if (U * halves) & 1:
+                    hv[U * halves] = 0
+            else:
+                xb[xa:xe] = r.reshape(-1)
+        P, o = self.P, self.stat_off
+        xb[x["stat"]:x["stat"] + U] = rows(flat[o:o + P])
+        xb[x["stat"] + U:x["stat"] + 2 * U] = rows(flat[o + P:o + 2 * P])
+        xb[x["half_end"]:x["half_end"] + U].view(torch.int32).copy_(rows(self._radii_view(k)))
+        xb[x["total"]:x["padded"]] = 0
+        return x
+
+    def _unpack_compact(self, k, idx, x):
+        flat, xb = self.flats[k], self.xbuf
+        U = self.P if idx is None else int(idx.numel())
+
+        def put(dst, src):
+            if idx is None:
+                dst.copy_(src.view(dst.shape))
+            else:
+                dst.index_copy_(0, idx, src.view((U,) + tuple(dst.shape[1:])))
+        for name, (a, b, shape) in self.slices.items():
+            xa, xe, halves = x["parts"][name]
+            dst = flat[a:b].view(shape)
+            if halves:
+                hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)[:U * halves]
+                r = torch.cat([xb[xa:xe].view(U, 1, shape[2]), hv.to(torch.float32).view(U, shape[1] - 1, shape[2])], dim=1)
+                put(dst, r)
+            else:
+                put(dst, xb[xa:xe])
+        P, o = self.P, self.stat_off
+        put(flat[o:o + P], xb[x["stat"]:x["stat"] + U])
+        put(flat[o + P:o + 2 * P], xb[x["stat"] + U:x["stat"] + 2 * U])
+        put(self._radii_view(k), xb[x["half_end"]:x["half_end"] + U].view(torch.int32))
+
+    def _combine_compact(self, recv, mine, x):
+        begin, shard = self.rank * x["shard"], x["shard"]
+        if self.on_gpu:
+            from diff_gaussian_rasterization import _C
+            _C.reduce_shards_mixed(recv, self.world, begin, x["sum_len"], x["half_end"], mine)
+            return
+        r = recv.view(self.world, shard)
+        n_sum = min(max(x["sum_len"] - begin, 0), shard)
+        n_half = min(max(x["half_end"] - begin, 0), shard)
+        if n_sum:
+            acc = r[0, :n_sum].clone()
+            for w in range(1, self.world):   # same order as the kernel
+                acc += r[w, :n_sum]
+            mine[:n_sum] = acc
+        if n_half > n_sum:   # bfloat16 pairs: fp32 accumulation in rank order, one rounding (to nearest even)
+            h = r[:, n_sum:n_half].contiguous().view(torch.bfloat16).view(self.world, -1).to(torch.float32)
+            acc = h[0].clone()
+            for w in range(1, self.world):
+                acc += h[w]
+            mine[n_sum:n_half].view(torch.bfloat16).copy_(acc.to(torch.bfloat16))
+        if n_half < shard:
+            mine[n_half:].view(torch.int32).copy_(r[:, n_half:].contiguous().view(torch.int32).view(self.world, -1).amax(0))
+
+    def _run_compact(self, k):
+        idx = self._union_rows(k)
+        if idx is None and not self.sh_rest_bf16:      # "auto" found (nearly) every row in the union: the dense form
+            self.last = {"form": "dense (union above threshold)", "rows": self.P, "bytes": int(2 * (self.world - 1) * self.shard * 4)}
+            return self._run_dense(k)
+        x = self._pack_compact(k, idx)
+        n, shard = x["padded"], x["shard"]
+        send = self.xbuf[:n]
+        recv = torch.empty(self.world * shard, dtype=torch.float32, device=self.device)
+        mine = torch.empty(shard, dtype=torch.float32, device=self.device)
+        self._all_to_all(recv, send)
+        self._combine_compact(recv, mine, x)
+        self._all_gather(send, mine)
+        self._unpack_compact(k, idx, x)
+        U = self.P if idx is None else int(idx.numel())
+        self.last = {"form": ("visible-union rows" if idx is not None else "all rows") +
+                             (", bf16 SH bands >= 1" if self.sh_rest_bf16 else ""),
+                     "rows": U, "bytes": self.bytes_per_rank(U)}
+
     def _run(self, k):
+        if self.world > 1 and self.compact:
+            return self._run_compact(k)
+        return self._run_dense(k)
+
+    def _run_dense(self, k):
         flat = self.flats[k]
         if self.world == 1:
             return
@@ -148,7 +356,7 @@ class ViewParallelExchange:
                 import warnings
                 warnings.warn(f"view-parallel exchange: all_to_all_single unavailable ({e}); using all_reduce")
                 self.two_phase = False
-                return self._run(k)
+                return self._run_dense(k)
             self._combine()
             dist.all_gather_into_tensor(flat, self.mine)
         else:
@@ -198,6 +406,34 @@ class ViewParallelExchange:
         out = {name: flat[a:b].view(shape) for name, (a, b, shape) in self.slices.items()}
         P, o = self.P, self.stat_off
         return out, flat[o:o + P], flat[o + P:o + 2 * P], self._radii_view(k)
+
+
+# ---- bytes / time model of the exchange (bench.py prints it next to what it measures) -------------
+XGMI_LINK_GBPS = 153.0        # 7 links x ~153 GB/s per GPU, taken per direction; a full mesh, one link per peer
+COLLECTIVE_LATENCY_US = 25.0  # assumed launch + synchronisation cost of one RCCL collective on an 8-GPU node (not measured:
+                              # no such node was available to any round of this project)
+
+
+def exchange_model(P, world, step_ms, floats_per_row=59, union_frac=1.0, sh_rest_bf16=False, sparse=False,
+                   link_GBps=XGMI_LINK_GBPS, latency_us=COLLECTIVE_LATENCY_US):
+    """Predicted cost of one step's exchange on a full xGMI mesh and the serialised speed-up it allows.
+    Row = floats_per_row gradient floats + 2 statistics + 1 radius (4 bytes each; the 45 higher-band SH floats 2 bytes each
+    with sh_rest_bf16).  Two phases (all-to-all, all-gather); in each a rank sends 1 / world of the buffer to every peer
+    over that peer's own link, so a phase takes buffer / world / link bandwidth + one collective latency.  sparse adds the
+    bitmap all-gather (P / 8 bytes to every peer) and moves union_frac x P rows.
+    -> dict(bytes_per_row, buffer_bytes, bytes_per_link_per_phase, exchange_ms, speedup, efficiency)."""
+    row = 4 * (floats_per_row + 3) - (2 * 45 if sh_rest_bf16 else 0)
+    rows = P * (union_frac if sparse else 1.0)
+    buf = row * rows
+    per_link = buf / world
+    t_phase = per_link / (link_GBps * 1e9) * 1e3 + latency_us * 1e-3
+    t = 2 * t_phase
+    if sparse:
+        t += (P / 8.0) / (link_GBps * 1e9) * 1e3 + latency_us * 1e-3
+    speedup = world * step_ms / (step_ms + t) if world > 1 else 1.0
+    return {"bytes_per_row": row, "rows": int(rows), "buffer_bytes": int(buf), "bytes_per_link_per_phase": int(per_link),
+            "exchange_ms": round(t, 4), "speedup": round(speedup, 2), "efficiency": round(speedup / world, 3),
+            "assumes": f"{link_GBps:.0f} GB/s per link and direction, {latency_us:.0f} us per collective, full mesh"}
 
 
 # ---- camera-sharded statistics (SURVEY.md 8e, tier 2) -----------------------------------------------------------------

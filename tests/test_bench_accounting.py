@@ -77,3 +77,20 @@ def test_own_algorithm_bytes_stay_below_the_reference_algorithms():
     assert own["blend_fwd"] < ref["blend_fwd"] * 1.05
     split = bench.own_stage_bytes(2_000_000, 1_800_000, 14_000_000, N, Tn, 9.0, word_bytes=6, key_bytes=2)
     assert split["tile_binning"] > 14_000_000 * 30
+
+
+def test_exchange_model_arithmetic():
+    """multiview.exchange_model (bench.py --gpus N): bytes per row, per link and phase, and the
+    serialised speed-up they allow."""
+    sys.path.insert(0, os.path.join(ROOT, "reduced-3dgs_amd"))
+    from multiview import exchange_model as m
+    d = m(500_000, 8, 0.67)
+    assert d["bytes_per_row"] == 248 and d["buffer_bytes"] == 124_000_000 and d["bytes_per_link_per_phase"] == 15_500_000
+    # two phases of 15.5 MB at 153 GB/s + two collective latencies
+    assert abs(d["exchange_ms"] - (2 * (15.5e6 / 153e9 * 1e3 + 0.025))) < 1e-3
+    assert abs(d["speedup"] - 8 * 0.67 / (0.67 + d["exchange_ms"])) < 0.01
+    b = m(500_000, 8, 0.67, sh_rest_bf16=True)
+    assert b["bytes_per_row"] == 158 and b["speedup"] > d["speedup"]
+    s = m(2_000_000, 8, 1.25, sparse=True, union_frac=0.5, sh_rest_bf16=True)
+    assert s["rows"] == 1_000_000 and s["exchange_ms"] < m(2_000_000, 8, 1.25, sh_rest_bf16=True)["exchange_ms"]
+    assert m(500_000, 1, 0.67)["speedup"] == 1.0

@@ -217,10 +217,42 @@ CHAIN = ("dL_dcov3D", "dL_dscales", "dL_drotations")   # what comes out of the c
 # regression of either side cannot hide behind the other); the fp32 mode (set_f64_chain(False)) restates the reference's
 # arithmetic and is held to the fp32 oracle at 1e-4 where the case allows it (test_reference_arithmetic_chain_mode).
 CHAIN_F64_VS_FP32_ORACLE_REL = 2.5e-4
+# Reference-arithmetic mode (set_f64_chain(False)), end to end against the fp32 oracle: 1e-4 on every element -- except
+# elements on which the REFERENCE's own fp32 chain lost at least CHAIN_ILL_KAPPA roundings of the tensor's maximum
+# (kappa = |fp32 oracle - exact| / (2^-24 max |exact|)): there the chain amplifies the rounding of its inputs (the order
+# in which a Gaussian's per-pixel terms were summed -- atomics in the reference: its own result varies run to run by as
+# much) beyond 1e-4.  At most CHAIN_ILL_MAX_FRACTION of a tensor's elements may be such exceptions, each is printed, none
+# may be further than CHAIN_ILL_CAP from the oracle; and the chain's arithmetic itself is held on EVERY element by feeding
+# the oracle's chain the HIP path's own inputs (CHAIN_SAME_INPUTS_REL).
+CHAIN_ILL_KAPPA = 500.0
+CHAIN_ILL_MAX_FRACTION = 1e-5
+CHAIN_ILL_CAP = 1e-3
+CHAIN_SAME_INPUTS_REL = 2e-6
+chain_exceptions = {}   # test id -> [(tensor, element, |hip - oracle| / max, kappa)]
+
+
+def chain_tensor_in_reference_mode(name, r32, got, r64, bar):
+    g = (got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)).reshape(r32.shape)
+    scale = np.abs(r32).max() + 1e-30
+    e = np.abs(g.astype(np.float64) - r32)
+    _note(name, float(e.max() / scale) if e.size else 0.0, 0.0)
+    idx = np.argwhere(e > bar * scale)
+    if len(idx) == 0:
+        return
+    print(chain_offenders(name, r32, got, r64, bar))
+    s64 = np.abs(r64).max() + 1e-30
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    assert len(idx) <= max(1, int(CHAIN_ILL_MAX_FRACTION * e.size)), f"{name}: {len(idx)} elements outside {bar:.1e}"
+    for row in idx:
+        t = tuple(row)
+        kappa = abs(float(r32[t]) - float(r64[t])) / (2.0 ** -24 * s64)
+        assert kappa >= CHAIN_ILL_KAPPA, f"{name}{t}: outside {bar:.1e} of the fp32 oracle on a WELL-conditioned element (kappa {kappa:.0f})"
+        assert e[t] <= CHAIN_ILL_CAP * scale, f"{name}{t}: {e[t] / scale:.2e} of the maximum from the fp32 oracle"
+        chain_exceptions.setdefault(test, []).append((name, t, float(e[t] / scale), float(kappa)))
 
 
 def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, chain="f64", chain_fp32_rel=GRAD_REL,
-                   tag=""):
+                   tag="", lam=None):
     """Every gradient tensor of the HIP path at north_star's bar -- max |err| <= 1e-4 max |ref|, and per element
     |err| <= 1e-4 |ref| + 1e-6 max |ref| on >= 99.9 % of the elements -- against
       * the fp32 oracle `gr` (raster_oracle.c, the reference's arithmetic term by term) AND the double evaluation `gr64`
@@ -257,12 +289,21 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, c
             grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element)
         else:
             bar = max(rel, chain_fp32_rel) if in_chain else rel
-            if in_chain and np.abs(r32 - got.cpu().numpy().reshape(r32.shape)).max() > bar * (np.abs(r32).max() + 1e-30):
-                print(chain_offenders(name + tag, r32, got, r64, bar))
-            grads_close(name + tag, r32, got, bar, per_element and not in_chain)
+            if in_chain:
+                chain_tensor_in_reference_mode(name + tag, r32, got, r64, bar)
+            else:
+                grads_close(name + tag, r32, got, bar, per_element)
             grads_close(name + tag + " [hip vs f64]", r64, got.double(), max(rel, GRAD_REL), per_element,
                         check=not in_chain)
         grads_close(name + " [fp32 oracle vs f64]", r64, r32, check=False)
+    if chain == "f32" and lam is not None:
+        # The chain's ARITHMETIC, separated from the rounding of its inputs: the oracle's per-Gaussian stage fed the HIP
+        # path's own 2D-stage sums must reproduce the HIP path's chain tensors to rounding -- on every element, the
+        # ill-conditioned ones included (no exception list here)
+        fed = orc.preprocess_bwd_from(st, dm2.cpu().numpy(), dconic.cpu().numpy().reshape(-1, 4), dcol.cpu().numpy(), lam)
+        for name, got in (("dL_dcov3D", dcov), ("dL_dscales", dsc), ("dL_drotations", drot), ("dL_dmeans3D", dm3)):
+            grads_close(name + tag + " [oracle chain fed the hip 2D sums]", fed[name], got, CHAIN_SAME_INPUTS_REL,
+                        per_element=False)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
     for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):
@@ -1022,7 +1063,7 @@ def test_reference_arithmetic_chain_mode(C_, fp32_chain, case):
     fargs, fout = hip_forward(C_, bg, g, cam, H, W, exact=True)
     assert fout[0].ticket == 0
     bout = hip_backward(C_, fargs, fout, dl, lam)
-    check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", chain_fp32_rel=chain_rel, tag=" {fp32 chain}")
+    check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", chain_fp32_rel=chain_rel, tag=" {fp32 chain}", lam=lam)
     # the same view through whichever path the library picks now (reserved / graph once the size has been seen)
     taken = 0
     for _ in range(2):
@@ -1071,7 +1112,7 @@ def test_reference_mode_every_output_at_every_config(C_, fp32_chain, name):
             dl = mask_ambiguous(ss.upstream_grad(W, H, seed=1) * (W * H), ref)
             gr, gr64 = oracle_backward(ref, dl, lam)
             bout = hip_backward(C_, fargs, fout, dl, lam)
-            check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", tag=" {reference mode}")
+            check_backward(bout, gr, ref["state"], 16, gr64=gr64, chain="f32", tag=" {reference mode}", lam=lam)
         else:
             ref = orc.forward(bg, g["means3D"], None, g["opacity"], g["scales"], g["rotations"], 1.0, None,
                               cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, g["sh"],
@@ -1421,6 +1462,11 @@ def test_zz_report_achieved_errors(C_):
     for k in sorted(achieved):
         print(f"  {k:<38s} max-normalised err {achieved[k][0]:.2e}   elements outside the per-element bar "
               f"{achieved[k][1]:.2e}   worst in {achieved[k][2]}")
+    print(f"reference-arithmetic mode: chain-tensor elements outside 1e-4 of the fp32 oracle (each with kappa >= "
+          f"{CHAIN_ILL_KAPPA:.0f}, at most {CHAIN_ILL_MAX_FRACTION:.0e} of a tensor):")
+    for k in sorted(chain_exceptions):
+        for (n, t, err, kappa) in chain_exceptions[k]:
+            print(f"  {k}: {n}{tuple(int(v) for v in t)}  |hip - oracle| / max = {err:.2e}  kappa = {kappa:.0f}")
     print(f"threshold-ambiguous pixels masked per test (gate {100.0 * AMBIG_MAX_FRACTION:.2f} %):")
     for k in sorted(ambig_seen):
         print(f"  {k:<90s} {100.0 * ambig_seen[k]:.4f} %")

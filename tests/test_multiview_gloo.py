@@ -253,3 +253,133 @@ def test_camera_sharded_colour_variance_merge_and_pixel_size_min():
     np.testing.assert_array_equal(results[0][5], results[1][5])                          # replicas agree bit for bit
     np.testing.assert_array_equal(results[0][5], np.minimum(results[0][4], results[1][4]))
     np.testing.assert_array_equal(results[0][2], results[1][2])
+
+
+# ---- compact transports (round 6): visible-union rows, bfloat16 SH bands ------------------------------------------------
+def _contract_inputs(rank, Pn, step, seen=0.45):
+    """Per-rank gradients as the rasterizer's backward leaves them: a Gaussian this view culled (radii == 0) has EXACT zeros
+    in every gradient tensor (include/r3dgs_rasterizer.h: every element is written, zeros included).  About half the
+    Gaussians are seen per rank, some by no rank at all."""
+    g = torch.Generator().manual_seed(7000 * step + 13 * Pn + rank)
+    radii = torch.randint(1, 40, (Pn,), generator=g, dtype=torch.int32)
+    never = torch.rand(Pn, generator=torch.Generator().manual_seed(99 + step)) < 0.2     # the same rows on every rank
+    radii[(torch.rand(Pn, generator=g) > seen) | never] = 0
+    vis = radii > 0
+    grads = {k: torch.randn((Pn,) + s, generator=g) * vis.view((-1,) + (1,) * len(s)) for k, s in SHAPES.items()}
+    vgrad = torch.randn(Pn, 3, generator=g) * vis.view(-1, 1)
+    return grads, vgrad, radii
+
+
+XC_SIZES = [257, 301, 94]   # none divisible by 4; the count changes between steps (resize)
+
+
+def _xc_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reduced-3dgs_amd"))
+    from multiview import ViewParallelExchange
+    cpu = torch.device("cpu")
+    forms = {"dense": dict(), "sparse": dict(sparse=True), "auto_low": dict(sparse="auto", sparse_threshold=0.05),
+             "auto_high": dict(sparse="auto", sparse_threshold=0.999), "bf16": dict(sh_rest_bf16=True),
+             "sparse_bf16": dict(sparse=True, sh_rest_bf16=True)}
+    exs = {n: ViewParallelExchange(SHAPES, XC_SIZES[0], cpu, two_phase=True, **kw) for n, kw in forms.items()}
+    res = []
+    for step, Pn in enumerate(XC_SIZES):
+        grads, vgrad, radii = _contract_inputs(rank, Pn, step)
+        per_form = {}
+        for n, ex in exs.items():
+            ex.resize(Pn)
+            born = {}
+            for k, v in grads.items():      # gradients born in the dense arena, as set_gradient_arena arranges
+                t = ex.arena(k, tuple(v.shape))
+                assert t is not None
+                t.copy_(v)
+                born[k] = t
+            ex.pack(born, vgrad, radii)
+            if step % 2:
+                kk = ex.exchange_async()
+                ex.wait(kk)
+                out, gnorm, vis, rmax = ex.unpack(kk)
+            else:
+                ex.exchange()
+                out, gnorm, vis, rmax = ex.unpack()
+            per_form[n] = ({k: v.clone().numpy() for k, v in out.items()}, gnorm.clone().numpy(), vis.clone().numpy(),
+                           rmax.clone().numpy(), dict(ex.last), ex.bytes_per_rank(ex.last["rows"]), ex.bytes_per_rank())
+        res.append(per_form)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_xc(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step, Pn in enumerate(XC_SIZES):
+        ins = [_contract_inputs(r, Pn, step) for r in range(world)]
+        union = sum((i[2] > 0).int() for i in ins) > 0
+        U = int(union.sum())
+        assert 0 < U < Pn
+        dense0 = results[0][step]["dense"]
+        for rank in range(world):
+            forms = results[rank][step]
+            # (1) the fp32 compact forms are the dense form BIT FOR BIT: the same rank-order sums per element, and rows
+            #     outside the union are the exact zeros every rank already holds
+            for n in ("sparse", "auto_low", "auto_high"):
+                for k in SHAPES:
+                    np.testing.assert_array_equal(forms[n][0][k], forms["dense"][0][k], err_msg=f"{n} {k} step {step}")
+                for j in (1, 2, 3):
+                    np.testing.assert_array_equal(forms[n][j], forms["dense"][j])
+            # (2) every form: all replicas hold the same bits
+            for n in forms:
+                for k in SHAPES:
+                    np.testing.assert_array_equal(forms[n][0][k], results[0][step][n][0][k])
+                for j in (1, 2, 3):
+                    np.testing.assert_array_equal(forms[n][j], results[0][step][n][j])
+            # (3) the dense form is the sum / max it always was
+            for k in SHAPES:
+                np.testing.assert_allclose(forms["dense"][0][k], sum(i[0][k] for i in ins).numpy(), rtol=1e-6, atol=1e-5)
+            want = ins[0][2]
+            for i in ins[1:]:
+                want = torch.maximum(want, i[2])
+            np.testing.assert_array_equal(forms["dense"][3], want.numpy())
+            # (4) bfloat16 SH bands >= 1: every other tensor, the DC band, statistics and radii are the dense bits; the
+            #     higher bands are the fp32 sum of the bf16-rounded per-rank values, rounded once more: within 2^-7 x world x
+            #     the largest addend per element (two roundings of relative 2^-8 each -- bfloat16 carries 8 significant bits)
+            for n in ("bf16", "sparse_bf16"):
+                for k in SHAPES:
+                    if k != "sh":
+                        np.testing.assert_array_equal(forms[n][0][k], dense0[0][k])
+                for j in (1, 2, 3):
+                    np.testing.assert_array_equal(forms[n][j], dense0[j])
+                np.testing.assert_array_equal(forms[n][0]["sh"][:, 0, :], dense0[0]["sh"][:, 0, :])
+                hi, hi_d = forms[n][0]["sh"][:, 1:, :], dense0[0]["sh"][:, 1:, :]
+                bound = 2.0 ** -7 * world * np.max([np.abs(i[0]["sh"][:, 1:, :].numpy()) for i in ins], axis=0) + 1e-30
+                assert np.all(np.abs(hi - hi_d) <= bound)
+                assert np.abs(hi - hi_d).max() > 0          # (it really is the reduced-precision path)
+                as_bf16 = torch.from_numpy(hi.copy()).to(torch.bfloat16).to(torch.float32).numpy()
+                np.testing.assert_array_equal(as_bf16, hi)   # the replicas continue with bfloat16-representable sums
+                np.testing.assert_array_equal(forms["sparse_bf16"][0]["sh"], forms["bf16"][0]["sh"])
+            # (5) what went over the links
+            assert forms["sparse"][4]["rows"] == U and forms["sparse"][4]["form"].startswith("visible-union")
+            assert forms["auto_high"][4]["rows"] == U                     # union below the threshold: sparse
+            assert forms["auto_low"][4]["form"].startswith("dense")       # union above it: the dense form for this step
+            assert forms["sparse"][5] < forms["dense"][6] and forms["sparse_bf16"][5] < forms["sparse"][5]
+            assert forms["bf16"][6] < 0.7 * forms["dense"][6]             # 248 -> 158 bytes per Gaussian
+
+
+def test_world2_compact_transports_equal_dense():
+    _run_xc(2)
+
+
+def test_world4_compact_transports_equal_dense_with_changing_gaussian_count():
+    _run_xc(4)

@@ -374,3 +374,38 @@ def test_gpu_reduce_shards_sum_and_max():
             acc += recv[w, :n_sum]
         assert torch.equal(out[:n_sum].cpu(), acc)
         assert torch.equal(out[n_sum:].cpu().view(torch.int32), ints.amax(0))
+
+
+@pytest.mark.gpu
+def test_gpu_reduce_shards_mixed_matches_the_host_path():
+    """r3dgs_reduce_shards_mixed: fp32 SUM | bfloat16 pairs (fp32 accumulation in rank order, one rounding to nearest even) |
+    int32 MAX, for shards that straddle both region borders -- bit for bit against the torch path the gloo tests run
+    (multiview.ViewParallelExchange._combine_compact), incl. half_end == sum_len (then it is r3dgs_reduce_shards)."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    world, shard = 8, 1000
+    g = torch.Generator().manual_seed(11)
+    for begin, sum_len, half_end in ((0, 400, 800), (2 * shard, 2 * shard + 17, 2 * shard + 18), (shard, 0, 5 * shard),
+                                     (4 * shard, 4 * shard + 600, 4 * shard + 600), (6 * shard, 100, 200)):
+        n_sum = min(max(sum_len - begin, 0), shard)
+        n_half = min(max(half_end - begin, 0), shard)
+        recv = torch.randn(world, shard, generator=g)
+        if n_half > n_sum:
+            halves = (torch.randn(world, 2 * (n_half - n_sum), generator=g) * 3).to(torch.bfloat16)
+            recv[:, n_sum:n_half] = halves.view(torch.float32)
+        ints = torch.randint(0, 500, (world, shard - n_half), generator=g, dtype=torch.int32)
+        recv[:, n_half:] = ints.view(torch.float32)
+        out = torch.empty(shard, device="cuda")
+        _C.reduce_shards_mixed(recv.cuda().contiguous().view(-1), world, begin, sum_len, half_end, out)
+        out = out.cpu()
+        acc = recv[0, :n_sum].clone()
+        for w in range(1, world):
+            acc += recv[w, :n_sum]
+        assert torch.equal(out[:n_sum], acc)
+        if n_half > n_sum:
+            h = recv[:, n_sum:n_half].contiguous().view(torch.bfloat16).view(world, -1).to(torch.float32)
+            acc = h[0].clone()
+            for w in range(1, world):
+                acc += h[w]
+            assert torch.equal(out[n_sum:n_half].contiguous().view(torch.bfloat16), acc.to(torch.bfloat16))
+        assert torch.equal(out[n_half:].contiguous().view(torch.int32), ints.amax(0))
