@@ -374,6 +374,16 @@ __device__ __forceinline__ uint32_t rect_tiles(uint2 rc)
 {
     return ((rc.y & 0xffffu) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.x >> 16));
 }
+// The sort word of the bucket sorts: (key - bucket minimum) << 40 | id << 16 | position.  Its three fields rest on invariants
+// that live elsewhere and are pinned here:
+//   * key span of a bucket < 2^24: keys are the bit patterns of positive floats (< 2^31) cut into >= kMinDepthBuckets
+//     equal-width buckets (common.h depth_bucket_count) -- and a sub-bucket only narrows its range;
+//   * id < 2^24: P >= 2^24 is routed to the generic sort (capi.hip plan_forward: generic_depth_sort);
+//   * position < 2^16: a word-sorted bucket holds at most kBucketCap records; a bigger one is first split in global memory
+//     into pieces of ~2048 (kGlobalSplitCap / kGlobalSplitMax) and a piece above kBucketCap takes the radix path.
+static_assert((1u << 31) / (unsigned)kMinDepthBuckets <= (1u << 24), "a depth bucket's key span must fit the sort word's 24 key bits");
+static_assert(kBucketCap <= 65536, "a word-sorted bucket's positions must fit the sort word's 16 position bits");
+static_assert(kGlobalSplitCap / kGlobalSplitMax <= (unsigned)kBucketCap, "a piece of a globally split bucket must fit the LDS sort");
 __device__ __forceinline__ unsigned long long sort_word(uint32_t key, uint32_t kmin, uint32_t id, uint32_t pos)
 {
     return ((unsigned long long)(key - kmin) << 40) | ((unsigned long long)id << 16) | (unsigned long long)pos;

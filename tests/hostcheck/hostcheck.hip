@@ -3,6 +3,7 @@
 // the exact source the HIP kernels execute per lane against the oracle WITHOUT a GPU.
 // It is not part of the product and nothing in reduced-3dgs_amd/ links it; the cooperative kernel
 // skeletons (LDS staging, DPP reductions, atomics, sorts) are only exercised by the -m gpu tests.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -296,6 +297,159 @@ void hc_lane_utilisation(int W, int H, const unsigned* ranges, const unsigned* p
                         blk[1] += fm;
                         blk[2] += bm;
                     }
+            }
+        }
+}
+
+// Three alternative lane mappings of the blend kernels, priced on the CPU before any is built (design aid, round 6:
+// tools/lane_utilisation.py, profiles/r06_lane_utilisation.txt).  Forward = the entry is kept by the (conservative) region
+// pre-test of the region in question and a pixel of that region is still live; useful lane = alpha >= 1/255 on a live pixel.
+// Backward = kept and in front of the region's deepest contributor; useful lane = in front of the PIXEL's last contributor
+// and alpha >= 1/255.  out[] (longs), f = forward, b = backward (b at index + 20):
+//   [0]  today's trips: evaluated (entry, 8x8 quadrant) pairs            [1]  useful lane-evaluations (independent of the mapping)
+//  (i) 64-pixel footprints chosen by the splat's orientation -- 8x8 quadrants, 16x4 strips or 4x16 strips, four of each per tile:
+//   [2]  trips if every ENTRY could pick its best footprint (the T recurrence forbids it: a wave's pixels would change under
+//        it; a lower bound)                                               [3]  trips if every TILE picks one footprint for all its entries
+//   [4]  trips with 16x4 strips everywhere                                [5]  trips with 4x16 strips everywhere
+//  (ii) two-phase walk: phase A evaluates alpha over compacted (entry, 4x4 block) items, four items per wave instruction;
+//       phase B runs the sequential T recurrence per PIXEL over that pixel's own survivors:
+//   [6]  phase-A items (kept (entry, 4x4 block) pairs)                    [7]  phase-B trips: per 8x8 quadrant wave the most survivors any of its
+//                                                                             pixels has, summed (lanes walk their own lists)
+//   [8]  survivors in all (= useful lane-evaluations: the LDS records phase A writes and phase B reads)
+//  (iii) one 16-lane DPP row owns a whole tile (16 pixels per lane: slot k = 4x4 block k), a wave walks FOUR tiles' lists side by
+//        side (2x2 tile groups), so that an entry's nine sums come from one row -- no cross-row combination:
+//   [9]  trips (per group and 64-entry chunk position: the longest of the four lists)
+//   [10] slots executed (per trip: the 4x4 blocks ANY of the four rows' entries keeps; a slot costs one evaluation of 64 lanes)
+//   [11] (entry, tile) pairs with at least one kept block (= the row-local reductions, one per row and trip instead of one wave
+//        reduction per pair)
+void hc_lane_variants(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
+                      const float* conic_op, const unsigned* n_contrib, long* out)
+{
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    for (int k = 0; k < 40; k++) out[k] = 0;
+    // region r of shape s: s = 0: 8x8 quadrants, 1: 16 wide x 4 tall strips, 2: 4 wide x 16 tall strips
+    auto region_of = [](int s, int lx, int ly) { return s == 0 ? (ly / 8) * 2 + lx / 8 : s == 1 ? ly / 4 : lx / 4; };
+    auto region_box = [](int s, int r, int* x0, int* x1, int* y0, int* y1) {
+        if (s == 0) { *x0 = (r & 1) * 8; *x1 = *x0 + 7; *y0 = (r >> 1) * 8; *y1 = *y0 + 7; }
+        else if (s == 1) { *x0 = 0; *x1 = 15; *y0 = r * 4; *y1 = *y0 + 3; }
+        else { *x0 = r * 4; *x1 = *x0 + 3; *y0 = 0; *y1 = 15; }
+    };
+    // per tile of a 2x2 group: for every list position the 16-bit mask of kept 4x4 blocks (forward / backward), for (iii)
+    std::vector<unsigned short> fmask[4], bmask[4];
+    for (int gy2 = 0; gy2 < (gy + 1) / 2; gy2++)
+        for (int gx2 = 0; gx2 < (gx + 1) / 2; gx2++) {
+            for (int m = 0; m < 4; m++) { fmask[m].clear(); bmask[m].clear(); }
+            for (int m = 0; m < 4; m++) {
+                const int tx = gx2 * 2 + (m & 1), ty = gy2 * 2 + (m >> 1);
+                if (tx >= gx || ty >= gy) continue;
+                const int tile = ty * gx + tx;
+                const unsigned r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+                FwdPix pix[256];
+                unsigned nc[256], last_of[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, last_blk[16];
+                long surv_f[256], surv_b[256];
+                for (int b = 0; b < 16; b++) last_blk[b] = 0;
+                for (int i = 0; i < 256; i++) {
+                    const int lx = i & 15, ly = i >> 4, x = tx * 16 + lx, y = ty * 16 + ly;
+                    const bool in = x < W && y < H;
+                    fwd_pix_init(pix[i], in);
+                    nc[i] = in ? n_contrib[(size_t)W * y + x] : 0u;
+                    surv_f[i] = surv_b[i] = 0;
+                    for (int s_ = 0; s_ < 3; s_++) {
+                        const int r = region_of(s_, lx, ly);
+                        if (nc[i] > last_of[s_][r]) last_of[s_][r] = nc[i];
+                    }
+                    const int b = (ly / 4) * 4 + lx / 4;
+                    if (nc[i] > last_blk[b]) last_blk[b] = nc[i];
+                }
+                long tile_trips_f[3] = {0, 0, 0}, tile_trips_b[3] = {0, 0, 0};
+                for (unsigned k = r0; k < r1; k++) {
+                    const unsigned pos = k - r0;
+                    const Splat s = splat_of(xy, conic_op, rgb, point_list[k]);
+                    const QSplat qs = scale_splat(s);
+                    // live pixels per region BEFORE this entry, then the per-pixel decisions
+                    bool live_r[3][4] = {{false}}, live_b[16];
+                    for (int b = 0; b < 16; b++) live_b[b] = false;
+                    for (int i = 0; i < 256; i++)
+                        if (fwd_pix_live(pix[i])) {
+                            const int lx = i & 15, ly = i >> 4;
+                            for (int s_ = 0; s_ < 3; s_++) live_r[s_][region_of(s_, lx, ly)] = true;
+                            live_b[(ly / 4) * 4 + lx / 4] = true;
+                        }
+                    bool keep_q0 = false;
+                    long nf[3] = {0, 0, 0}, nb[3] = {0, 0, 0};
+                    for (int s_ = 0; s_ < 3; s_++)
+                        for (int r = 0; r < 4; r++) {
+                            int x0, x1, y0, y1;
+                            region_box(s_, r, &x0, &x1, &y0, &y1);
+                            const bool keep = region_may_contribute(s, (float)(tx * 16 + x0), (float)(tx * 16 + x1),
+                                                                    (float)(ty * 16 + y0), (float)(ty * 16 + y1));
+                            if (s_ == 0) keep_q0 |= keep;
+                            nf[s_] += keep && live_r[s_][r];
+                            nb[s_] += keep && pos < last_of[s_][r];
+                        }
+                    out[0] += nf[0];
+                    out[20] += nb[0];
+                    out[2] += std::min(nf[0], std::min(nf[1], nf[2]));
+                    out[22] += std::min(nb[0], std::min(nb[1], nb[2]));
+                    out[4] += nf[1];
+                    out[24] += nb[1];
+                    out[5] += nf[2];
+                    out[25] += nb[2];
+                    for (int s_ = 0; s_ < 3; s_++) { tile_trips_f[s_] += nf[s_]; tile_trips_b[s_] += nb[s_]; }
+                    unsigned short mf = 0, mb = 0;
+                    for (int b = 0; b < 16; b++) {
+                        const float bx0 = (float)(tx * 16 + (b & 3) * 4), by0 = (float)(ty * 16 + (b >> 2) * 4);
+                        const bool keep = region_may_contribute(s, bx0, bx0 + 3.f, by0, by0 + 3.f);
+                        if (keep && live_b[b]) { mf |= (unsigned short)(1u << b); out[6]++; }
+                        if (keep && pos < last_blk[b]) { mb |= (unsigned short)(1u << b); out[26]++; }
+                    }
+                    fmask[m].push_back(mf);
+                    bmask[m].push_back(mb);
+                    out[11] += mf != 0;
+                    out[31] += mb != 0;
+                    for (int i = 0; i < 256; i++) {
+                        const int lx = i & 15, ly = i >> 4;
+                        const float fx = (float)(tx * 16 + lx), fy = (float)(ty * 16 + ly);
+                        bool inb;
+                        const float alpha = fwd_alpha(qs, fx, fy, &inb);
+                        const bool vis = inb && alpha >= 1.0f / 255.0f;
+                        if (vis && fwd_pix_live(pix[i])) { out[1]++; surv_f[i]++; }
+                        if (vis && pos < nc[i]) { out[21]++; surv_b[i]++; }
+                        float Tb;
+                        if (keep_q0) fwd_step(qs, fx, fy, pos + 1, pix[i], &Tb);
+                    }
+                }
+                out[3] += std::min(tile_trips_f[0], std::min(tile_trips_f[1], tile_trips_f[2]));
+                out[23] += std::min(tile_trips_b[0], std::min(tile_trips_b[1], tile_trips_b[2]));
+                for (int q = 0; q < 4; q++) {
+                    long mf = 0, mb = 0;
+                    for (int j = 0; j < 64; j++) {
+                        const int i = ((q >> 1) * 8 + (j >> 3)) * 16 + (q & 1) * 8 + (j & 7);
+                        mf = std::max(mf, surv_f[i]);
+                        mb = std::max(mb, surv_b[i]);
+                        out[8] += surv_f[i];
+                        out[28] += surv_b[i];
+                    }
+                    out[7] += mf;
+                    out[27] += mb;
+                }
+            }
+            // (iii): each row walks the entries of ITS tile that keep at least one block, the four rows side by side
+            for (int dir = 0; dir < 2; dir++) {
+                std::vector<unsigned short> rows[4];
+                size_t longest = 0;
+                for (int m = 0; m < 4; m++) {
+                    for (unsigned short v : (dir ? bmask[m] : fmask[m]))
+                        if (v) rows[m].push_back(v);
+                    longest = std::max(longest, rows[m].size());
+                }
+                out[9 + 20 * dir] += (long)longest;
+                for (size_t t = 0; t < longest; t++) {
+                    unsigned any = 0;
+                    for (int m = 0; m < 4; m++)
+                        if (t < rows[m].size()) any |= rows[m][t];
+                    out[10 + 20 * dir] += __builtin_popcount(any);
+                }
             }
         }
 }

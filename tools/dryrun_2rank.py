@@ -11,6 +11,10 @@ cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per
        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
        "--no-cpu-baseline"]
 out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+line = next((l for l in reversed(out.stdout.splitlines()) if l.startswith("{")), None)
+if line:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "dryrun_2rank_line.json"), "w").write(line + "\n")
 print(out.stdout[-3000:])
 print(out.stderr[-1500:], file=sys.stderr)
 sys.exit(out.returncode)

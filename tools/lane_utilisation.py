@@ -62,7 +62,50 @@ def run(name):
           f"{blk[3]} = {100 * blk[3] / max(4 * blk[0], 1):.1f} % of today's 4 blocks per trip")
     print(f"    backward: trips {blk[5]} -> {blk[2]} ({100 * blk[2] / max(blk[5], 1):.1f} %), kept (entry, 4x4 block) pairs "
           f"{blk[4]} = {100 * blk[4] / max(4 * blk[5], 1):.1f} %")
+    variants(L, name, W, H, st)
     sys.stdout.flush()
+
+
+# VALU instructions per trip of today's kernels at the metric shape (profiles/r05_pmc_summary.json: 92.3 M / 150.8 M VALU over
+# 3.45 M / 3.40 M evaluated (entry, quadrant) pairs) and what the pieces of a trip are taken to cost in the variants.  ASSUMPTIONS,
+# stated so that the prices can be redone: alpha evaluation (offsets, falloff, exp, min, two compares) 14; the forward's
+# recurrence (test, three FMAs, T update, bookkeeping) 12; the backward's accumulation 21 and its wave reduction + slab
+# bookkeeping 23 per reduced entry; an LDS record append / fetch in (ii) 5 each; a vector bit scan + LDS address per row and
+# trip in (iii) 8.
+I_F, I_B = 26.7, 44.3
+C_ALPHA, C_REC_F, C_ACC_B, C_RED_B, C_LIST, C_ROWSCAN = 14.0, 12.0, 21.0, 23.0, 5.0, 8.0
+
+
+def variants(L, name, W, H, st):
+    out = np.zeros(40, np.int64)
+    L.hc_lane_variants(C.c_int(W), C.c_int(H), p(st["ranges"]), p(st["point_list"]), p(st["xy"]), p(st["rgb"]),
+                       p(st["conic_op"]), p(st["n_contrib"]), p(out))
+    f, b = out[:20], out[20:]
+    print("  -- three alternative lane mappings, priced (VERDICT r5 item 5; raw counts from hc_lane_variants, prices from the "
+          "stated per-piece costs) --")
+    for tag, v, per_trip in (("forward ", f, I_F), ("backward", b, I_B)):
+        t0 = max(int(v[0]), 1)
+        print(f"  {tag}: today {t0} trips x {per_trip} VALU, {v[1]} useful lane-evaluations = {100 * v[1] / (64 * t0):.1f} % of the lanes")
+        print(f"    (i) footprints by orientation: 16x4 strips everywhere {v[4]} trips ({100 * v[4] / t0:.1f} %), 4x16 {v[5]} "
+              f"({100 * v[5] / t0:.1f} %); best footprint per TILE {v[3]} ({100 * v[3] / t0:.1f} %); per ENTRY (not realisable: a "
+              f"wave's pixels would change under its T recurrence) {v[2]} ({100 * v[2] / t0:.1f} %)")
+    # (ii): forward only -- the backward's nine sums are per ENTRY over pixels, lanes that walk their own lists are at
+    # different entries
+    t0 = max(int(f[0]), 1)
+    a_trips = f[6] / 4.0
+    cost_ii = a_trips * (C_ALPHA + C_LIST) + f[7] * (C_REC_F + C_LIST)
+    print(f"    (ii) two-phase walk, forward: phase A {f[6]} (entry, 4x4 block) items = {a_trips:.0f} trips of four, phase B "
+          f"{f[7]} trips (per quadrant: its busiest pixel's survivors; {f[8]} survivor records through LDS, "
+          f"{8 * f[8] / max((W * H), 1):.0f} B per pixel): "
+          f"{cost_ii / 1e6:.1f} M VALU against {t0 * I_F / 1e6:.1f} M today = {100 * cost_ii / (t0 * I_F):.1f} %  "
+          f"(backward: not applicable -- an entry's sums need its pixels at the same entry)")
+    for tag, v, per_slot, red in (("forward ", f, I_F, 0.0), ("backward", b, C_ALPHA + C_ACC_B, C_RED_B)):
+        t0 = max(int(v[0]), 1)
+        today = t0 * (I_F if red == 0.0 else I_B)
+        cost = v[10] * per_slot + v[9] * (C_ROWSCAN + red)
+        print(f"    (iii) a DPP row owns a tile, four tiles per wave, {tag}: {v[9]} trips, {v[10]} slots of 64 lanes "
+              f"({100 * v[1] / max(64 * v[10], 1):.1f} % of the lanes useful), {v[11]} (entry, tile) pairs -> "
+              f"{cost / 1e6:.1f} M VALU against {today / 1e6:.1f} M today = {100 * cost / today:.1f} %")
 
 
 if __name__ == "__main__":
