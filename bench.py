@@ -516,9 +516,14 @@ def main():
             step_compute_ms = max(1e3 * elapsed / args.steps - exchange_ms, 1e-3)
             exchange_forms = {"dense_fp32": {"exchange_ms": round(exchange_ms, 4), "bytes_per_rank": exch.bytes_per_rank(),
                                              "rows": P, "model": exchange_model(P, world, step_compute_ms)}}
-            for tag, kw in (("visible_union", dict(sparse=True)), ("bf16_sh_rest", dict(sh_rest_bf16=True)),
-                            ("visible_union_bf16_sh_rest", dict(sparse=True, sh_rest_bf16=True))):
+            rest_floats = 3.0 * (Kbar - 1.0)   # mean higher-band SH floats a row carries when the bands travel by degree
+            for tag, kw, by_degree in (("visible_union", dict(sparse=True), False), ("bf16_sh_rest", dict(sh_rest_bf16=True), False),
+                                       ("visible_union_bf16_sh_rest", dict(sparse=True, sh_rest_bf16=True), False),
+                                       ("sh_bands_by_degree", dict(), True),
+                                       ("sh_bands_by_degree_bf16", dict(sh_rest_bf16=True), True)):
                 ex2 = ViewParallelExchange(GRAD_SHAPES, P, device, two_phase=True, **kw)
+                if by_degree:
+                    ex2.set_degrees(degrees)
                 exch = ex2
                 if os.environ.get("R3DGS_BENCH_NO_ARENA") != "1":
                     _C.set_gradient_arena(ex2.arena)
@@ -548,7 +553,8 @@ def main():
                                        "rows": rows, "form": ex2.last["form"],
                                        "model": exchange_model(P, world, step_compute_ms, union_frac=rows / P,
                                                                sparse=bool(kw.get("sparse")),
-                                                               sh_rest_bf16=bool(kw.get("sh_rest_bf16")))}
+                                                               sh_rest_bf16=bool(kw.get("sh_rest_bf16")),
+                                                               sh_rest_floats=rest_floats if by_degree else 45.0)}
                 exchange_forms[tag]["serialised_iters_per_s_with_this_form"] = round(
                     world / ((step_compute_ms + exchange_forms[tag]["exchange_ms"]) * 1e-3), 2)
             exch = dense_ex

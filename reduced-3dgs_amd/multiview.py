@@ -23,7 +23,10 @@ its own stream and the buffers are double-buffered: the rasterizer's backward of
 straight into buffer k % 2 (`arena`), `exchange_async()` starts moving it, and step k+1's forward / backward
 proceed meanwhile on buffer (k+1) % 2; `wait()` is called where the optimizer needs the sums.
 
-Two opt-in transports cut the bytes a step puts on the links (round 6; DESIGN.md section 7 has the bytes / time model):
+Three opt-in transports cut the bytes a step puts on the links (round 6; DESIGN.md section 7 has the bytes / time model):
+  * `set_degrees(degrees)`: SH BANDS BY DEGREE.  For every band b >= 1 only the rows of the Gaussians whose degree reaches it
+    travel; the bands above a Gaussian's degree are exact zeros on every rank (the backward writes them as zeros) and the
+    degrees are replicated, so every rank derives the same row lists locally.  Lossless, bit-identical to the dense form.
   * `sparse=True | "auto"`: VISIBLE-UNION rows only.  The ranks all-gather their visibility bitmaps (P / 8 bytes each), OR
     them, and exchange a compact buffer holding the rows of the Gaussians at least one rank saw -- every other row is an
     exact zero on every rank by the rasterizer's contract (gradients, statistics and radii of a culled Gaussian are
@@ -60,6 +63,7 @@ class ViewParallelExchange:
         self.sparse_threshold = float(sparse_threshold)
         self.sh_rest_bf16 = bool(sh_rest_bf16) and "sh" in shapes and len(shapes["sh"]) == 2 and shapes["sh"][0] > 1
         self.last = {"form": "dense", "rows": int(P), "bytes": None}   # what the last exchange put on the links
+        self._deg, self._band_all = None, None                          # set_degrees()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = torch.device(device)
@@ -93,49 +97,108 @@ class ViewParallelExchange:
             self.recv = torch.empty(self.world * self.shard, dtype=torch.float32, device=self.device)
             self.mine = torch.empty(self.shard, dtype=torch.float32, device=self.device)
         # compact transport (visible-union rows and / or bfloat16 SH bands): its own buffer, sized for all P rows once
+        self._deg, self._band_all = None, None     # a new layout: the caller sets the degrees again (set_degrees)
         self.xbuf = None
-        if self.compact:
-            self.xbuf = torch.zeros(self._xlayout(P)["padded"], dtype=torch.float32, device=self.device)
+        if self.compact:   # sized for the dense row count (every compact form is at most that + its padding)
+            self.xbuf = torch.zeros(self.flats[0].numel() + self.world, dtype=torch.float32, device=self.device)
         w8 = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=self.device)
         self._bit_weights = w8
 
     @property
     def compact(self):
-        return bool(self.sparse) or self.sh_rest_bf16
+        return bool(self.sparse) or self.sh_rest_bf16 or self._deg is not None
 
-    def _xlayout(self, U):
-        """Layout of the compact exchange buffer for U rows, in 4-byte words: [fp32 SUM | bfloat16 pairs SUM | int32 MAX],
-        tensor after tensor inside each region (a Gaussian's row is `words_per_row` words in total)."""
-        off, parts = 0, {}
-        half = 0
+    def set_degrees(self, degrees):
+        """Per-Gaussian SH degrees ([P] or [P, 1] int tensor, the SAME on every rank -- `GaussianModel._degrees` is replicated
+        state) -> the exchange carries, for every SH band b >= 1, only the rows of the Gaussians whose degree reaches it:
+        the bands above a Gaussian's degree are exact zeros on every rank by the rasterizer's contract (its backward writes
+        them as zeros), so -- as with the visible-union rows -- the dense arena already holds their sum.  Lossless, bit-identical
+        to the dense form; the mixed-degree scenes the method produces (reduced-3dgs culls SH bands per Gaussian) drop from
+        248 to ~146 bytes per row at a uniform mix of degrees 0..3.  None switches it off.  Call it again whenever the degrees
+        change (oneupSHdegree, cull_sh_bands) and after resize()."""
+        if degrees is None or "sh" not in self.shapes or len(self.shapes["sh"]) != 2:
+            self._deg, self._band_all = None, None
+        else:
+            d = degrees.reshape(-1).to(device=self.device, dtype=torch.int64)
+            assert d.numel() == self.P, "set_degrees: one degree per Gaussian"
+            self._deg = d
+            nb = int(round(self.shapes["sh"][0] ** 0.5)) - 1          # highest band of the tensor (3 for M = 16)
+            self._band_all = {b: torch.nonzero(d >= b).squeeze(1) for b in range(1, nb + 1)}
+        if self.compact and self.xbuf is None:   # sized for the dense row count: whatever the degrees become, it fits
+            self.xbuf = torch.zeros(self.flats[0].numel() + self.world, dtype=torch.float32, device=self.device)
+
+    def _plan(self, idx, counts_only=None):
+        """The compact exchange buffer of a step as a list of SEGMENTS -- (tensor, column range of its per-Gaussian row, row
+        index list or None = all P rows, kind f32 | bf16 | i32) -- laid out in three regions of 4-byte words:
+        [fp32 SUM | bfloat16 pairs SUM | int32 MAX].  idx: the visible-union rows (None: all).  counts_only: a dict
+        {"rows": U, band: n_b} to lay out hypothetical counts (bytes_per_rank) without index lists."""
+        segs = []
+        U = (self.P if idx is None else int(idx.numel())) if counts_only is None else int(counts_only["rows"])
+
+        def band_rows(b):
+            if counts_only is not None:
+                return None, int(counts_only.get(b, U))
+            if self._deg is None:
+                return idx, U
+            if idx is None:
+                r = self._band_all[b]
+            else:
+                r = idx[self._deg.index_select(0, idx) >= b]
+            return r, int(r.numel())
         for name, shp in self.shapes.items():
             n = 1
             for s_ in shp:
                 n *= s_
-            if self.sh_rest_bf16 and name == "sh":
+            if name == "sh" and len(shp) == 2 and shp[0] > 1 and (self.sh_rest_bf16 or self._deg is not None):
                 ch = shp[1]
-                parts[name] = (off, off + U * ch, n - ch)      # the DC band stays fp32; n - ch halves per row follow
-                off += U * ch
-                half = U * (n - ch)
+                kind = "bf16" if self.sh_rest_bf16 else "f32"
+                segs.append(dict(name=name, c0=0, c1=ch, rows=idx, n=U, kind="f32"))          # the DC band: every row
+                if self._deg is None:
+                    segs.append(dict(name=name, c0=ch, c1=n, rows=idx, n=U, kind=kind))
+                else:
+                    nb = int(round(shp[0] ** 0.5)) - 1
+                    for b_ in range(1, nb + 1):
+                        r, cnt = band_rows(b_)
+                        segs.append(dict(name=name, c0=ch * b_ * b_, c1=ch * (b_ + 1) * (b_ + 1), rows=r, n=cnt, kind=kind))
             else:
-                parts[name] = (off, off + U * n, 0)
-                off += U * n
-        stat = off
-        sum_len = off + 2 * U
-        half_words = (half + 1) // 2
-        half_end = sum_len + half_words
-        total = half_end + U
+                segs.append(dict(name=name, c0=0, c1=n, rows=idx, n=U, kind="f32"))
+        segs.append(dict(name="@grad_norm", c0=0, c1=1, rows=idx, n=U, kind="f32"))
+        segs.append(dict(name="@visible", c0=0, c1=1, rows=idx, n=U, kind="f32"))
+        segs.append(dict(name="@radii", c0=0, c1=1, rows=idx, n=U, kind="i32"))
+        off = 0
+        for sg in segs:
+            if sg["kind"] == "f32":
+                sg["off"] = off
+                off += sg["n"] * (sg["c1"] - sg["c0"])
+        sum_len, half = off, 0
+        for sg in segs:
+            if sg["kind"] == "bf16":
+                sg["off"] = half                       # in halves, relative to the region
+                half += sg["n"] * (sg["c1"] - sg["c0"])
+        half_end = sum_len + (half + 1) // 2
+        off = half_end
+        for sg in segs:
+            if sg["kind"] == "i32":
+                sg["off"] = off
+                off += sg["n"]
+        total = off
         pad = (-total) % max(self.world, 1)
-        return {"parts": parts, "stat": stat, "sum_len": sum_len, "half": half, "half_end": half_end, "total": total,
+        return {"segs": segs, "rows": U, "sum_len": sum_len, "half": half, "half_end": half_end, "total": total,
                 "padded": total + pad, "shard": (total + pad) // max(self.world, 1)}
 
     def bytes_per_rank(self, rows=None):
         """Bytes ONE rank sends per step: (world - 1) / world of the buffer in each of the two phases (all-to-all, then
-        all-gather), plus -- sparse forms -- its visibility bitmap to every peer.  rows: the rows exchanged (default P)."""
+        all-gather), plus -- sparse forms -- its visibility bitmap to every peer.  rows: the rows exchanged (default P; the
+        per-band row counts of set_degrees are scaled with it)."""
         w = max(self.world, 1)
         if not self.compact:
             return int(2 * (w - 1) * self.shard * 4)
-        x = self._xlayout(self.P if rows is None else rows)
+        U = self.P if rows is None else int(rows)
+        counts = {"rows": U}
+        if self._band_all is not None:
+            for b_, r in self._band_all.items():
+                counts[b_] = int(round(int(r.numel()) * U / max(self.P, 1)))
+        x = self._plan(None, counts_only=counts)
         bitmap = (w - 1) * ((self.P + 7) // 8) if self.sparse else 0
         return int(2 * (w - 1) * x["shard"] * 4 + bitmap)
 
@@ -252,51 +315,57 @@ class ViewParallelExchange:
             return None
         return idx
 
+    def _dense2d(self, k, name):
+        """[P, n] view of a tensor's (or a statistic's) part of dense buffer k."""
+        flat, P, o = self.flats[k], self.P, self.stat_off
+        if name == "@grad_norm":
+            return flat[o:o + P].view(P, 1)
+        if name == "@visible":
+            return flat[o + P:o + 2 * P].view(P, 1)
+        if name == "@radii":
+            return self._radii_view(k).view(P, 1)
+        a, b, _shape = self.slices[name]
+        return flat[a:b].view(P, -1)
+
     def _pack_compact(self, k, idx):
-        flat, xb = self.flats[k], self.xbuf
-        U = self.P if idx is None else int(idx.numel())
-        x = self._xlayout(U)
-        rows = (lambda t: t) if idx is None else (lambda t: t.index_select(0, idx))
-        for name, (a, b, shape) in self.slices.items():
-            xa, xe, halves = x["parts"][name]
-            r = rows(flat[a:b].view(shape))
-            if halves:
-                xb[xa:xe] = r[:, 0, :].reshape(-1)
-                hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)
-                hv[:U * halves] = r[:, 1:, :].reshape(-1).to(torch.bfloat16)
-                if (U * halves) & 1:
-                    hv[U * halves] = 0
+        xb = self.xbuf
+        x = self._plan(idx)
+        hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)
+        for sg in x["segs"]:
+            if sg["n"] == 0:
+                continue
+            src = self._dense2d(k, sg["name"])[:, sg["c0"]:sg["c1"]]
+            r = (src if sg["rows"] is None else src.index_select(0, sg["rows"])).reshape(-1)
+            if sg["kind"] == "f32":
+                xb[sg["off"]:sg["off"] + r.numel()] = r
+            elif sg["kind"] == "bf16":
+                hv[sg["off"]:sg["off"] + r.numel()] = r.to(torch.bfloat16)
             else:
-                xb[xa:xe] = r.reshape(-1)
-        P, o = self.P, self.stat_off
-        xb[x["stat"]:x["stat"] + U] = rows(flat[o:o + P])
-        xb[x["stat"] + U:x["stat"] + 2 * U] = rows(flat[o + P:o + 2 * P])
-        xb[x["half_end"]:x["half_end"] + U].view(torch.int32).copy_(rows(self._radii_view(k)))
+                xb[sg["off"]:sg["off"] + r.numel()].view(torch.int32).copy_(r)
+        if x["half"] & 1:
+            hv[x["half"]] = 0
         xb[x["total"]:x["padded"]] = 0
         return x
 
     def _unpack_compact(self, k, idx, x):
-        flat, xb = self.flats[k], self.xbuf
-        U = self.P if idx is None else int(idx.numel())
-
-        def put(dst, src):
-            if idx is None:
-                dst.copy_(src.view(dst.shape))
+        xb = self.xbuf
+        hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)
+        for sg in x["segs"]:
+            if sg["n"] == 0:
+                continue
+            cols = sg["c1"] - sg["c0"]
+            cnt = sg["n"] * cols
+            if sg["kind"] == "f32":
+                r = xb[sg["off"]:sg["off"] + cnt]
+            elif sg["kind"] == "bf16":
+                r = hv[sg["off"]:sg["off"] + cnt].to(torch.float32)
             else:
-                dst.index_copy_(0, idx, src.view((U,) + tuple(dst.shape[1:])))
-        for name, (a, b, shape) in self.slices.items():
-            xa, xe, halves = x["parts"][name]
-            dst = flat[a:b].view(shape)
-            if halves:
-                hv = xb[x["sum_len"]:x["half_end"]].view(torch.bfloat16)[:U * halves]
-                r = torch.cat([xb[xa:xe].view(U, 1, shape[2]), hv.to(torch.float32).view(U, shape[1] - 1, shape[2])], dim=1)
-                put(dst, r)
+                r = xb[sg["off"]:sg["off"] + cnt].view(torch.int32)
+            dst = self._dense2d(k, sg["name"])[:, sg["c0"]:sg["c1"]]
+            if sg["rows"] is None:
+                dst.copy_(r.view(sg["n"], cols))
             else:
-                put(dst, xb[xa:xe])
-        P, o = self.P, self.stat_off
-        put(flat[o:o + P], xb[x["stat"]:x["stat"] + U])
-        put(flat[o + P:o + 2 * P], xb[x["stat"] + U:x["stat"] + 2 * U])
-        put(self._radii_view(k), xb[x["half_end"]:x["half_end"] + U].view(torch.int32))
+                dst.index_copy_(0, sg["rows"], r.view(sg["n"], cols))
 
     def _combine_compact(self, recv, mine, x):
         begin, shard = self.rank * x["shard"], x["shard"]
@@ -323,7 +392,7 @@ class ViewParallelExchange:
 
     def _run_compact(self, k):
         idx = self._union_rows(k)
-        if idx is None and not self.sh_rest_bf16:      # "auto" found (nearly) every row in the union: the dense form
+        if idx is None and not self.sh_rest_bf16 and self._deg is None:   # "auto" found (nearly) every row in the union: the dense form
             self.last = {"form": "dense (union above threshold)", "rows": self.P, "bytes": int(2 * (self.world - 1) * self.shard * 4)}
             return self._run_dense(k)
         x = self._pack_compact(k, idx)
@@ -335,10 +404,11 @@ class ViewParallelExchange:
         self._combine_compact(recv, mine, x)
         self._all_gather(send, mine)
         self._unpack_compact(k, idx, x)
-        U = self.P if idx is None else int(idx.numel())
+        bitmap = (self.world - 1) * ((self.P + 7) // 8) if self.sparse else 0
         self.last = {"form": ("visible-union rows" if idx is not None else "all rows") +
+                             (", SH bands by degree" if self._deg is not None else "") +
                              (", bf16 SH bands >= 1" if self.sh_rest_bf16 else ""),
-                     "rows": U, "bytes": self.bytes_per_rank(U)}
+                     "rows": x["rows"], "bytes": int(2 * (self.world - 1) * shard * 4 + bitmap)}
 
     def _run(self, k):
         if self.world > 1 and self.compact:
@@ -415,14 +485,15 @@ COLLECTIVE_LATENCY_US = 25.0  # assumed launch + synchronisation cost of one RCC
 
 
 def exchange_model(P, world, step_ms, floats_per_row=59, union_frac=1.0, sh_rest_bf16=False, sparse=False,
-                   link_GBps=XGMI_LINK_GBPS, latency_us=COLLECTIVE_LATENCY_US):
+                   sh_rest_floats=45.0, link_GBps=XGMI_LINK_GBPS, latency_us=COLLECTIVE_LATENCY_US):
     """Predicted cost of one step's exchange on a full xGMI mesh and the serialised speed-up it allows.
     Row = floats_per_row gradient floats + 2 statistics + 1 radius (4 bytes each; the 45 higher-band SH floats 2 bytes each
-    with sh_rest_bf16).  Two phases (all-to-all, all-gather); in each a rank sends 1 / world of the buffer to every peer
+    with sh_rest_bf16; sh_rest_floats < 45: the MEAN number of higher-band SH floats a row carries when the bands travel by
+    degree, set_degrees -- 3 ((deg + 1)^2 - 1) averaged over the Gaussians, 19.5 for a uniform mix of degrees 0..3).  Two phases (all-to-all, all-gather); in each a rank sends 1 / world of the buffer to every peer
     over that peer's own link, so a phase takes buffer / world / link bandwidth + one collective latency.  sparse adds the
     bitmap all-gather (P / 8 bytes to every peer) and moves union_frac x P rows.
     -> dict(bytes_per_row, buffer_bytes, bytes_per_link_per_phase, exchange_ms, speedup, efficiency)."""
-    row = 4 * (floats_per_row + 3) - (2 * 45 if sh_rest_bf16 else 0)
+    row = 4 * (floats_per_row + 3 - 45) + (2 if sh_rest_bf16 else 4) * sh_rest_floats
     rows = P * (union_frac if sparse else 1.0)
     buf = row * rows
     per_link = buf / world
@@ -431,7 +502,7 @@ def exchange_model(P, world, step_ms, floats_per_row=59, union_frac=1.0, sh_rest
     if sparse:
         t += (P / 8.0) / (link_GBps * 1e9) * 1e3 + latency_us * 1e-3
     speedup = world * step_ms / (step_ms + t) if world > 1 else 1.0
-    return {"bytes_per_row": row, "rows": int(rows), "buffer_bytes": int(buf), "bytes_per_link_per_phase": int(per_link),
+    return {"bytes_per_row": round(row, 1) if row != int(row) else int(row), "rows": int(rows), "buffer_bytes": int(buf), "bytes_per_link_per_phase": int(per_link),
             "exchange_ms": round(t, 4), "speedup": round(speedup, 2), "efficiency": round(speedup / world, 3),
             "assumes": f"{link_GBps:.0f} GB/s per link and direction, {latency_us:.0f} us per collective, full mesh"}
 

@@ -266,8 +266,16 @@ def _contract_inputs(rank, Pn, step, seen=0.45):
     radii[(torch.rand(Pn, generator=g) > seen) | never] = 0
     vis = radii > 0
     grads = {k: torch.randn((Pn,) + s, generator=g) * vis.view((-1,) + (1,) * len(s)) for k, s in SHAPES.items()}
+    # ... and exact zeros in the SH bands above its degree (the degrees are replicated state: the same on every rank)
+    deg = _degrees(Pn, step)
+    keep = (torch.arange(16)[None, :] < ((deg.view(-1, 1) + 1) ** 2)).unsqueeze(-1)
+    grads["sh"] = grads["sh"] * keep
     vgrad = torch.randn(Pn, 3, generator=g) * vis.view(-1, 1)
     return grads, vgrad, radii
+
+
+def _degrees(Pn, step):
+    return torch.randint(0, 4, (Pn,), generator=torch.Generator().manual_seed(555 + step), dtype=torch.int32)
 
 
 XC_SIZES = [257, 301, 94]   # none divisible by 4; the count changes between steps (resize)
@@ -283,7 +291,9 @@ def _xc_worker(rank, world, port, q):
     cpu = torch.device("cpu")
     forms = {"dense": dict(), "sparse": dict(sparse=True), "auto_low": dict(sparse="auto", sparse_threshold=0.05),
              "auto_high": dict(sparse="auto", sparse_threshold=0.999), "bf16": dict(sh_rest_bf16=True),
-             "sparse_bf16": dict(sparse=True, sh_rest_bf16=True)}
+             "sparse_bf16": dict(sparse=True, sh_rest_bf16=True),
+             # SH bands by degree (set_degrees): lossless, alone and on top of the other two
+             "bands": dict(), "sparse_bands": dict(sparse=True), "sparse_bands_bf16": dict(sparse=True, sh_rest_bf16=True)}
     exs = {n: ViewParallelExchange(SHAPES, XC_SIZES[0], cpu, two_phase=True, **kw) for n, kw in forms.items()}
     res = []
     for step, Pn in enumerate(XC_SIZES):
@@ -291,6 +301,8 @@ def _xc_worker(rank, world, port, q):
         per_form = {}
         for n, ex in exs.items():
             ex.resize(Pn)
+            if "bands" in n:
+                ex.set_degrees(_degrees(Pn, step).view(-1, 1))
             born = {}
             for k, v in grads.items():      # gradients born in the dense arena, as set_gradient_arena arranges
                 t = ex.arena(k, tuple(v.shape))
@@ -334,7 +346,7 @@ def _run_xc(world):
             forms = results[rank][step]
             # (1) the fp32 compact forms are the dense form BIT FOR BIT: the same rank-order sums per element, and rows
             #     outside the union are the exact zeros every rank already holds
-            for n in ("sparse", "auto_low", "auto_high"):
+            for n in ("sparse", "auto_low", "auto_high", "bands", "sparse_bands"):
                 for k in SHAPES:
                     np.testing.assert_array_equal(forms[n][0][k], forms["dense"][0][k], err_msg=f"{n} {k} step {step}")
                 for j in (1, 2, 3):
@@ -355,7 +367,7 @@ def _run_xc(world):
             # (4) bfloat16 SH bands >= 1: every other tensor, the DC band, statistics and radii are the dense bits; the
             #     higher bands are the fp32 sum of the bf16-rounded per-rank values, rounded once more: within 2^-7 x world x
             #     the largest addend per element (two roundings of relative 2^-8 each -- bfloat16 carries 8 significant bits)
-            for n in ("bf16", "sparse_bf16"):
+            for n in ("bf16", "sparse_bf16", "sparse_bands_bf16"):
                 for k in SHAPES:
                     if k != "sh":
                         np.testing.assert_array_equal(forms[n][0][k], dense0[0][k])
@@ -369,12 +381,16 @@ def _run_xc(world):
                 as_bf16 = torch.from_numpy(hi.copy()).to(torch.bfloat16).to(torch.float32).numpy()
                 np.testing.assert_array_equal(as_bf16, hi)   # the replicas continue with bfloat16-representable sums
                 np.testing.assert_array_equal(forms["sparse_bf16"][0]["sh"], forms["bf16"][0]["sh"])
+                np.testing.assert_array_equal(forms["sparse_bands_bf16"][0]["sh"], forms["bf16"][0]["sh"])
             # (5) what went over the links
             assert forms["sparse"][4]["rows"] == U and forms["sparse"][4]["form"].startswith("visible-union")
             assert forms["auto_high"][4]["rows"] == U                     # union below the threshold: sparse
             assert forms["auto_low"][4]["form"].startswith("dense")       # union above it: the dense form for this step
             assert forms["sparse"][5] < forms["dense"][6] and forms["sparse_bf16"][5] < forms["sparse"][5]
             assert forms["bf16"][6] < 0.7 * forms["dense"][6]             # 248 -> 158 bytes per Gaussian
+            # SH bands by degree at a uniform mix of degrees 0..3: 48 -> ~22.5 SH floats per row, 248 -> ~146 bytes
+            assert forms["bands"][4]["form"] == "all rows, SH bands by degree" and 0.5 < forms["bands"][5] / forms["dense"][6] < 0.68
+            assert forms["sparse_bands"][5] < forms["sparse"][5] and forms["sparse_bands_bf16"][5] < forms["sparse_bands"][5]
 
 
 def test_world2_compact_transports_equal_dense():
