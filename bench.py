@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 import synth_scene as ss  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
-PROFILE_ROUND = "r05" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")) else "r04"
+PROFILE_ROUND = next((r for r in ("r06", "r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_summary.json"))), "r04")
 # committed rocprofv3 --pmc summaries (tools/pmc_summary.py), per workload they were collected on
 PMC_SUMMARIES = {
     "metric_500k_1600x1062": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary.json"),
@@ -43,7 +43,7 @@ PMC_SUMMARIES = {
     "clustered_500k_1600x1062": os.path.join("profiles", f"{PROFILE_ROUND}_pmc_summary_clustered_500k.json"),
 }
 PMC_SUMMARY = PMC_SUMMARIES["metric_500k_1600x1062"]
-VALU_RATE = next((p_ for p_ in (os.path.join("profiles", n) for n in ("r05_valu_rate.txt", "r04_valu_rate_warm.txt",
+VALU_RATE = next((p_ for p_ in (os.path.join("profiles", n) for n in ("r06_valu_rate.txt", "r05_valu_rate.txt", "r04_valu_rate_warm.txt",
                                                                       "r03_valu_rate.txt"))
                   if os.path.exists(os.path.join(ROOT, p_))), None)
 KERNEL_STATS = os.path.join("profiles", f"{PROFILE_ROUND}_kernel_stats_bench_500k_1600x1062.csv")

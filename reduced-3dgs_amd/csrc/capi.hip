@@ -681,11 +681,12 @@ FwdPlan make_fwd_plan(const FwdCall& c, uint32_t reserve)
     p.fwd_ppl = ppl0 == 3 ? 2 : ppl0;
     p.color_grid = color_grid_env >= 0 ? color_grid_env : std::min(4096, std::max(512, c.P / 512));
     static const int fuse = env_int("R3DGS_COLOR_FUSE", 1, 0, 1);
-    // share of the colour chunks carried by the histogram / scatter / bucket-sort launches: 20 / 35 / 45 % (measured at
-    // 500 k), 25 / 25 / 50 % above 1 M Gaussians (2 M: stage 0.257 vs 0.266 ms, 6 M: 0.762 vs 0.778)
+    // share of the colour chunks carried by the histogram / scatter / bucket-sort launches: 25 / 45 / 30 % up to 1 M Gaussians
+    // (round 6, profiles/r06_sweep_colour_split.txt: depth sort + colour 0.0896 against 0.0929 ms with round 5's 20 / 35 / 45 at
+    // 500 k, both alternating rounds), 25 / 25 / 50 % above (2 M: stage 0.257 vs 0.266 ms, 6 M: 0.762 vs 0.778)
     static const int split0_env = env_int("R3DGS_COLOR_SPLIT0", -1, 0, 100), split1_env = env_int("R3DGS_COLOR_SPLIT1", -1, 0, 100);
     const bool big = c.P > (1 << 20);
-    const int split0 = split0_env >= 0 ? split0_env : big ? 25 : 20, split1 = split1_env >= 0 ? split1_env : big ? 25 : 35;
+    const int split0 = split0_env >= 0 ? split0_env : 25, split1 = split1_env >= 0 ? split1_env : big ? 25 : 45;
     p.color_fuse = fuse;
     p.color_split[0] = split0;
     p.color_split[1] = split0 + split1 > 100 ? 100 - split0 : split1;

@@ -223,11 +223,12 @@ CHAIN_F64_VS_FP32_ORACLE_REL = 2.5e-4
 # in which a Gaussian's per-pixel terms were summed -- atomics in the reference: its own result varies run to run by as
 # much) beyond 1e-4.  At most CHAIN_ILL_MAX_FRACTION of a tensor's elements may be such exceptions, each is printed, none
 # may be further than CHAIN_ILL_CAP from the oracle; and the chain's arithmetic itself is held on EVERY element by feeding
-# the oracle's chain the HIP path's own inputs (CHAIN_SAME_INPUTS_REL).
+# the oracle's chain the HIP path's own inputs: the outputs must then be EQUAL, bit for bit (measured so in round 6: both
+# sides are the same fp32 expressions built with -ffp-contract=off and correctly rounded division / sqrt).
 CHAIN_ILL_KAPPA = 500.0
 CHAIN_ILL_MAX_FRACTION = 1e-5
 CHAIN_ILL_CAP = 1e-3
-CHAIN_SAME_INPUTS_REL = 2e-6
+CHAIN_SAME_INPUTS_REL = 0.0   # measured 0: the product's fp32 chain and the oracle's are the same arithmetic, bit for bit
 chain_exceptions = {}   # test id -> [(tensor, element, |hip - oracle| / max, kappa)]
 
 
@@ -304,6 +305,7 @@ def check_backward(bout, gr, st, M, rel=GRAD_REL, per_element=True, gr64=None, c
         for name, got in (("dL_dcov3D", dcov), ("dL_dscales", dsc), ("dL_drotations", drot), ("dL_dmeans3D", dm3)):
             grads_close(name + tag + " [oracle chain fed the hip 2D sums]", fed[name], got, CHAIN_SAME_INPUTS_REL,
                         per_element=False)
+            np.testing.assert_array_equal(got.cpu().numpy().reshape(fed[name].shape), fed[name])   # (bit for bit, in fact)
     # API contract: exact zeros for culled Gaussians and for SH bands above a Gaussian's degree
     inv = torch.from_numpy(st["radii"] == 0).cuda()
     for t in (dm2, dcol, dop, dm3, dcov, dsc, drot):

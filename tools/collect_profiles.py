@@ -1,4 +1,4 @@
-"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r05_* and regenerates profiles/README.md."""
+"""Copies the outputs of tools/refresh_profiles.sh (gpurun_out/) into profiles/r06_* and regenerates profiles/README.md."""
 import os
 import shutil
 import subprocess
@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-R = "r05"
+R = "r06"
 
 
 def last_line(src, dst, mode="w"):
@@ -27,7 +27,11 @@ shutil.copy(os.path.join(G, "pmc_summary.json"), os.path.join(P, f"{R}_pmc_summa
 for tag in ("2M", "6M", "clustered_500k"):
     if os.path.exists(os.path.join(G, f"pmc_summary_{tag}.json")):
         shutil.copy(os.path.join(G, f"pmc_summary_{tag}.json"), os.path.join(P, f"{R}_pmc_summary_{tag}.json"))
-shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate.txt"))
+if os.path.exists(os.path.join(G, "valu_rate.txt")):
+    shutil.copy(os.path.join(G, "valu_rate.txt"), os.path.join(P, f"{R}_valu_rate.txt"))
+for extra in ("sweep_colour_split.txt", "dryrun_2rank_line.json"):
+    if os.path.exists(os.path.join(G, extra)):
+        shutil.copy(os.path.join(G, extra), os.path.join(P, f"{R}_{extra}"))
 if os.path.exists(os.path.join(G, "other_workloads.jsonl")):
     shutil.copy(os.path.join(G, "other_workloads.jsonl"), os.path.join(P, f"{R}_other_workloads.jsonl"))
 for tl in ("bwd_timeline", "bwd_timeline_clustered", "bwd_timeline_clustered_whole_lists", "fwd_timeline"):
@@ -36,7 +40,7 @@ for tl in ("bwd_timeline", "bwd_timeline_clustered", "bwd_timeline_clustered_who
 open(os.path.join(P, f"{R}_gpu_tests.txt"), "w").write(open(os.path.join(G, "pytest_gpu.log")).read() +
                                                        "\n" + open(os.path.join(G, "smoke.log")).read()[-1600:])
 if os.path.exists(os.path.join(G, "ab_rounds.txt")):
-    shutil.copy(os.path.join(G, "ab_rounds.txt"), os.path.join(P, f"{R}_ab_round4_vs_round5.txt"))
+    shutil.copy(os.path.join(G, "ab_rounds.txt"), os.path.join(P, f"{R}_ab_round5_vs_round6.txt"))
 if os.path.exists(os.path.join(G, "host_bound.log")):
     shutil.copy(os.path.join(G, "host_bound.log"), os.path.join(P, f"{R}_host_bound_bindings.txt"))
 for wl, short in (("garden_like_2M_1600x1062", "garden_like_2M"), ("train_like_6M_1920x1080", "train_like_6M"),

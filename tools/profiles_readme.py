@@ -1,4 +1,4 @@
-"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r05_*).
+"""Regenerates profiles/README.md from the committed measurement files of the round (profiles/r06_*).
 
     python tools/profiles_readme.py
 
@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = os.path.join(ROOT, "profiles")
-R, PREV = "r05", "r04"   # bracketed numbers: the previous round's files
+R, PREV = "r06", "r05"   # bracketed numbers: the previous round's files
 
 
 def jl(name):
@@ -66,7 +66,7 @@ def kernel_table():
     cols = {w: kstats(f"{R}_kernel_stats_{short}.csv") for w, short, _ in WL}
     old = {"metric_500k_1600x1062": ks_old, "garden_like_2M_1600x1062": kstats(f"{PREV}_kernel_stats_garden_like_2M.csv"),
            "train_like_6M_1920x1080": kstats(f"{PREV}_kernel_stats_train_like_6M.csv")}
-    out = ["| kernel (µs, rocprofv3 --kernel-trace --stats; [round 4]) | " + " | ".join(w for w, _, _ in WL) + " |", "|---|" + "---|" * len(WL)]
+    out = ["| kernel (µs, rocprofv3 --kernel-trace --stats; [round 5]) | " + " | ".join(w for w, _, _ in WL) + " |", "|---|" + "---|" * len(WL)]
     for label, prefix in KERNELS:
         cells = []
         for w, _, _ in WL:
@@ -104,7 +104,7 @@ def traffic_table():
 
 
 def others_table():
-    out = ["| workload | it/s [round 4] | ms/step | stages ms: " + " / ".join(STAGES) + " | render FPS |", "|---|---|---|---|---|"]
+    out = ["| workload | it/s [round 5] | ms/step | stages ms: " + " / ".join(STAGES) + " | render FPS |", "|---|---|---|---|---|"]
     for w, o in others.items():
         prev = f" [{old_others[w]['value']}]" if w in old_others else ""
         out.append(f"| {w} (P = {o['config']['gaussians']}, R̄ = {o['config']['num_rendered_mean'] / 1e6:.2f} M, binned "
@@ -116,15 +116,18 @@ def others_table():
 
 def txt(name, skip="/opt"):
     p_ = os.path.join(P, name)
+    if not os.path.exists(p_) and name.startswith(R + "_"):   # not re-collected this round: the previous round's file
+        p_ = os.path.join(P, PREV + name[len(R):])
     return "".join(l for l in open(p_) if not l.startswith(skip)) if os.path.exists(p_) else "(not collected)\n"
 
 
 vb = bench.pmc_valu("blend_bwd", "metric_500k_1600x1062", st["blend_bwd"]["avg_ms"])
 vf = bench.pmc_valu("blend_fwd", "metric_500k_1600x1062", st["blend_fwd"]["avg_ms"])
-f64 = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if "f64" in l and " 8 waves/SIMD" in l]
-f32 = [l.rstrip() for l in open(os.path.join(P, f"{R}_valu_rate.txt")) if l.startswith("v_fma_f32 ") and " 8 waves/SIMD" in l]
+VR = os.path.join(P, f"{R}_valu_rate.txt") if os.path.exists(os.path.join(P, f"{R}_valu_rate.txt")) else os.path.join(P, f"{PREV}_valu_rate.txt")
+f64 = [l.rstrip() for l in open(VR) if "f64" in l and " 8 waves/SIMD" in l]
+f32 = [l.rstrip() for l in open(VR) if l.startswith("v_fma_f32 ") and " 8 waves/SIMD" in l]
 
-new = f'''# profiles/ — measurements on MI355X (round 5)
+new = f'''# profiles/ — measurements on MI355X (round 6)
 
 Every `{R}_*` file comes from visits of `tools/refresh_profiles.sh` to a 1-GPU MI355X box (gfx950, ROCm 7.2, torch 2.10+rocm7.0;
 256 visible CPUs, **cgroup CPU quota 16**); `tools/collect_profiles.py` copies the results here and runs this generator
@@ -132,7 +135,7 @@ Every `{R}_*` file comes from visits of `tools/refresh_profiles.sh` to a 1-GPU M
 (workload `metric_500k_1600x1062`: 500 000 Gaussians, 1600×1062, SH degree 3, SURVEY.md §8d recipe, 8 cameras; V̄ =
 {d50['config']['visible_mean'] / 1e3:.0f}k visible, `num_rendered` R̄ = {d50['config']['num_rendered_mean'] / 1e6:.2f} M — the reference's count, which the byte formulas are
 written in — of which {d50['config']['pairs_binned_mean'] / 1e6:.2f} M (tile, Gaussian) pairs are binned, N = 1.70 Mpix) unless a workload is named.  These are
-this build's own visits; **the number of record is the driver's `BENCH_r05.json`**.  Boxes differ: one visit of this round measured
+this build's own visits; **the number of record is the driver's `BENCH_r06.json`**.  Boxes differ: one visit of this round measured
 every stage 1.2–1.4× slower than the others (1057 it/s for the same build), so every A/B below is from ONE visit, with the
 previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds are compared.
 
@@ -144,7 +147,7 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | `{R}_kernel_stats_*.csv` | `rocprofv3 --kernel-trace --stats` of `bench.py --steps 10 --warmup 3` on the metric workload, the clustered 500 k scene, 2 M, 6 M @1920×1080 and the clustered 2 M scene |
 | `{R}_pmc_summary.json` | (`tools/pmc_summary.py`) per-kernel means of four separate `rocprofv3 --kernel-trace --pmc …` passes (VALU instructions by class; SQ activity / wait / LDS counters; `FETCH_SIZE`; `WRITE_SIZE`) of `bench.py --steps 3 --warmup 1`; `bench.py` cites it as `roofline.traffic`, `roofline.valu`, `stages.*.counter_bytes` |
 | `{R}_pmc_summary_2M.json`, `_6M.json`, `_clustered_500k.json` | the `FETCH_SIZE` / `WRITE_SIZE` passes of the same command on those workloads (`bench.py --workload …` cites them) |
-| `{R}_ab_round4_vs_round5.txt` | five workloads through round 4's library and this round's, alternating, in one visit |
+| `{R}_ab_round5_vs_round6.txt` | five workloads through round 5's library and this round's, alternating, in one visit |
 | `{R}_other_workloads.jsonl` | `tools/other_workloads.sh`: bench.py lines of the configs[0..4] stand-ins and of the two clustered scenes |
 | `{R}_bwd_timeline.txt`, `{R}_bwd_timeline_clustered.txt`, `{R}_bwd_timeline_clustered_whole_lists.txt` | `tools/bwd_timeline.py` (debug build `-DR3_TIMELINE`): when and where every workgroup of the backward blend ran — metric scene, clustered scene with list segments (default) and without |
 | `{R}_bwd_tail_model_clustered_500k.txt` | `tools/bwd_tail_model.py clustered_500k_1600x1062`: tile-weight histogram of the clustered scene and the processor-sharing model of its schedule |
@@ -156,15 +159,19 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | `{R}_valu_rate.txt` | `tools/valu_rate.hip`: cycles per wave64 instruction and SIMD for 25 instruction kinds at 1 / 2 / 4 / 5 / 8 waves per SIMD, now with `v_fma_f64 / v_mul_f64 / v_add_f64` |
 | `{R}_gpu_tests.txt` | `pytest tests -m gpu -s`: every gradient distance measured (HIP vs the fp32 oracle, HIP vs the double evaluation, fp32 oracle vs the double evaluation, the fp32-chain mode, segments vs whole lists), the own-loop report |
 | `{R}_host_bound_bindings.txt` | `tools/host_bound_bench.py`: steps/s of the 10k and 300k workloads through the ctypes marshalling and the compiled torch binding |
-| `r01_*` … `r04_*` | earlier rounds, kept for comparison |
+| `{R}_contraction_flips.txt` | `tools/contraction_flips.py` (CPU): integer outputs that differ between the oracle built with `-ffp-contract=off` and with `-ffp-contract=fast -mfma`, per BASELINE config stand-in, seen from a rotated camera — the error bar on "bit-exact vs a CUDA build" (INTEGRATION.md §5) |
+| `{R}_exp_prebwd_lean.txt` | one-visit A/B of a lean form of the per-Gaussian backward (half-wave LDS windows, 3 / 4 / 5 waves per SIMD by launch bounds): no gain at three waves, 20 % / 85 % slower with the spills the fourth / fifth wave cost — not in the tree |
+| `{R}_sweep_colour_split.txt` | `tools/ab.sh`: colour-stream grid / split and depth-bucket-load knobs around the defaults, two alternating rounds |
+| `{R}_dryrun_2rank_line.json` | `tools/dryrun_2rank.py`: the bench line of the N > 1 code path run as two ranks on ONE GPU over gloo (functional only): `exchange_forms` lists every compact transport with its bytes and the model's prediction |
+| `r01_*` … `r05_*` | earlier rounds, kept for comparison |
 
 ## Headline (N = 1)
 
 | | value |
 |---|---|
-| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, strict), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) [round 4: {old50['value']}] |
+| training iterations/s (fwd + bwd through the autograd boundary, 1 view/iter, strict), 50 steps | **{d50['value']} it/s** ({d50['ms_per_step']} ms/step; GPU first-to-last kernel {d50['host']['gpu_event_ms_per_step']} ms/step; Σ stage {d50['host']['gpu_stage_ms_sum']} ms) [round 5: {old50['value']}] |
 | the driver's form, 20 steps / 5 warm-up | **{d20['value']} it/s** ({d20['ms_per_step']} ms/step = {d20['host']['step_over_gpu_stage_sum']} × Σ stage ms); passes in the timed region: {d20['config']['passes_in_timed_region']} |
-| stages ms ({' / '.join(STAGES)}) | {stages_of(d50)} [round 4: {stages_of(old50)}] |
+| stages ms ({' / '.join(STAGES)}) | {stages_of(d50)} [round 5: {stages_of(old50)}] |
 | same, strict mode off | {ab['nonstrict']['value']} it/s |
 | `lambda_sh_sparsity = 0.1` (full_eval.py:33,44) | {d50['value_sh_sparsity']} it/s ({d50['sh_sparsity']['ms_per_step']} ms/step) |
 | reference rects (`R3DGS_TIGHT_RECT=0`) | {ab['refrects']['value']} it/s, stages {stages_of(ab['refrects'])} |
@@ -173,14 +180,14 @@ previous round's library (`R3DGS_LIB=old`) run beside the new one where rounds a
 | under `cpu_burn 64` | {burn[0]['value']} / {burn[1]['value']} it/s |
 | render only (`render.py`'s FPS path) | {d50['render_fps']} FPS = {d50['render_mpix_per_s']} Mpix/s |
 | dominant kernel against the HBM roof (contract form) | `blend_bwd` stage: {d50['roofline']['achieved']} GB/s of SURVEY §8d bytes = **{d50['roofline']['frac']}** of 8 TB/s; bytes that moved per launch (counters): {d50['roofline']['traffic'] / 1e6:.0f} MB |
-| dominant kernel against the roof that binds it (VALU issue) | `blend_bwd_kernel`: {vb['insts'] / 1e6:.1f} M VALU instructions, floor {vb['floor_ms']} ms / kernel {vb['kernel_ms_committed_profile']} ms = **{vb['floor_ms'] / vb['kernel_ms_committed_profile']:.2f}** [round 4: 0.72]; `blend_fwd_kernel`: floor {vf['floor_ms']} / {vf['kernel_ms_committed_profile']} ms = {vf['floor_ms'] / vf['kernel_ms_committed_profile']:.2f} |
+| dominant kernel against the roof that binds it (VALU issue) | `blend_bwd_kernel`: {vb['insts'] / 1e6:.1f} M VALU instructions, floor {vb['floor_ms']} ms / kernel {vb['kernel_ms_committed_profile']} ms = **{vb['floor_ms'] / vb['kernel_ms_committed_profile']:.2f}** [round 5: 0.84]; `blend_fwd_kernel`: floor {vf['floor_ms']} / {vf['kernel_ms_committed_profile']} ms = {vf['floor_ms'] / vf['kernel_ms_committed_profile']:.2f} |
 | whole iteration | `B_iter` = {d50['iter_roofline']['B_iter_bytes'] / 1e9:.3f} GB (reference-algorithm bytes) → {100 * d50['iter_roofline']['frac_of_8TBps']:.1f} % of 8 TB/s (target 40 %); bytes the counters saw move: {d50['iter_roofline']['counter_traffic_bytes'] / 1e9:.2f} GB/step = {100 * d50['iter_roofline']['frac_counter_traffic']:.1f} % |
 | CPU baseline (`cpu_baseline`, kind "port") | {d50['cpu_baseline']['value']} it/s on {d50['cpu_baseline']['cores']} threads of a {d50['cpu_baseline'].get('cpu_model')}: {d50['cpu_baseline']['sample'][:110]}…; the bench workload itself by the C restatement: {d50['cpu_baseline']['same_workload_sample']['value']} it/s |
 
-## This round's library against round 4's, same visit (`{R}_ab_round4_vs_round5.txt`: `bench.py --steps 20 --warmup 5 --cameras 4`, `R3DGS_LIB=old` = the round-4 tree built beside)
+## This round's library against round 5's, same visit (`{R}_ab_round5_vs_round6.txt`: `bench.py --steps 20 --warmup 5 --cameras 4`, `R3DGS_LIB=old` = the round-5 tree built beside)
 
 ```
-{txt(f"{R}_ab_round4_vs_round5.txt")}```
+{txt(f"{R}_ab_round5_vs_round6.txt")}```
 
 ## Kernels
 
@@ -202,7 +209,7 @@ moves (the reference's 64-bit key sort) and can exceed the HBM peak; `counter_GB
 Tile weights (`{R}_bwd_tail_model_clustered_500k.txt`, first lines):
 
 ```
-{"".join(open(os.path.join(P, f"{R}_bwd_tail_model_clustered_500k.txt")).readlines()[:3])}```
+{"".join(open(os.path.join(P, f"{R if os.path.exists(os.path.join(P, f'{R}_bwd_tail_model_clustered_500k.txt')) else PREV}_bwd_tail_model_clustered_500k.txt")).readlines()[:3])}```
 
 Whole tile lists (`R3DGS_BWD_SEG=0`; one workgroup per tile, heaviest first) — the chip drains for the last third of the kernel:
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit that regenerates everything under profiles/r05_* (run through gpurun; results land in gpurun_out/,
+# One GPU-box visit that regenerates everything under profiles/r06_* (run through gpurun; results land in gpurun_out/,
 # tools/collect_profiles.py copies them into profiles/ and regenerates profiles/README.md).
 set -u
 export PYTHONPATH=$PWD:$PWD/reduced-3dgs_amd TMPDIR=/tmp
