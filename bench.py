@@ -120,7 +120,9 @@ STAGE_KERNELS = {
     # (the kernel that orders the backward's (tile, segment) units heaviest first runs inside this stage's events too)
     "blend_bwd": [("r3::blend_bwd_kernel<4, true, false>", 1, True), ("r3::pair_reduce_kernel", 1, False),
                   ("r3::unit_order_kernel", 1, False)],
-    "preprocess_bwd": [("r3::preprocess_bwd_kernel<", 1, False)],   # <dense degree-3 rows?, covariance chain in double?>
+    # <dense degree-3 rows (M = 16: every workload here), covariance chain in double (the default; R3DGS_F64_CHAIN=0: the other)>
+    "preprocess_bwd": [("r3::preprocess_bwd_kernel<true, " + ("false" if os.environ.get("R3DGS_F64_CHAIN") == "0" else "true") + ">",
+                        1, False)],
 }
 
 
@@ -303,6 +305,9 @@ def main():
     ap.add_argument("--workload", default="metric_500k_1600x1062", choices=list(ss.WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cameras", type=int, default=8)
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed region and its instrumented pass: no render-only, lambda_sh_sparsity or reference-mode "
+                         "leg -- for rocprofv3 passes, whose per-kernel means would otherwise mix those legs' launches in")
     args = ap.parse_args()
     cg_warm0 = cgroup_cpu()   # throttling seen from here to the timed region decides whether to align with a period
     ncpu = effective_cpus()
@@ -593,7 +598,7 @@ def main():
     with torch.no_grad():
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(0 if args.main_only else args.steps):
             s_ = settings[cam_index(i)]
             _C.rasterize_gaussians(s_.bg, leaves["means3D"], empty, leaves["opacity"], leaves["scales"],
                                    leaves["rotations"], 1.0, empty, s_.viewmatrix, s_.projmatrix, s_.tanfovx,
@@ -606,7 +611,7 @@ def main():
     # of the direction derivatives the forward left.  A second number; `value` stays lambda = 0,
     # the default of arguments/__init__.py:94.
     sparsity = None
-    if world == 1:
+    if world == 1 and not args.main_only:
         lam = 0.1
         for i in range(5):
             train_step(i, lam)
@@ -637,7 +642,7 @@ def main():
     # stays the default mode.  (the driver's record then holds the rate of the mode a CUDA build can be
     # compared with at 1e-4.)
     reference_mode = None
-    if world == 1:
+    if world == 1 and not args.main_only:
         was_tight, was_f64 = _C.set_tight_rects(False), _C.set_f64_chain(False)
         try:
             with torch.no_grad():   # the longer lists' pair counts, per camera (and the reservation learns them)
@@ -804,8 +809,8 @@ def main():
         "step_ms_exchange_overlapped": round(overlapped_ms_per_step, 4) if overlapped_ms_per_step is not None else None,
         "overlap_frac": (round(max(0.0, min(1.0, (1e3 * elapsed / args.steps - overlapped_ms_per_step) / exchange_ms)), 3)
                          if exchange_ms and overlapped_ms_per_step else None),
-        "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1),
-        "render_fps": round(args.steps / render_s, 1),
+        "render_mpix_per_s": round(args.steps * N / render_s / 1e6, 1) if not args.main_only else None,
+        "render_fps": round(args.steps / render_s, 1) if not args.main_only else None,
         "roofline": roofline,
         # frac_of_8TBps: SURVEY 8d's reference-algorithm bytes (work this library avoids counts in its favour) -- NOT HBM
         # utilisation; frac_counter_traffic: the bytes the committed rocprofv3 counters saw move, per step, over the same time

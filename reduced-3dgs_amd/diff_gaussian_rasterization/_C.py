@@ -106,8 +106,9 @@ _lib.r3dgs_pack_view_stats.restype = _i
 _lib.r3dgs_pack_view_stats.argtypes = [_i] + [_vp] * 6
 _lib.r3dgs_reduce_shards.restype = _i
 _lib.r3dgs_reduce_shards.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
-_lib.r3dgs_reduce_shards_mixed.restype = _i
-_lib.r3dgs_reduce_shards_mixed.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
+if hasattr(_lib, "r3dgs_reduce_shards_mixed"):   # (absent from an older A/B build loaded through R3DGS_LIB)
+    _lib.r3dgs_reduce_shards_mixed.restype = _i
+    _lib.r3dgs_reduce_shards_mixed.argtypes = [_i, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp, _vp]
 _lib.r3dgs_profile_enable.argtypes = [_i]
 _lib.r3dgs_profile_stage_name.restype = C.c_char_p
 _lib.r3dgs_profile_stage_name.argtypes = [_i]
