@@ -667,6 +667,7 @@ __global__ __launch_bounds__(64, R3_BWD_OCC) void blend_bwd_kernel(BwdPassArgs* 
             dst[0] = make_float4(g.mx * half_w, g.my * half_h, g.cA, g.cB);
             dst[1] = make_float4(g.cC, g.op, g.r, g.g);
             dst[2] = make_float4(g.b, 0.f, 0.f, 0.f);
+            if (kPairStride >= 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);   // 64-byte rows: the whole burst is written
             a.pair_flag[slot] = 1;
         }
     }

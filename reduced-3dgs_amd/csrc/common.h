@@ -35,8 +35,14 @@ namespace r3 {
 constexpr size_t kAlign = 256;
 constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the backward blend:
                               // dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb
-constexpr int kAccStride = 12;  // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
-constexpr int kPairStride = 12; // floats per row of the per-pair slab: 48-B rows, written / read as three float4
+#ifndef R3_ACC_STRIDE
+#define R3_ACC_STRIDE 12
+#endif
+#ifndef R3_PAIR_STRIDE
+#define R3_PAIR_STRIDE 12
+#endif
+constexpr int kAccStride = R3_ACC_STRIDE;    // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
+constexpr int kPairStride = R3_PAIR_STRIDE;  // floats per row of the per-pair slab: 48-B rows, written / read as three float4
                                 // (36-B rows measured 2.4x write amplification: partial lines, nine dword accesses)
 
 // Per-view counters.  Every preprocess workgroup stores one PrePartial (no atomics, nothing to pre-clear: the first

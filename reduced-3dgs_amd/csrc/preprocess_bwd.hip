@@ -103,11 +103,16 @@ __device__ __forceinline__ void pair_reduce_group(const PairReduceArgs& a, uint3
         // same key <=> same run); asking the Gaussian's record for its pair range was a dependent gather per run
         const bool from_before = key == key0 && key_before == key;
         const bool into_next = lane == 63 && key_after == key;
+#ifdef R3_EXP_PR_NOSTORE   // timing experiment only (wrong results): what the scattered 48-byte run-sum stores cost --
+        // 17 of pair_reduce's 41 us at 500 k, 52 of 116 at 2 M, 152 of 282 at 6 M (profiles/r06_exp_pair_reduce_stores.txt)
+        if (v[0] != 12345.678f) return;
+#endif
         if (!from_before && !into_next) {
             float4* dst = reinterpret_cast<float4*>(a.acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
             dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+            if (kAccStride >= 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);   // 64-byte rows: the whole burst is written
         } else {
             float* wp = a.wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
             if (from_before) {  // continues a run of the previous group: this group's leading piece
@@ -151,7 +156,11 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* 
         const uint32_t e = e0 + 64u * g;
 #pragma unroll
         for (int k = 0; k < kPairGrad; k++) v[g][k] = 0.f;
+#ifdef R3_EXP_PR_NOLOAD    // timing experiment only (wrong results): what fetching the flagged slab rows costs
+        if (flag[g] && e == 0xFFFFFFF0u) {
+#else
         if (flag[g]) {  // ~1/3 of the pairs contribute; the rest of the slab is stale memory, never read
+#endif
             pair_flag[e] = 0;  // consumed: all flags are zero again when this kernel ends (next backward pass)
             const float4* src = reinterpret_cast<const float4*>(pair_grad + (size_t)e * kPairStride);
             const float4 r0 = src[0], r1 = src[1];
