@@ -1462,6 +1462,7 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         pb.tiles = geom.tiles;
         pb.acc = geom.acc;
         pb.wave_part = plan.has_pairs ? bin.wave_part : nullptr;
+        pb.pair_grad = plan.has_pairs ? bin.pair_grad : nullptr;
         pb.header = geom.header;
         pb.lambda_sh = lambda_sh_sparsity;
         pb.sh_ddir = (lambda_sh_sparsity == 0.f && sh_derivative_cache()) ? geom.sh_ddir : nullptr;

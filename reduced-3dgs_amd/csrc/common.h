@@ -41,6 +41,13 @@ constexpr int kPairGrad = 9;  // floats per (tile, Gaussian) pair parked by the 
 #ifndef R3_PAIR_STRIDE
 #define R3_PAIR_STRIDE 12
 #endif
+// floats per piece of wave_part (the leading / trailing partial run sum of a 64-pair group): 9 packed (the round-2 layout, nine
+// 4-byte stores by one lane), or 12 with -DR3_WP_VEC (experiment: three 16-byte stores and loads per piece)
+#ifdef R3_WP_VEC
+constexpr int kPieceStride = 12;
+#else
+constexpr int kPieceStride = 9;
+#endif
 constexpr int kAccStride = R3_ACC_STRIDE;    // floats per Gaussian in the reduced 2D-stage gradient row (9 used)
 constexpr int kPairStride = R3_PAIR_STRIDE;  // floats per row of the per-pair slab: 48-B rows, written / read as three float4
                                 // (36-B rows measured 2.4x write amplification: partial lines, nine dword accesses)
@@ -345,7 +352,7 @@ struct BinState {
         BinState b;
         b.point_list = c.take<uint32_t>(R);
         b.pair_grad = c.take<float>(R * kPairStride);
-        b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPairGrad);
+        b.wave_part = c.take<float>((R / 64 + 1) * 2 * kPieceStride);
         b.pair_flag = c.take<unsigned char>(R);
         if (wide == 1) {
             b.pair_rank = c.take<uint32_t>(R);
@@ -679,6 +686,7 @@ struct PreBwdArgs {       // preprocess_bwd.hip
     const uint32_t* tiles;
     const float* acc;
     const float* wave_part;
+    const float* pair_grad;   // -DR3_ACC_IN_SLAB (experiment): the run sums stay in the slab, in the row of the run's last pair
     const GeomHeader* header;
     float lambda_sh;
     const float* sh_ddir; // GeomState::sh_ddir when the backward may use it (no sparsity term, not switched off), else null

@@ -108,25 +108,49 @@ __device__ __forceinline__ void pair_reduce_group(const PairReduceArgs& a, uint3
         if (v[0] != 12345.678f) return;
 #endif
         if (!from_before && !into_next) {
+#ifdef R3_ACC_IN_SLAB   // experiment: the run sum stays where the run ends (a write next to the rows this wave just read) and the
+                        // per-Gaussian kernel gathers it by pair_start instead of reading a row this store scattered
+            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(a.pair_grad) + (size_t)e * kPairStride);
+#else
             float4* dst = reinterpret_cast<float4*>(a.acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
+#endif
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
             dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
             if (kAccStride >= 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);   // 64-byte rows: the whole burst is written
         } else {
-            float* wp = a.wave_part + (size_t)(e >> 6) * 2 * kPairGrad;
+            float* wp = a.wave_part + (size_t)(e >> 6) * 2 * kPieceStride;
+#ifdef R3_WP_VEC
+            if (from_before) {  // continues a run of the previous group: this group's leading piece
+                float4* w4 = reinterpret_cast<float4*>(wp);
+                w4[0] = make_float4(v[0], v[1], v[2], v[3]);
+                w4[1] = make_float4(v[4], v[5], v[6], v[7]);
+                w4[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+            }
+            if (into_next) {  // continues into the next group: trailing piece
+                float4* w4 = reinterpret_cast<float4*>(wp + kPieceStride);
+                w4[0] = make_float4(v[0], v[1], v[2], v[3]);
+                w4[1] = make_float4(v[4], v[5], v[6], v[7]);
+                w4[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+            }
+#else
             if (from_before) {  // continues a run of the previous group: this group's leading piece
 #pragma unroll
                 for (int k = 0; k < kPairGrad; k++) wp[k] = v[k];
             }
             if (into_next) {  // continues into the next group: trailing piece
 #pragma unroll
-                for (int k = 0; k < kPairGrad; k++) wp[kPairGrad + k] = v[k];
+                for (int k = 0; k < kPairGrad; k++) wp[kPieceStride + k] = v[k];
             }
+#endif
         }
     }
 }
 
+// R3_PR_WAVES (experiment): waves per SIMD the register allocation is held to (80 VGPRs = 6 by default)
+#ifdef R3_PR_WAVES
+__attribute__((amdgpu_waves_per_eu(R3_PR_WAVES, R3_PR_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void pair_reduce_kernel(const PairReduceArgs* __restrict__ ap)
 {
     const PairReduceArgs a = *ap;
@@ -269,20 +293,39 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
             const uint32_t last = start + ntile - 1u;
             const uint32_t w0 = start >> 6, w1 = last >> 6;
             if (w0 == w1) {
+#ifdef R3_ACC_IN_SLAB
+                const float4* ap = reinterpret_cast<const float4*>(a.pair_grad + (size_t)last * kPairStride);
+#else
                 const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
+#endif
                 const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
                 acc9[0] = a0.x; acc9[1] = a0.y; acc9[2] = a0.z; acc9[3] = a0.w;
                 acc9[4] = a1.x; acc9[5] = a1.y; acc9[6] = a1.z; acc9[7] = a1.w;
                 acc9[8] = a2.x;
             } else {
-                const float* wp = a.wave_part + (size_t)w0 * 2 * kPairGrad + kPairGrad;  // trailing piece of w0
+#ifdef R3_WP_VEC
+                const float4* w4 = reinterpret_cast<const float4*>(a.wave_part + (size_t)w0 * 2 * kPieceStride + kPieceStride);
+                float4 p0 = w4[0], p1 = w4[1], p2 = w4[2];
+                acc9[0] = p0.x; acc9[1] = p0.y; acc9[2] = p0.z; acc9[3] = p0.w;
+                acc9[4] = p1.x; acc9[5] = p1.y; acc9[6] = p1.z; acc9[7] = p1.w;
+                acc9[8] = p2.x;
+                for (uint32_t w = w0 + 1; w <= w1; w++) {  // leading piece of every following group
+                    w4 = reinterpret_cast<const float4*>(a.wave_part + (size_t)w * 2 * kPieceStride);
+                    p0 = w4[0]; p1 = w4[1]; p2 = w4[2];
+                    acc9[0] += p0.x; acc9[1] += p0.y; acc9[2] += p0.z; acc9[3] += p0.w;
+                    acc9[4] += p1.x; acc9[5] += p1.y; acc9[6] += p1.z; acc9[7] += p1.w;
+                    acc9[8] += p2.x;
+                }
+#else
+                const float* wp = a.wave_part + (size_t)w0 * 2 * kPieceStride + kPieceStride;  // trailing piece of w0
 #pragma unroll
                 for (int k = 0; k < kPairGrad; k++) acc9[k] = wp[k];
                 for (uint32_t w = w0 + 1; w <= w1; w++) {  // leading piece of every following group
-                    wp = a.wave_part + (size_t)w * 2 * kPairGrad;
+                    wp = a.wave_part + (size_t)w * 2 * kPieceStride;
 #pragma unroll
                     for (int k = 0; k < kPairGrad; k++) acc9[k] += wp[k];
                 }
+#endif
             }
             g2x = acc9[0];
             g2y = acc9[1];
