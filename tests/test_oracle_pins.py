@@ -134,3 +134,20 @@ def test_cov3d_matches_reference_python_covariance(golden_dir, mod):
     b = orc.forward(scales=None, rotations=None, cov3D_precomp=want, **args)
     assert np.array_equal(a["radii"], b["radii"]) or (a["radii"] != b["radii"]).mean() < 0.01   # 1-ulp cov differences
     assert np.abs(a["color"] - b["color"]).max() < 1e-4
+
+
+def test_contraction_probe_small_case(tmp_path):
+    """tools/contraction_flips.py on configs[0]: the oracle built with FMA contraction allowed (what nvcc does to the
+    reference's expressions) against the default build, seen from a rotated camera -- radii and tile counts agree, a good
+    part of the depth keys differs in its last bits.  Keeps the tool that INTEGRATION.md section 5's table comes from alive."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "contraction_flips.py"), "cfg0_10k_400"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["workload"] == "cfg0_10k_400" and d["radii_differ"] == 0 and d["tiles_touched_differ"] == 0
+    assert d["num_rendered"][0] == d["num_rendered"][1] and d["list_ids_differ"] == 0
+    assert 0 < d["depth_bits_differ"] < d["visible"]

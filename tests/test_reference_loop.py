@@ -1,7 +1,8 @@
 """The reference's OWN training loop on this repository's drop-in packages (VERDICT r1, row g: "train.py / render.py
 run unmodified").  Needs a GPU AND a checkout of graphdeco-inria/reduced-3dgs (R3DGS_REFERENCE=/path, default
 /root/reference): the reference never ships with this repository, so the test skips cleanly without it -- on the
-authoring container there is no GPU, on the GPU box there is no reference; it is here for whoever has both:
+authoring container there is no GPU, on the GPU box there is no reference; it is here for whoever has both (what CAN run
+where only the reference exists -- the call signatures of every operator, against stubs -- is tests/test_reference_call_sites.py):
 
     R3DGS_REFERENCE=/path/to/reduced-3dgs python -m pytest tests/test_reference_loop.py -m gpu -q
 
