@@ -102,7 +102,10 @@ static_assert(sizeof(PassInfo) == 32, "PassInfo = 32 B");
 constexpr int kMinDepthBuckets = 1024;
 constexpr int kMaxDepthBuckets = 16384;
 constexpr int kBucketCap = 4096;     // (key, id) pairs one workgroup sorts in LDS (32 KB)
-constexpr int kHistBatch = 4096;     // Gaussians a histogram / scatter workgroup handles per round (16 per thread)
+#ifndef R3_HIST_BATCH
+#define R3_HIST_BATCH 4096
+#endif
+constexpr int kHistBatch = R3_HIST_BATCH;   // Gaussians a histogram / scatter workgroup handles per round (16 per thread)
 // Gaussians per histogram / scatter workgroup: rounds of kHistBatch, as many as keep the row count near 256 (one
 // workgroup per CU: their nb-entry LDS tables leave room for no more at large nb).  Every such workgroup carries
 // nb-entry tables (its histogram row, its scan of the bucket totals), so with a fixed 4096 Gaussians per workgroup
