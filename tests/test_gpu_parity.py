@@ -434,8 +434,13 @@ def unit_list_fit(pairs, gx, gy, block=4, lists=8):
     dict(P=20_000, W=640, H=360, f=400.0, cam_seed=3, gseed=4, degree_mode="mixed", scale_mu=0.02),
     dict(P=3_000, W=333, H=77, f=200.0, cam_seed=None, gseed=1, degree_mode="all3", scale_mu=0.05),
     dict(P=500_000, W=1600, H=1062, f=1200.0, cam_seed=None, gseed=0, degree_mode="all3", scale_mu=0.012),
-    dict(P=6_000, W=2064, H=1100, f=1500.0, cam_seed=None, gseed=2, degree_mode="all0", scale_mu=0.03),   # 8901 tiles: the
-], ids=["20k_mixed", "ragged_333x77", "metric_500k_1600x1062", "8901_tiles"])                             # re-reading path
+    # the order kernel keeps 1 / 2 / 8 tiles per thread in registers (unit_order_kernel<KEEP>, round 6) or re-reads: one case
+    # per instantiation -- 8901 tiles = 1200 slots per list (<2>), a 4K image = 4080 slots (<8>), an 8K image = 16 208 slots
+    # (<8>, re-reading)
+    dict(P=6_000, W=2064, H=1100, f=1500.0, cam_seed=None, gseed=2, degree_mode="all0", scale_mu=0.03),
+    dict(P=8_000, W=3840, H=2160, f=2800.0, cam_seed=None, gseed=3, degree_mode="all0", scale_mu=0.03),
+    dict(P=8_000, W=7680, H=4320, f=5600.0, cam_seed=None, gseed=4, degree_mode="all0", scale_mu=0.03),
+], ids=["20k_mixed", "ragged_333x77", "metric_500k_1600x1062", "8901_tiles", "32400_tiles_4K", "129600_tiles_8K"])
 def test_backward_tile_order_changes_no_bit(C_, kw):
     """The backward blend starts its tiles heaviest first (set_tile_order, on by default).  Every tile's arithmetic is its
     own, so every gradient must equal the row-major launch's bit for bit; and the weight the order is built from must be
