@@ -454,6 +454,30 @@ void hc_lane_variants(int W, int H, const unsigned* ranges, const unsigned* poin
         }
 }
 
+// How many list entries a TILE-level region test (the blend kernels' region_may_contribute over the whole 16x16 tile) would
+// drop before they are binned (design aid, round 6): out[0] = list entries, out[1] = entries whose tile test says "cannot
+// contribute", out[2] = of those, entries of Gaussians whose rect has at most 32 tiles (a 32-bit mask could carry the decision).
+void hc_tile_test_stats(int W, int H, const unsigned* ranges, const unsigned* point_list, const float* xy, const float* rgb,
+                        const float* conic_op, const unsigned* tiles_of_gaussian, long* out)
+{
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    out[0] = out[1] = out[2] = 0;
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const int tile = ty * gx + tx;
+            for (unsigned k = ranges[2 * tile]; k < ranges[2 * tile + 1]; k++) {
+                const unsigned id = point_list[k];
+                const Splat s = splat_of(xy, conic_op, rgb, id);
+                const bool keep = region_may_contribute(s, (float)(tx * 16), (float)(tx * 16 + 15), (float)(ty * 16), (float)(ty * 16 + 15));
+                out[0]++;
+                if (!keep) {
+                    out[1]++;
+                    if (tiles_of_gaussian[id] <= 32u) out[2]++;
+                }
+            }
+        }
+}
+
 // acc: double[P][9] = mx, my, cA, cB, cC, op, r, g, b  (mx,my already scaled by 0.5W / 0.5H)
 void hc_blend_bwd(int P, int W, int H, const unsigned* ranges, const unsigned* point_list, const float* bg,
                   const float* xy, const float* conic_op, const float* rgb, const float* final_T,
