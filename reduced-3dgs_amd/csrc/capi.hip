@@ -25,6 +25,7 @@
 #include <time.h>
 
 #include <atomic>
+#include <random>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -1435,6 +1436,16 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         pr.tiles = geom.tiles;
         pr.acc = geom.acc;
         pr.wave_part = bin.wave_part;
+        {   // this pass's stamp: a 64-bit counter that starts at a random value per process -- no row left by an earlier
+            // pass of this or of another process (recycled device memory) can carry it
+            static std::atomic<unsigned long long> stamp{[] {
+                std::random_device rd;
+                return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ 0x9E3779B97F4A7C15ull;
+            }()};
+            const unsigned long long st = stamp.fetch_add(1);
+            pr.stamp0 = (uint32_t)st;
+            pr.stamp1 = (uint32_t)(st >> 32);
+        }
         PreBwdArgs& pb = a.pre;
         FwdInputs& in = pb.in;
         in.P = P;
@@ -1463,6 +1474,8 @@ int r3dgs_backward(int P, const int* D, int M, int R, const float* background, i
         pb.acc = geom.acc;
         pb.wave_part = plan.has_pairs ? bin.wave_part : nullptr;
         pb.pair_grad = plan.has_pairs ? bin.pair_grad : nullptr;
+        pb.stamp0 = pr.stamp0;
+        pb.stamp1 = pr.stamp1;
         pb.header = geom.header;
         pb.lambda_sh = lambda_sh_sparsity;
         pb.sh_ddir = (lambda_sh_sparsity == 0.f && sh_derivative_cache()) ? geom.sh_ddir : nullptr;

@@ -163,7 +163,8 @@ struct GeomState {
     unsigned long long* hist_rows;  // [rows][nb + 1]  per-workgroup (tile sum << 24 | count) histograms
     uint32_t* hist_base;            // [rows][nb + 1]  first slot of each workgroup inside each bucket
     GRec* rec;            // [P]
-    float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward)
+    float* acc;           // [P * kAccStride]  per-Gaussian sums of the per-pair gradients (backward): 9 sums, then the 64-bit stamp of
+                          // the backward pass that wrote the row (a row without the current stamp reads as zeros)
     ushort4* rect;        // [P]  tile rect (minx, miny, maxx, maxy)
     uint32_t* depth_key;  // [P]  float bits of view depth, 0xFFFFFFFF when culled
     uint32_t* tiles;      // [P]  tiles_touched
@@ -680,6 +681,10 @@ struct PairReduceArgs {   // preprocess_bwd.hip
     const uint32_t* tiles;
     float* acc;
     float* wave_part;
+    uint32_t stamp0, stamp1;   // this backward pass's stamp (process nonce, pass number): a run whose nine sums are all zero
+                               // -- a third of the visible Gaussians of the metric scene: nothing contributed in any of their
+                               // tiles -- stores NO row; a stored row carries the stamp in its pad words and the per-Gaussian
+                               // kernel reads a row without this pass's stamp as zeros (preprocess_bwd.hip)
 };
 struct PreBwdArgs {       // preprocess_bwd.hip
     FwdInputs in;
@@ -690,6 +695,7 @@ struct PreBwdArgs {       // preprocess_bwd.hip
     const float* acc;
     const float* wave_part;
     const float* pair_grad;   // -DR3_ACC_IN_SLAB (experiment): the run sums stay in the slab, in the row of the run's last pair
+    uint32_t stamp0, stamp1;  // as PairReduceArgs
     const GeomHeader* header;
     float lambda_sh;
     const float* sh_ddir; // GeomState::sh_ddir when the backward may use it (no sparsity term, not switched off), else null

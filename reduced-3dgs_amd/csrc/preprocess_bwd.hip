@@ -114,10 +114,25 @@ __device__ __forceinline__ void pair_reduce_group(const PairReduceArgs& a, uint3
 #else
             float4* dst = reinterpret_cast<float4*>(a.acc + (size_t)gid * kAccStride);   // 48-B row: three 16-B stores
 #endif
+#ifndef R3_NO_ZERO_ROW_SKIP
+            // A run without a contributing pair (all nine sums exactly zero: a third of the visible Gaussians of the metric scene,
+            // more in a densified one) stores nothing: the reader takes a row that does not carry THIS pass's stamp for zeros.
+            // 40-54 % of this kernel is these scattered stores (profiles/r06_exp_pair_reduce_stores.txt); pair_reduce 41 -> 39 us
+            // at 500 k, 127 -> 92 at 2 M, 282 -> 187 at 6 M.  -DR3_NO_ZERO_ROW_SKIP: every run stores its row (A/B builds).
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < kPairGrad; k++) nz |= v[k] != 0.f;
+            if (nz) {
+                dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+                dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                dst[2] = make_float4(v[8], __uint_as_float(a.stamp0), __uint_as_float(a.stamp1), 0.f);
+            }
+#else
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
             dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
             if (kAccStride >= 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);   // 64-byte rows: the whole burst is written
+#endif
         } else {
             float* wp = a.wave_part + (size_t)(e >> 6) * 2 * kPieceStride;
 #ifdef R3_WP_VEC
@@ -298,7 +313,11 @@ __global__ __launch_bounds__(kBwdBlock) void preprocess_bwd_kernel(const PreBwdA
 #else
                 const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)i * kAccStride);
 #endif
-                const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+                float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+#ifndef R3_NO_ZERO_ROW_SKIP
+                if (__float_as_uint(a2.y) != a.stamp0 || __float_as_uint(a2.z) != a.stamp1)   // not written by this pass: zeros
+                    a0 = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 acc9[0] = a0.x; acc9[1] = a0.y; acc9[2] = a0.z; acc9[3] = a0.w;
                 acc9[4] = a1.x; acc9[5] = a1.y; acc9[6] = a1.z; acc9[7] = a1.w;
                 acc9[8] = a2.x;
